@@ -1,0 +1,77 @@
+"""ctypes binding of libcassie2d.so (the HIP extension).  No fallback: if the library is
+missing or no HIP device is present the import / create call raises."""
+import ctypes as ct
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class CassieVecConfig(ct.Structure):
+    _fields_ = [("env_kind", ct.c_int), ("control_mode", ct.c_int), ("n_substeps", ct.c_int),
+                ("flags", ct.c_int), ("auto_reset", ct.c_int)]
+
+
+EXPORTS = [
+    # legacy ABI (include/cassie2d.h)
+    "Cassie2dInit", "Reset", "StepOsc", "StepTorque", "StepJacobian", "StepPd", "GetGeneralState",
+    "GetOperationalSpaceState", "Display", "Render",
+    # batched ABI (include/cassie_vec.h)
+    "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
+    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecSetTrajectory", "CassieVecReset", "CassieVecResetTo",
+    "CassieVecStep", "CassieVecSubstep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
+    "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
+    "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
+]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the HIP extension; raises OSError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise OSError("HIP extension %s is missing: run `python -m cassierl_amd.build` (needs hipcc); "
+                      "cassierl_amd has no CPU fallback" % path)
+    # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both own the GPU.
+    # Importing torch first makes the dynamic loader bind libcassie2d.so to the runtime torch already loaded
+    # (same SONAME), so tensors, streams and our kernels share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ct.CDLL(path)
+    vp, dp, u8p = ct.c_void_p, ct.c_void_p, ct.c_void_p
+    L.CassieVecCreate.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, ct.c_int, ct.POINTER(CassieVecConfig)]
+    L.CassieVecFree.argtypes = [vp]
+    L.CassieVecFree.restype = None
+    L.CassieVecLastError.argtypes = [vp]
+    L.CassieVecLastError.restype = ct.c_char_p
+    L.CassieVecNumEnvs.argtypes = [vp]
+    L.CassieVecActionDim.argtypes = [vp]
+    L.CassieVecSetStream.argtypes = [vp, vp]
+    L.CassieVecSynchronize.argtypes = [vp]
+    L.CassieVecSetTrajectory.argtypes = [vp, dp, dp, ct.c_int]
+    L.CassieVecReset.argtypes = [vp, u8p, dp]
+    L.CassieVecResetTo.argtypes = [vp, u8p, dp, dp, dp]
+    L.CassieVecStep.argtypes = [vp, dp, dp, dp, u8p, dp]
+    L.CassieVecSubstep.argtypes = [vp, ct.c_int, dp, ct.c_int]
+    L.CassieVecGetState.argtypes = [vp, dp, dp]
+    L.CassieVecGetOpState.argtypes = [vp, dp]
+    L.CassieVecStatePtr.argtypes = [vp]
+    L.CassieVecStatePtr.restype = ct.c_void_p
+    L.CassieVecStepHost.argtypes = [vp, dp, dp, dp, u8p]
+    L.CassieVecGetStateHost.argtypes = [vp, dp, dp]
+    L.CassieVecSetStateHost.argtypes = [vp, dp]
+    L.CassieVecGetFullStateHost.argtypes = [vp, dp]
+    L.CassieVecDebugSubstepHost.argtypes = [vp, ct.c_int, dp, dp]
+    L.CassieVecTimeSteps.argtypes = [vp, dp, ct.c_int, dp, dp, u8p, ct.POINTER(ct.c_float)]
+    L.Cassie2dInit.restype = ct.c_void_p
+    _LIB = L
+    return L

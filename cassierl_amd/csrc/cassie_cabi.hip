@@ -1,0 +1,351 @@
+// cassie_cabi.hip -- host side of libcassie2d.so: the C-ABI of include/cassie2d.h (legacy, batch-of-one)
+// and include/cassie_vec.h (batched) on top of the kernels in cassie_kernels.hip.
+// There is no CPU code path here: every entry point launches HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cassie2d.h"
+#include "../../include/cassie_vec.h"
+#include "cassie_kernels.hip"
+
+static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
+static_assert(sizeof(StateGeneral) == 208 && sizeof(StateOperationalSpace) == 144 && sizeof(ControllerOsc) == 56 &&
+                  sizeof(ControllerPd) == 48 && sizeof(ControllerTorque) == 48 && sizeof(ControllerForce) == 48,
+              "ABI struct sizes (RobotInterface.h:14-50)");
+
+struct CassieVec {
+  int n = 0, device = 0;
+  CassieVecConfig cfg{};
+  hipStream_t stream = nullptr;
+  double* state = nullptr;
+  double* traj_qpos = nullptr;
+  double traj_tmax = 0.0;
+  int traj_n = 0;
+  // scratch for the host-pointer conveniences
+  double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
+  uint8_t* d_done = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace {
+
+int fail(CassieVec* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(h, CASSIE_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
+
+cassie::VecParams make_params(CassieVec* h) {
+  cassie::VecParams p{};
+  p.state = h->state;
+  p.n_envs = h->n;
+  p.adim = adim_of(h->cfg.control_mode);
+  p.n_sub = h->cfg.n_substeps;
+  p.flags = h->cfg.flags;
+  p.env_kind = h->cfg.env_kind;
+  p.auto_reset = h->cfg.auto_reset;
+  p.traj_qpos = h->traj_qpos;
+  p.traj_tmax = h->traj_tmax;
+  p.traj_n = h->traj_n;
+  return p;
+}
+
+int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
+  dim3 grid(h->n), block(64);
+  if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL(cassie::env_step_kernel<0>, grid, block, 0, h->stream, p);
+  else if (mode == CASSIE_CTRL_TORQUE) hipLaunchKernelGGL(cassie::env_step_kernel<1>, grid, block, 0, h->stream, p);
+  else return fail(h, CASSIE_EINVAL, "control mode %d has no HIP kernel in this build (OSC / Jacobian: later round)", mode);
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+// reset_mode: 0 = Cassie2dEnv.reset pose, 1 = states from arrays, 2 = keep state (mj_forward only)
+int launch_reset(CassieVec* h, const uint8_t* mask, const double* q, const double* v, double* obs, bool keep) {
+  cassie::VecParams p = make_params(h);
+  p.obs = obs;
+  if (keep) {
+    // forward only: feed the current state back in as the "new" state
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(cassie::get_state_kernel, dim3((h->n * 13 + 255) / 256), dim3(256), 0, h->stream, h->state, h->n, h->d_q, h->d_v);
+    q = h->d_q; v = h->d_v;
+  }
+  hipLaunchKernelGGL(cassie::env_reset_kernel, dim3(h->n), dim3(64), 0, h->stream, p, mask, q, v);
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConfig* cfg) {
+  if (!out || n_envs <= 0) return CASSIE_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "libcassie2d: no HIP device available; this library has no CPU path\n");
+    return CASSIE_ENODEVICE;
+  }
+  if (device < 0 || device >= ndev) return CASSIE_EINVAL;
+  CassieVec* h = new CassieVec();
+  h->n = n_envs; h->device = device;
+  if (cfg) h->cfg = *cfg;
+  else { h->cfg.env_kind = CASSIE_ENV_WALK; h->cfg.control_mode = CASSIE_CTRL_PD; h->cfg.n_substeps = 10; h->cfg.flags = 0; h->cfg.auto_reset = 1; }
+  if (h->cfg.n_substeps <= 0) h->cfg.n_substeps = 10;
+  auto bail = [&](int code) { CassieVecFree(h); return code; };
+  if (hipSetDevice(device) != hipSuccess) return bail(CASSIE_EHIP);
+  size_t n = (size_t)n_envs;
+  if (hipMalloc(&h->state, n * cassie::ENV_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_act, n * 7 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_obs, n * 26 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_rew, n * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_done, n) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_q, n * 18 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_v, n * 13 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
+  // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
+  hipLaunchKernelGGL(cassie::env_init_kernel, dim3((n_envs * cassie::ENV_STRIDE + 255) / 256), dim3(256), 0, h->stream, h->state, n_envs);
+  if (launch_reset(h, nullptr, nullptr, nullptr, nullptr, true) != CASSIE_OK) return bail(CASSIE_EHIP);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
+  *out = h;
+  return CASSIE_OK;
+}
+
+void CassieVecFree(CassieVec* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipFree(h->state); hipFree(h->traj_qpos); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  delete h;
+}
+
+const char* CassieVecLastError(const CassieVec* h) { return h ? h->err.c_str() : "null handle"; }
+int CassieVecNumEnvs(const CassieVec* h) { return h ? h->n : 0; }
+int CassieVecActionDim(const CassieVec* h) { return h ? adim_of(h->cfg.control_mode) : 0; }
+int CassieVecSetStream(CassieVec* h, void* s) { if (!h) return CASSIE_EINVAL; h->stream = (hipStream_t)s; return CASSIE_OK; }
+int CassieVecSynchronize(CassieVec* h) { if (!h) return CASSIE_EINVAL; HIPCHK(h, hipStreamSynchronize(h->stream)); return CASSIE_OK; }
+void* CassieVecStatePtr(CassieVec* h) { return h ? h->state : nullptr; }
+
+int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* qpos_host, int n) {
+  if (!h || !time_host || !qpos_host || n <= 0) return fail(h, CASSIE_EINVAL, "bad trajectory");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->traj_qpos) hipFree(h->traj_qpos);
+  HIPCHK(h, hipMalloc(&h->traj_qpos, (size_t)n * 13 * sizeof(double)));
+  HIPCHK(h, hipMemcpy(h->traj_qpos, qpos_host, (size_t)n * 13 * sizeof(double), hipMemcpyHostToDevice));
+  h->traj_tmax = time_host[n - 1];  // cassie2d_trajectory.py:17
+  h->traj_n = n;
+  return CASSIE_OK;
+}
+
+int CassieVecReset(CassieVec* h, const uint8_t* mask_dev, double* obs_dev) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  return launch_reset(h, mask_dev, nullptr, nullptr, obs_dev, false);
+}
+
+int CassieVecResetTo(CassieVec* h, const uint8_t* mask_dev, const double* qpos_dev, const double* qvel_dev, double* obs_dev) {
+  if (!h || !qpos_dev) return fail(h, CASSIE_EINVAL, "qpos_dev is required");
+  HIPCHK(h, hipSetDevice(h->device));
+  return launch_reset(h, mask_dev, qpos_dev, qvel_dev, obs_dev, false);
+}
+
+int CassieVecStep(CassieVec* h, const double* actions_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, double* terminal_obs_dev) {
+  if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(h, CASSIE_EINVAL, "null argument");
+  if (h->cfg.env_kind == CASSIE_ENV_WALK && !h->traj_qpos) return fail(h, CASSIE_EINVAL, "walk env needs CassieVecSetTrajectory first");
+  HIPCHK(h, hipSetDevice(h->device));
+  cassie::VecParams p = make_params(h);
+  p.actions = actions_dev; p.obs = obs_dev; p.reward = reward_dev; p.done = done_dev; p.terminal_obs = terminal_obs_dev;
+  return launch_step(h, h->cfg.control_mode, p);
+}
+
+int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, int n_sub) {
+  if (!h || !actions_dev || n_sub <= 0) return fail(h, CASSIE_EINVAL, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  cassie::VecParams p = make_params(h);
+  p.actions = actions_dev; p.adim = adim_of(control_mode); p.n_sub = n_sub; p.obs = nullptr;
+  return launch_step(h, control_mode, p);
+}
+
+int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(cassie::get_state_kernel, dim3((h->n * 13 + 255) / 256), dim3(256), 0, h->stream, h->state, h->n, qpos_dev, qvel_dev);
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+int CassieVecGetOpState(CassieVec* h, double* x18_dev) {
+  if (!h || !x18_dev) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  cassie::VecParams p = make_params(h);
+  hipLaunchKernelGGL(cassie::env_opstate_kernel, dim3(h->n), dim3(64), 0, h->stream, p, x18_dev);
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+int CassieVecStepHost(CassieVec* h, const double* a, double* obs, double* rew, uint8_t* done) {
+  if (!h || !a) return CASSIE_EINVAL;
+  size_t n = h->n;
+  int ad = adim_of(h->cfg.control_mode);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_act, a, n * ad * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = CassieVecStep(h, h->d_act, h->d_obs, h->d_rew, h->d_done, nullptr);
+  if (rc) return rc;
+  if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, n * 26 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (rew) HIPCHK(h, hipMemcpyAsync(rew, h->d_rew, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int CassieVecGetStateHost(CassieVec* h, double* q, double* v) {
+  if (!h) return CASSIE_EINVAL;
+  int rc = CassieVecGetState(h, h->d_q, h->d_v);
+  if (rc) return rc;
+  size_t n = h->n;
+  if (q) HIPCHK(h, hipMemcpyAsync(q, h->d_q, n * 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (v) HIPCHK(h, hipMemcpyAsync(v, h->d_v, n * 13 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int CassieVecSetStateHost(CassieVec* h, const double* s) {
+  if (!h || !s) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->state, s, (size_t)h->n * cassie::ENV_STRIDE * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int CassieVecGetFullStateHost(CassieVec* h, double* s) {
+  if (!h || !s) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(s, h->state, (size_t)h->n * cassie::ENV_STRIDE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int CassieVecDebugSubstepHost(CassieVec* h, int control_mode, const double* a, double* dbg_host) {
+  if (!h || !a || !dbg_host) return CASSIE_EINVAL;
+  size_t n = h->n;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->d_dbg) HIPCHK(h, hipMalloc(&h->d_dbg, n * cassie::DBG_STRIDE * sizeof(double)));
+  HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, n * cassie::DBG_STRIDE * sizeof(double), h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_act, a, n * adim_of(control_mode) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  cassie::VecParams p = make_params(h);
+  p.actions = h->d_act; p.adim = adim_of(control_mode); p.n_sub = 1; p.obs = nullptr; p.debug = h->d_dbg;
+  int rc = launch_step(h, control_mode, p);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(dbg_host, h->d_dbg, n * cassie::DBG_STRIDE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int CassieVecTimeSteps(CassieVec* h, const double* actions_dev, int steps, double* obs_dev, double* reward_dev, uint8_t* done_dev, float* avg_ms) {
+  if (!h || steps <= 0 || !avg_ms) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < steps; i++) {
+    int rc = CassieVecStep(h, actions_dev, obs_dev, reward_dev, done_dev, nullptr);
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = ms / steps;
+  return CASSIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ legacy ABI
+struct Cassie2d {
+  CassieVec* vec;
+  bool display;
+};
+
+static void legacy_die(const char* what, CassieVec* v) {
+  fprintf(stderr, "libcassie2d: %s: %s\n", what, v ? CassieVecLastError(v) : "");
+  abort();  // the reference exits the process on init failure too (Cassie2d.cpp:49-52)
+}
+
+Cassie2d* Cassie2dInit(void) {
+  CassieVecConfig cfg{};
+  cfg.env_kind = CASSIE_ENV_STAND; cfg.control_mode = CASSIE_CTRL_PD; cfg.n_substeps = 1; cfg.flags = 0; cfg.auto_reset = 0;
+  CassieVec* v = nullptr;
+  int rc = CassieVecCreate(&v, 1, 0, &cfg);
+  if (rc != CASSIE_OK) { fprintf(stderr, "libcassie2d: Cassie2dInit failed (%d): no usable MI355X/HIP device\n", rc); abort(); }
+  Cassie2d* c = new Cassie2d();
+  c->vec = v; c->display = false;
+  return c;
+}
+
+void Reset(Cassie2d* c, StateGeneral* s) {
+  double q[13], v[13];
+  for (int i = 0; i < 3; i++) { q[i] = s->base_pos[i]; v[i] = s->base_vel[i]; }
+  for (int i = 0; i < 5; i++) { q[3 + i] = s->left_pos[i]; v[3 + i] = s->left_vel[i]; q[8 + i] = s->right_pos[i]; v[8 + i] = s->right_vel[i]; }
+  CassieVec* h = c->vec;
+  if (hipMemcpy(h->d_q, q, sizeof q, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(h->d_v, v, sizeof v, hipMemcpyHostToDevice) != hipSuccess)
+    legacy_die("Reset copy", h);
+  if (launch_reset(h, nullptr, h->d_q, h->d_v, nullptr, false)) legacy_die("Reset", h);
+  if (CassieVecSynchronize(h)) legacy_die("Reset sync", h);
+}
+
+static void legacy_step(Cassie2d* c, int mode, const double* a, int adim) {
+  CassieVec* h = c->vec;
+  if (hipMemcpy(h->d_act, a, adim * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) legacy_die("Step copy", h);
+  if (CassieVecSubstep(h, mode, h->d_act, 1)) legacy_die("Step", h);
+  if (CassieVecSynchronize(h)) legacy_die("Step sync", h);
+}
+
+void StepTorque(Cassie2d* c, ControllerTorque* a) { legacy_step(c, CASSIE_CTRL_TORQUE, a->torques, 6); }
+void StepPd(Cassie2d* c, ControllerPd* a) { legacy_step(c, CASSIE_CTRL_PD, a->angles, 6); }
+void StepOsc(Cassie2d* c, ControllerOsc* a) { legacy_step(c, CASSIE_CTRL_OSC, a->body_xdd, 7); }
+void StepJacobian(Cassie2d* c, ControllerForce* a) { legacy_step(c, 3, a->left_force, 6); }
+
+void GetGeneralState(Cassie2d* c, StateGeneral* s) {
+  double q[13], v[13];
+  if (CassieVecGetStateHost(c->vec, q, v)) legacy_die("GetGeneralState", c->vec);
+  for (int i = 0; i < 3; i++) { s->base_pos[i] = q[i]; s->base_vel[i] = v[i]; }
+  for (int i = 0; i < 5; i++) { s->left_pos[i] = q[3 + i]; s->left_vel[i] = v[3 + i]; s->right_pos[i] = q[8 + i]; s->right_vel[i] = v[8 + i]; }
+}
+
+void GetOperationalSpaceState(Cassie2d* c, StateOperationalSpace* s) {
+  double x[18];
+  CassieVec* h = c->vec;
+  if (CassieVecGetOpState(h, h->d_q)) legacy_die("GetOperationalSpaceState", h);
+  if (hipMemcpy(x, h->d_q, sizeof x, hipMemcpyDeviceToHost) != hipSuccess) legacy_die("GetOperationalSpaceState copy", h);
+  // only elements [0],[1] of each vector and body_x[2]/body_xd[2] are written (Cassie2d.cpp:225-235, quirk Q4)
+  for (int i = 0; i < 2; i++) {
+    s->body_x[i] = x[i]; s->body_xd[i] = x[3 + i];
+    s->left_x[i] = x[6 + i]; s->left_xd[i] = x[9 + i];
+    s->right_x[i] = x[12 + i]; s->right_xd[i] = x[15 + i];
+  }
+  s->body_x[2] = x[2]; s->body_xd[2] = x[5];
+}
+
+void Display(Cassie2d* c, bool display) { c->display = display; }
+void Render(Cassie2d*) {}
+
+}  // extern "C"

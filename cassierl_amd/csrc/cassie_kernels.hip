@@ -1,0 +1,727 @@
+// cassie_kernels.hip -- MI355X (gfx950) kernels for the batched Cassie2d hot path.
+//
+// One wavefront (64 lanes) per environment instance, one wavefront per workgroup.
+// The generalised-coordinate state and every per-step intermediate live in LDS / VGPRs
+// for all n_sub physics substeps of one Env.step(); HBM is touched once on entry
+// (state + action, one coalesced 640-byte read) and once on exit (state, obs, reward, done).
+//
+// What one substep computes (reference call sites):
+//   Cassie2d::StepPd / Step        src/Cassie2d/Cassie2d.cpp:86-117   (controller law + mj_step)
+//   mj_step (MuJoCo Pro 1.50, PGS / elliptic / Euler; model/cassie2d_stiff.xml:5)
+//   GetOperationalSpaceState       src/Cassie2d/Cassie2d.cpp:218-237
+//   Cassie2dEnv.step / reset       rllab/envs/cassie2d.py:78-225, cassie_stand2d.py:72-137
+//
+// Formulation: sagittal-plane reduction (tables in cassie2d_planar.h, derived offline from
+// model/cassie2d_stiff.xml).  Lane roles inside the wave:
+//   link lanes  0..10   planar FK of the 11 links (angle, origin, COM, inertial force)
+//   dof  lanes  d = lane&15 < 13 in 16-lane groups 0 and 1: group 0 carries M, group 1 carries
+//               M + h*diag(damping); both are inverted by the same in-register Gauss-Jordan
+//               instruction stream (DPP row broadcasts of the pivot row)
+//   row  lanes  0..45   one FIXED constraint slot per lane (4 connect rows, 8 joint-limit rows,
+//               17 contact (normal,tangent) pairs in MuJoCo's contact order); lane i keeps row i of
+//               A = J M^-1 J' + R in registers and its own residual, so a PGS row update is
+//               "owner lane computes delta -> v_readlane -> one FMA on every lane".
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cassie2d_planar.h"
+#include "cassie_vec_layout.h"
+
+namespace cassie {
+
+constexpr int NV = CP_NV, NL = CP_NLINK, NU = CP_NU, NSLOT = CP_NSLOT;
+constexpr int SLOT_LIM = 4, SLOT_CON = 12;
+constexpr double MINVAL = 1e-15;
+constexpr double H = CP_TIMESTEP;
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
+
+__device__ __forceinline__ double rdlane(double x, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// broadcast lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
+template <int K> __device__ __forceinline__ double row_bcast(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// exchange with lane^1 (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ double swap1(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }  // single-wave workgroup: fence only
+
+struct Smem {
+  double q[16], v[16], ws[16], kq[16], kv[16], ctrl[8];
+  double lc[12], ls[12], lw[12], lox[12], loz[12], lvx[12], lvz[12], lax[12], laz[12];
+  double lcx[12], lcz[12], lfx[12], lfz[12];
+  double s1x[16], s1z[16], s2[16];
+  double tau[16], qs[16], g[16];
+  double minv[NV * NV + 7], mhinv[NV * NV + 7];
+  double rowJ[NSLOT + 2][8];
+  double rowf[NSLOT + 2];
+  double site[2][6][4];
+};
+
+struct LaneConst {
+  // link role
+  int ancmask;
+  double comx, comz, mass;
+  // dof role
+  int d, grp, dvalid, dlink, submask, rel, act;
+  double sigma, damping, armature, gear, clo, chi;
+  int kL, kR;
+  // row role
+  int kind, leg, comp, rdof, link1, link2, pm1, pm2;
+  double d1x, d1z, d2x, d2z, radius, invw, lim_lo, lim_hi;
+  double solref0, solref1, simp0, simp1, simp2;
+};
+
+__device__ __forceinline__ void load_lane_const(LaneConst& c, int lane) {
+  int l = lane < NL ? lane : 0;
+  c.ancmask = lane < NL ? cp_link_ancmask[l] : 0;
+  c.comx = cp_link_com[0][l][0]; c.comz = cp_link_com[0][l][1]; c.mass = cp_link_mass[l];
+  c.d = lane & 15; c.grp = lane >> 4; c.dvalid = (c.d < NV) && (lane < 32);
+  int d = c.d < NV ? c.d : 0;
+  c.dlink = cp_dof_link[d]; c.submask = cp_dof_submask[d]; c.rel = cp_dof_rel[d]; c.act = cp_dof_act[d];
+  c.sigma = cp_dof_sigma[d]; c.damping = cp_dof_damping[d]; c.armature = cp_dof_armature[d];
+  int a = c.act >= 0 ? c.act : 0;
+  c.gear = c.act >= 0 ? cp_act_gear[a] : 0.0; c.clo = cp_act_ctrlrange[a][0]; c.chi = cp_act_ctrlrange[a][1];
+  c.kL = d < 8 ? d : -1;                     // compact index of this dof in a left-leg row
+  c.kR = d < 3 ? d : (d >= 8 ? d - 5 : -1);  // ... in a right-leg row
+  int s = lane < NSLOT ? lane : 0;
+  c.kind = lane < NSLOT ? cp_slot_kind[s] : -1; c.leg = cp_slot_leg[s]; c.comp = cp_slot_comp[s]; c.rdof = cp_slot_dof[s];
+  c.link1 = cp_slot_link1[s]; c.link2 = cp_slot_link2[s];
+  c.pm1 = cp_link_pathmask8[c.link1]; c.pm2 = cp_link_pathmask8[c.link2];
+  c.d1x = cp_slot_d1[0][s][0]; c.d1z = cp_slot_d1[0][s][1]; c.d2x = cp_slot_d2[0][s][0]; c.d2z = cp_slot_d2[0][s][1];
+  c.radius = cp_slot_radius[s]; c.invw = cp_slot_invweight[s];
+  int rd = c.rdof >= 0 ? c.rdof : 0;
+  c.lim_lo = cp_jnt_range[rd][0]; c.lim_hi = cp_jnt_range[rd][1];
+  const double* sr = c.kind == 0 ? cp_eq_solref[s >> 1] : (c.kind == 1 ? cp_limit_solref : cp_contact_solref);
+  const double* si = c.kind == 0 ? cp_eq_solimp[s >> 1] : (c.kind == 1 ? cp_limit_solimp : cp_contact_solimp);
+  c.solref0 = sr[0]; c.solref1 = sr[1]; c.simp0 = si[0]; c.simp1 = si[1]; c.simp2 = si[2];
+}
+
+__device__ __forceinline__ double impedance(double d0, double d1, double width, double x) {
+  if (d0 == d1 || width <= MINVAL) return 0.5 * (d0 + d1);
+  x = fabs(x / width);
+  if (x >= 1.0) return d1;
+  if (x <= 0.0) return d0;
+  double y = x <= 0.5 ? 2.0 * x * x : 1.0 - 2.0 * (1.0 - x) * (1.0 - x);
+  return d0 + y * (d1 - d0);
+}
+
+// ---------------------------------------------------------------- planar forward kinematics on the link lanes
+// Reads sm.q/sm.v-like arrays (qsrc, vsrc), writes link arrays.  SEM selects the model semantics table.
+template <int SEM>
+__device__ __forceinline__ void planar_fk(Smem& sm, const double* qsrc, const double* vsrc, const LaneConst& c, int lane) {
+  double th = 0.0, w = 0.0;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    int dk = cp_link_dof[k];
+    double sg = cp_link_sigma[k];
+    double dq = sg * (qsrc[dk] - cp_qpos0[dk]), dv = sg * vsrc[dk];
+    if ((c.ancmask >> k) & 1) { th += dq; w += dv; }
+  }
+  double sn, cs;
+  sincos(th, &sn, &cs);
+  if (lane < NL) { sm.lc[lane] = cs; sm.ls[lane] = sn; sm.lw[lane] = w; }
+  lds_sync();
+  // chain sums: origin (relative to the pelvis origin), origin velocity (relative part), velocity-product accel
+  double ox = 0, oz = 0, vx = 0, vz = 0, ax = 0, az = CP_GRAVITY;
+#pragma unroll
+  for (int k = 1; k < NL; k++) {
+    int p = cp_link_parent[k];
+    double pc = sm.lc[p], ps = sm.ls[p], pw = sm.lw[p];
+    double fx = cp_link_off[SEM][k][0], fz = cp_link_off[SEM][k][1];
+    double tx = pc * fx + ps * fz, tz = -ps * fx + pc * fz;
+    if ((c.ancmask >> k) & 1) {
+      ox += tx; oz += tz;
+      vx += pw * tz; vz -= pw * tx;          // w y^ x t
+      ax -= pw * pw * tx; az -= pw * pw * tz;  // centripetal
+    }
+  }
+  if (lane < NL) {
+    double cx0 = SEM == 0 ? c.comx : cp_link_com[SEM][lane][0], cz0 = SEM == 0 ? c.comz : cp_link_com[SEM][lane][1];
+    double rx = cs * cx0 + sn * cz0, rz = -sn * cx0 + cs * cz0;
+    sm.lox[lane] = ox; sm.loz[lane] = oz; sm.lvx[lane] = vx; sm.lvz[lane] = vz; sm.lax[lane] = ax; sm.laz[lane] = az;
+    sm.lcx[lane] = ox + rx; sm.lcz[lane] = oz + rz;
+    sm.lfx[lane] = c.mass * (ax - w * w * rx); sm.lfz[lane] = c.mass * (az - w * w * rz);
+  }
+  lds_sync();
+}
+
+// point on a link (relative to the pelvis origin)
+__device__ __forceinline__ void link_point(const Smem& sm, int link, double dx, double dz, double& px, double& pz) {
+  double cs = sm.lc[link], sn = sm.ls[link];
+  px = sm.lox[link] + cs * dx + sn * dz;
+  pz = sm.loz[link] - sn * dx + cs * dz;
+}
+
+// compact Jacobian row (component comp: 0 = x, 1 = z) of a point on `link`; legbase = 1 (left) or 6 (right)
+__device__ __forceinline__ void jac_compact(const Smem& sm, int pm, int legbase, int comp, double px, double pz, double sgn, double* J) {
+  // base slides
+  J[0] += sgn * (comp == 0 ? 1.0 : 0.0);
+  J[1] += sgn * (comp == 1 ? 1.0 : 0.0);
+  // pitch hinge: sigma = +1, anchor = pelvis origin (0,0)
+  J[2] += sgn * (comp == 0 ? pz : -px);
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    int l = legbase + k;
+    double rx = px - sm.lox[l], rz = pz - sm.loz[l];
+    double val = cp_link_sigma[1 + k] * (comp == 0 ? rz : -rx);
+    if ((pm >> (3 + k)) & 1) J[3 + k] += sgn * val;
+  }
+}
+
+// ---------------------------------------------------------------- coalesced HBM <-> LDS state movement
+// s1 lane map: 0 kv[12] | 1..13 qstate | 14..19 ctrl | 20 time | 21 PGS iterations
+__device__ __forceinline__ double load_state(const double* st, Smem& sm, int lane) {
+  double s0 = st[lane];
+  double s1 = lane < ENV_STRIDE - 64 ? st[64 + lane] : 0.0;
+  if (lane < 13) sm.q[lane] = s0;
+  else if (lane < 26) sm.v[lane - 13] = s0;
+  else if (lane < 39) sm.ws[lane - 26] = s0;
+  else if (lane < 52) sm.kq[lane - 39] = s0;
+  else sm.kv[lane - 52] = s0;
+  if (lane == 0) sm.kv[12] = s1;
+  if (lane >= 14 && lane < 20) sm.ctrl[lane - 14] = s1;
+  return s1;
+}
+__device__ __forceinline__ void store_state(double* st, const Smem& sm, int lane, double qstate_l, double time, int niter) {
+  double w0;
+  if (lane < 13) w0 = sm.q[lane];
+  else if (lane < 26) w0 = sm.v[lane - 13];
+  else if (lane < 39) w0 = sm.ws[lane - 26];
+  else if (lane < 52) w0 = sm.kq[lane - 39];
+  else w0 = sm.kv[lane - 52];
+  st[lane] = w0;
+  if (lane < ENV_STRIDE - 64) {
+    double w1 = 0.0;
+    if (lane == 0) w1 = sm.kv[12];
+    else if (lane < 14) w1 = qstate_l;
+    else if (lane < 20) w1 = sm.ctrl[lane - 14];
+    else if (lane == 20) w1 = time;
+    else if (lane == 21) w1 = (double)niter;
+    st[64 + lane] = w1;
+  }
+}
+
+struct StepOut { int niter; unsigned long long active; };
+
+// ---------------------------------------------------------------- one mj_forward (+ optional Euler integration)
+// On entry sm.q/v/ws hold the state; ctrl is this dof lane's actuator command (pre-clamp).
+template <bool INTEGRATE>
+__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg) {
+  // ---- kinematics
+  planar_fk<0>(sm, sm.q, sm.v, c, lane);
+  // ---- per-dof subtree sums (dof lanes, both groups)
+  double msub = 0, s1x = 0, s1z = 0, s2 = 0, bias = 0;
+  const double odx = sm.lox[c.dlink], odz = sm.loz[c.dlink];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    double rx = sm.lcx[l] - odx, rz = sm.lcz[l] - odz;
+    double m = cp_link_mass[l], fx = sm.lfx[l], fz = sm.lfz[l];
+    if ((c.submask >> l) & 1) {
+      msub += m; s1x += m * rx; s1z += m * rz; s2 += m * (rx * rx + rz * rz) + cp_link_inertia[0][l];
+      bias += c.d == 0 ? fx : (c.d == 1 ? fz : c.sigma * (fx * rz - fz * rx));
+    }
+  }
+  if (c.dvalid && c.grp == 0) { sm.s1x[c.d] = s1x; sm.s1z[c.d] = s1z; sm.s2[c.d] = s2; }
+  lds_sync();
+  // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal)
+  double Mr[NV];
+  static_for<0, NV>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    double val;
+    if constexpr (C < 2) {
+      val = c.d < 2 ? (c.d == C ? msub : 0.0) : c.sigma * (C == 0 ? s1z : -s1x);
+    } else {
+      constexpr int LC = C == 2 ? 0 : C - 2;
+      constexpr double SC = C == 2 ? 1.0 : -1.0;
+      double ocx = sm.lox[LC], ocz = sm.loz[LC];
+      double c1x = sm.s1x[C], c1z = sm.s1z[C], c2 = sm.s2[C];
+      int code = (c.rel >> (2 * C)) & 3;
+      double deep_row = s2 + (odx - ocx) * s1x + (odz - ocz) * s1z;
+      double deep_col = c2 + (ocx - odx) * c1x + (ocz - odz) * c1z;
+      double hh = code == 1 ? deep_row : (code == 2 ? deep_col : 0.0);
+      double slide = SC * (c.d == 0 ? c1z : -c1x);
+      val = c.d < 2 ? slide : c.sigma * SC * hh;
+    }
+    if (C == c.d) val += c.armature + (c.grp == 1 ? H * c.damping : 0.0);
+    Mr[C] = val;
+  });
+  if (dbg && c.dvalid && c.grp == 0) {
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dbg[DBG_M + c.d * NV + C] = Mr[C]; });
+    dbg[DBG_BIAS + c.d] = bias;
+  }
+  if (!c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mr[C] = (C == (lane & 15)) ? 1.0 : 0.0; }); }
+  // ---- in-register Gauss-Jordan inverse, rows on lanes, both 16-lane groups at once
+  static_for<0, NV>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    double piv = row_bcast<K>(Mr[K]);
+    double inv = 1.0 / piv;
+    double t = Mr[K] * inv;
+    bool isk = (lane & 15) == K;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      if constexpr (C != K) {
+        double pk = row_bcast<K>(Mr[C]);
+        Mr[C] = isk ? pk * inv : Mr[C] - t * pk;
+      }
+    });
+    Mr[K] = isk ? inv : -t;
+  });
+  if (c.dvalid) {
+    double* dst = c.grp == 0 ? sm.minv : sm.mhinv;
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dst[c.d * NV + C] = Mr[C]; });
+  }
+  // ---- smooth forces and unconstrained acceleration
+  double v_d = sm.v[c.d < NV ? c.d : 0];
+  double u = ctrl < c.clo ? c.clo : (ctrl > c.chi ? c.chi : ctrl);
+  double tau = -c.damping * v_d - bias + c.gear * u;
+  double qs = 0.0;
+  static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mr[C] * row_bcast<C>(tau); });
+  if (c.dvalid && c.grp == 0) { sm.tau[c.d] = tau; sm.qs[c.d] = qs; }
+  lds_sync();
+  if (dbg && c.dvalid && c.grp == 0) dbg[DBG_QS + c.d] = qs;
+  // ---- constraint rows on the row lanes (fixed slots)
+  double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double pos = 0.0;
+  bool active = false;
+  const int legbase = c.leg == 0 ? 1 : 6;
+  const int vbase = c.leg == 0 ? 3 : 8;
+  const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+  if (c.kind == 0) {
+    double p1x, p1z, p2x, p2z;
+    link_point(sm, c.link1, c.d1x, c.d1z, p1x, p1z);
+    link_point(sm, c.link2, c.d2x, c.d2z, p2x, p2z);
+    jac_compact(sm, c.pm1, legbase, c.comp, p1x, p1z, 1.0, J);
+    jac_compact(sm, c.pm2, legbase, c.comp, p2x, p2z, -1.0, J);
+    pos = c.comp == 0 ? p1x - p2x : p1z - p2z;
+    active = true;
+  } else if (c.kind == 1) {
+    double qd = sm.q[c.rdof];
+    double dlo = qd - c.lim_lo, dhi = c.lim_hi - qd;
+    int k = 3 + c.rdof - vbase;
+    double sgn = 0.0;
+    if (dlo < 0) { active = true; pos = dlo; sgn = 1.0; }
+    else if (dhi < 0) { active = true; pos = dhi; sgn = -1.0; }
+    static_for<3, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; J[K] = (k == K) ? sgn : 0.0; });
+  } else if (c.kind >= 2) {
+    double cx, cz;
+    link_point(sm, c.link1, c.d1x, c.d1z, cx, cz);
+    double dist = basez + cz - c.radius;
+    if (dist < 0) {
+      active = true;
+      double pz = 0.5 * dist - basez;
+      jac_compact(sm, c.pm1, legbase, c.comp, cx, pz, 1.0, J);
+      pos = dist;  // both rows of the pair keep the normal distance (shared regulariser); the tangent row's own pos is 0
+    }
+  }
+  const unsigned long long amask = __ballot(active);
+  out.active = amask;
+  // row velocity, impedance, regulariser, reference acceleration
+  double vel = J[0] * sm.v[0] + J[1] * sm.v[1] + J[2] * sm.v[2];
+  double bq = J[0] * sm.qs[0] + J[1] * sm.qs[1] + J[2] * sm.qs[2];
+  double jw = J[0] * sm.ws[0] + J[1] * sm.ws[1] + J[2] * sm.ws[2];
+  static_for<0, 5>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    vel += J[3 + K] * sm.v[vbase + K]; bq += J[3 + K] * sm.qs[vbase + K]; jw += J[3 + K] * sm.ws[vbase + K];
+  });
+  double tc = c.solref0 < 2.0 * H ? 2.0 * H : c.solref0;
+  double kk_ = 1.0 / (c.simp1 * c.simp1 * tc * tc * c.solref1 * c.solref1), bb_ = 2.0 / (c.simp1 * tc);
+  double imp = impedance(c.simp0, c.simp1, c.simp2, pos);
+  double R = (1.0 - imp) / imp * c.invw;
+  R = R > MINVAL ? R : MINVAL;
+  double own_pos = c.kind == 3 ? 0.0 : pos;
+  double imp_own = c.kind == 3 ? impedance(c.simp0, c.simp1, c.simp2, 0.0) : imp;
+  double aref = -bb_ * vel - kk_ * imp_own * own_pos;
+  double b = active ? bq - aref : 0.0;
+  double jar = jw - aref;
+  if (lane < NSLOT) { static_for<0, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; sm.rowJ[lane][K] = J[K]; }); }
+  // ---- X = M^-1 J' (13 values per row lane)
+  double X[NV];
+  {
+    const double* mi = sm.minv;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      double s = mi[C * NV + 0] * J[0] + mi[C * NV + 1] * J[1] + mi[C * NV + 2] * J[2];
+      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; s += mi[C * NV + vbase + K] * J[3 + K]; });
+      X[C] = s;
+    });
+  }
+  lds_sync();
+  // ---- A row: A[i][s] = X_i . J_s for active slots (static slot -> static leg -> static register indices)
+  double Ar[NSLOT];
+  static_for<0, NSLOT>([&](auto ss) {
+    constexpr int S = decltype(ss)::value;
+    constexpr int LEG = S < 4 ? S / 2 : (S < 12 ? (S - 4) / 4 : ((S - 12) / 2 <= 8 ? 0 : 1));
+    constexpr int VB = LEG == 0 ? 3 : 8;
+    double a = 0.0;
+    if ((amask >> S) & 1) {
+      const double* js = sm.rowJ[S];
+      a = X[0] * js[0] + X[1] * js[1] + X[2] * js[2] + X[VB] * js[3] + X[VB + 1] * js[4] + X[VB + 2] * js[5] + X[VB + 3] * js[6] +
+          X[VB + 4] * js[7];
+      if (lane == S) a += R;
+    }
+    Ar[S] = a;
+  });
+  // diagonal element and partner data
+  double Adiag = 1.0;
+  static_for<0, NSLOT>([&](auto ss) { constexpr int S = decltype(ss)::value; if (lane == S && active) Adiag = Ar[S]; });
+  double Ainv = 1.0 / Adiag;
+  double Apart = swap1(Adiag);  // for a normal lane: A_tt of its tangent partner
+  double Ant = 0.0;             // for a normal lane: A[n][t]
+  static_for<0, (NSLOT - SLOT_CON) / 2>([&](auto pp) { constexpr int S = SLOT_CON + 2 * decltype(pp)::value; if (lane == S) Ant = Ar[S + 1]; });
+  // ---- warm start: forces from qacc_warmstart (mj_constraintUpdate), kept only if the dual cost beats zero
+  const double mu = CP_CONTACT_MU;
+  double D = 1.0 / R;
+  double f = 0.0;
+  {
+    double pj = swap1(jar);
+    if (active) {
+      if (c.kind == 0) f = -D * jar;
+      else if (c.kind == 1) f = jar < 0 ? -D * jar : 0.0;
+      else {
+        double jn = c.kind == 2 ? jar : pj, jt = c.kind == 2 ? pj : jar;
+        double N = jn * mu, U1 = jt * mu, T = fabs(U1);
+        double fn, ft;
+        if (N >= mu * T || (T <= 0 && N >= 0)) { fn = 0; ft = 0; }
+        else if (mu * N + T <= 0 || (T <= 0 && N < 0)) { fn = -D * jn; ft = -D * jt; }
+        else {
+          double Dm = D / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+          fn = -Dm * NmT * mu;
+          ft = -fn / T * U1 * mu;
+        }
+        f = c.kind == 2 ? fn : ft;
+      }
+    }
+  }
+  double res = 0.0;  // (A f)_i
+  static_for<0, NSLOT>([&](auto ss) {
+    constexpr int S = decltype(ss)::value;
+    if ((amask >> S) & 1) res += Ar[S] * rdlane(f, S);
+  });
+  {
+    double cost = wave_sum(active ? f * (0.5 * res + b) : 0.0);
+    if (cost > 0) { f = 0.0; res = 0.0; }
+  }
+  res += b;
+  if (dbg && lane < NSLOT) {
+    dbg[DBG_F0 + lane] = f; dbg[DBG_B + lane] = b; dbg[DBG_R + lane] = active ? R : 0.0;
+    dbg[DBG_AREF + lane] = active ? aref : 0.0; dbg[DBG_ADIAG + lane] = active ? Adiag : 0.0;
+  }
+  // ---- PGS (mj_solPGS, elliptic cones): residual per lane, delta broadcast by v_readlane
+  const double scale = 1.0 / (CP_MEANINERTIA * NV);
+  int niter = 0;
+  for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+    double acc = 0.0;
+    // single-row constraints: connect (0..3) and joint limits (4..11)
+    static_for<0, SLOT_CON>([&](auto ss) {
+      constexpr int S = decltype(ss)::value;
+      if ((amask >> S) & 1) {
+        double cand = f - res * Ainv;
+        if constexpr (S >= SLOT_LIM) cand = cand < 0 ? 0.0 : cand;
+        double d = cand - f;
+        double chg = d * (0.5 * d * Adiag + res);
+        if (chg > 1e-10) { d = 0.0; chg = 0.0; }
+        double Dd = rdlane(d, S);
+        if (lane == S) { f += d; acc -= chg; }
+        res += Ar[S] * Dd;
+      }
+    });
+    // contact pairs: normal on the even lane S, tangent on S+1
+    static_for<0, (NSLOT - SLOT_CON) / 2>([&](auto pp) {
+      constexpr int S = SLOT_CON + 2 * decltype(pp)::value;
+      if ((amask >> S) & 1) {
+        // lane S gathers the pair locally: its own (res,f) are the normal's; the partner's via DPP
+        double rt = swap1(res), ot = swap1(f);
+        double rn = res, on = f;
+        double Ann = Adiag, Att = Apart;
+        double fn = on, ft = ot;
+        if (fn < MINVAL) {
+          fn = fn - rn * Ainv;
+          fn = fn < 0 ? 0.0 : fn;
+          ft = 0.0;
+        } else {
+          double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
+          if (denom >= MINVAL) {
+            double x = -(fn * rn + ft * rt) / denom;
+            if (fn + x * fn < 0) x = -1.0;
+            double fn0 = fn;
+            fn = fn0 + x * fn0; ft = ft + x * ft;
+          }
+        }
+        if (fn >= MINVAL) {
+          double bc = rt - Att * ot + Ant * (fn - on);
+          double x0 = -bc / Att;
+          double v1 = x0 / mu;
+          double val = v1 * v1 - fn * fn;
+          ft = x0;
+          if (val >= 1e-10) {
+            double delta = val * Att * mu * mu / (2.0 * v1 * v1);
+            if (delta >= 1e-10) ft = (x0 > 0 ? 1.0 : (x0 < 0 ? -1.0 : 0.0)) * mu * fn;
+          }
+        }
+        double dn = fn - on, dt = ft - ot;
+        double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+        if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
+        double Dn = rdlane(dn, S), Dt = rdlane(dt, S);
+        if (lane == S) { f += dn; acc -= chg; }
+        if (lane == S + 1) f += Dt;
+        res += Ar[S] * Dn + Ar[S + 1] * Dt;
+      }
+    });
+    niter = iter + 1;
+    double improvement = wave_sum(acc);
+    if (improvement * scale < CP_TOLERANCE) break;
+  }
+  out.niter = niter;
+  if (lane < NSLOT) sm.rowf[lane] = active ? f : 0.0;
+  lds_sync();
+  if (dbg && lane < NSLOT) dbg[DBG_F + lane] = active ? f : 0.0;
+  // ---- total generalised force g = tau + J' f on the dof lanes, then both accelerations
+  double g = tau;
+  static_for<0, NSLOT>([&](auto ss) {
+    constexpr int S = decltype(ss)::value;
+    constexpr int LEG = S < 4 ? S / 2 : (S < 12 ? (S - 4) / 4 : ((S - 12) / 2 <= 8 ? 0 : 1));
+    if ((amask >> S) & 1) {
+      int k = LEG == 0 ? c.kL : c.kR;
+      double js = sm.rowJ[S][k < 0 ? 0 : k];
+      g += (k < 0 ? 0.0 : js) * sm.rowf[S];
+    }
+  });
+  double acc_d = 0.0;  // group 0: qacc = M^-1 g ; group 1: (M + hB)^-1 g
+  static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; acc_d += Mr[C] * row_bcast<C>(g); });
+  if (dbg && c.dvalid) dbg[(c.grp == 0 ? DBG_QACC : DBG_QACCH) + c.d] = acc_d;
+  lds_sync();
+  if (c.dvalid && c.grp == 0) sm.ws[c.d] = acc_d;  // qacc_warmstart <- qacc
+  if (INTEGRATE && c.dvalid && c.grp == 1) {
+    double vn = sm.v[c.d] + H * acc_d;  // mj_Euler with implicit joint damping
+    sm.v[c.d] = vn;
+    sm.q[c.d] = sm.q[c.d] + H * vn;
+  }
+  lds_sync();
+}
+
+// ---------------------------------------------------------------- operational-space state (Cassie2d.cpp:218-237)
+// kinematics of the LAST setState (kq,kv; quirk Q1/Q2) with the RBDL-semantics tables; pitch from the current state.
+__device__ __forceinline__ void opstate18(Smem& sm, const LaneConst& c, int lane, bool fix_stale, double* s18 /*LDS*/) {
+  const double* qk = fix_stale ? sm.q : sm.kq;
+  const double* vk = fix_stale ? sm.v : sm.kv;
+  planar_fk<1>(sm, qk, vk, c, lane);
+  if (lane < 5) {
+    int sid = lane + 1;
+    int l = cp_site_link[sid];
+    double dx = cp_site_d[1][sid][0], dz = cp_site_d[1][sid][1];
+    double cs = sm.lc[l], sn = sm.ls[l], w = sm.lw[l];
+    double rx = cs * dx + sn * dz, rz = -sn * dx + cs * dz;
+    double bx = qk[0] - cp_qpos0[0] + cp_link_off[1][0][0], bz = qk[1] - cp_qpos0[1] + cp_link_off[1][0][1];
+    sm.site[0][lane][0] = bx + sm.lox[l] + rx;
+    sm.site[0][lane][1] = bz + sm.loz[l] + rz;
+    sm.site[0][lane][2] = vk[0] + sm.lvx[l] + w * rz;
+    sm.site[0][lane][3] = vk[1] + sm.lvz[l] - w * rx;
+  }
+  lds_sync();
+  if (lane < 2) {
+    int i = lane;
+    s18[i] = sm.site[0][0][i];
+    s18[3 + i] = sm.site[0][0][2 + i];
+    s18[6 + i] = (sm.site[0][1][i] + sm.site[0][2][i]) / 2.0;
+    s18[9 + i] = (sm.site[0][1][2 + i] + sm.site[0][2][2 + i]) / 2.0;
+    s18[12 + i] = (sm.site[0][3][i] + sm.site[0][4][i]) / 2.0;
+    s18[15 + i] = (sm.site[0][3][2 + i] + sm.site[0][4][2 + i]) / 2.0;
+  }
+  if (lane == 2) {
+    s18[2] = sm.q[2]; s18[5] = sm.v[2];
+    s18[8] = 0; s18[11] = 0; s18[14] = 0; s18[17] = 0;  // never written by the reference (Q4)
+  }
+  lds_sync();
+}
+
+// ---------------------------------------------------------------- the fused Env.step kernel
+// MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
+template <int MODE>
+__global__ void __launch_bounds__(64) env_step_kernel(VecParams p) {
+  __shared__ Smem sm;
+  __shared__ double s18[18];
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (env >= p.n_envs) return;
+  double* st = p.state + (size_t)env * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, lane);
+  double s1 = load_state(st, sm, lane);
+  double qstate_l = s1;  // lane 1+j holds qstate[j]
+  double time = rdlane(s1, 20);
+  lds_sync();
+  // action for this dof lane
+  double act_l = 0.0;
+  if (p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[(size_t)env * p.adim + c.act];
+  double* dbg = p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr;
+  StepOut so; so.niter = 0; so.active = 0;
+  int niter_sum = 0;
+  for (int sub = 0; sub < p.n_sub; sub++) {
+    // DynamicModel::setState: remember the pre-step state (kinematics used by GetOperationalSpaceState)
+    if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }
+    double ctrl;
+    if (MODE == 0) {
+      int dd = c.d < NV ? c.d : 0;
+      ctrl = 10.0 * (act_l - sm.q[dd]) + 5.0 * (0.0 - sm.v[dd]);
+    } else {
+      ctrl = act_l;
+    }
+    lds_sync();
+    substep<true>(sm, c, lane, ctrl, so, dbg);
+    niter_sum += so.niter;
+    time += 0.0005;
+    if (sub == p.n_sub - 1 && c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;  // mj_data->ctrl
+  }
+  lds_sync();
+  // ---- observation, reward, termination (Cassie2dEnv.step) -- optional
+  if (p.obs) {
+    const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+    opstate18(sm, c, lane, fix_kin, s18);
+    double sp = 0.0;  // obs[lane], lane < 26
+    if (lane < 17) sp = s18[lane + 1];
+    if (lane == 5 || lane == 11) sp -= s18[0];
+    double reward = 0.0;
+    int done = 0;
+    if (p.env_kind == 0) {
+      // reference-gait lookup (cassie2d_trajectory.py:16-19)
+      double tmax = p.traj_tmax;
+      int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
+      const double* rq = p.traj_qpos + (size_t)idx * NV;
+      if (lane >= 17 && lane < 26) {
+        int k = lane - 17;  // columns 0,1,2,3,4,6,8,9,11
+        int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
+        sp = rq[col];
+      }
+      // reward (cassie2d.py:197-218); qstate is the reset pose unless FLAG_FIX_STALE_QSTATE (quirk Q3)
+      const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
+      auto qst = [&](int j) { return fixq ? sm.q[j] : rdlane(qstate_l, 1 + j); };
+      double j = qst(3) + qst(4) + qst(6);
+      j += qst(8) + qst(9) + qst(11);
+      double sum = 0.0;
+      for (int i = 20; i < 26; i++) sum += rdlane(sp, i);
+      j -= sum; j = exp(-(j * j));
+      double pp = s18[0] + s18[1];
+      pp -= rdlane(sp, 17) + rdlane(sp, 18); pp = exp(-(pp * pp));
+      double oo = s18[2];
+      oo -= rdlane(sp, 19); oo = exp(-(oo * oo));
+      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+      done = (s18[1] < 0.6) || (s18[1] > 1.2) || (reward < 0.6);
+    } else {
+      double a2 = 0.0;
+      for (int i = 0; i < p.adim; i++) { double a = p.actions[(size_t)env * p.adim + i]; a2 += a * a; }
+      double z = s18[1];
+      double m = (rdlane(sp, 5) + rdlane(sp, 11)) / 2.0;
+      reward = 0.0;
+      reward -= 2 * (0.9 - z) * (0.9 - z);
+      reward -= 2 * m * m;
+      reward += 1;
+      reward -= 0.001 * a2;
+      done = z < 0.5;
+    }
+    if (p.terminal_obs && lane < 26) p.terminal_obs[(size_t)env * 26 + lane] = sp;
+    if (done && p.auto_reset) {
+      // Cassie2dEnv.reset: qinit -> Reset (mj_forward with the stale ctrl, no setState) -> op-space state from the
+      // STALE kinematics (quirk Q2)
+      if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }
+      if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
+      time = 0.0;
+      lds_sync();
+      substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+      opstate18(sm, c, lane, fix_kin, s18);
+      sp = 0.0;
+      if (lane < 17) sp = s18[lane + 1];
+      if (lane == 5 || lane == 11) sp -= s18[0];
+    }
+    if (lane < 26) p.obs[(size_t)env * 26 + lane] = sp;
+    if (lane == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
+  }
+  // ---- coalesced state write-back
+  store_state(st, sm, lane, qstate_l, time, niter_sum);
+}
+
+// ---------------------------------------------------------------- masked reset (Cassie2dEnv.reset / Cassie2d::Reset)
+__global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_t* mask, const double* qpos_in, const double* qvel_in) {
+  __shared__ Smem sm;
+  __shared__ double s18[18];
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (env >= p.n_envs) return;
+  if (mask && !mask[env]) return;
+  double* st = p.state + (size_t)env * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, lane);
+  load_state(st, sm, lane);
+  lds_sync();
+  if (lane < 13) {
+    sm.q[lane] = qpos_in ? qpos_in[(size_t)env * NV + lane] : cp_env_qinit[lane];
+    sm.v[lane] = qvel_in ? qvel_in[(size_t)env * NV + lane] : 0.0;
+  }
+  lds_sync();
+  double qstate_l = (lane >= 1 && lane < 14) ? sm.q[lane - 1] : 0.0;
+  StepOut so;
+  substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+  if (p.obs) {
+    opstate18(sm, c, lane, (p.flags & FLAG_FIX_STALE_KIN) != 0, s18);
+    double sp = 0.0;
+    if (lane < 17) sp = s18[lane + 1];
+    if (lane == 5 || lane == 11) sp -= s18[0];
+    if (lane < 26) p.obs[(size_t)env * 26 + lane] = sp;
+  }
+  store_state(st, sm, lane, qstate_l, 0.0, so.niter);
+}
+
+// op-space state only (GetOperationalSpaceState for every env)
+__global__ void __launch_bounds__(64) env_opstate_kernel(VecParams p, double* out18) {
+  __shared__ Smem sm;
+  __shared__ double s18[18];
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (env >= p.n_envs) return;
+  const double* st = p.state + (size_t)env * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, lane);
+  load_state(st, sm, lane);
+  lds_sync();
+  opstate18(sm, c, lane, (p.flags & FLAG_FIX_STALE_KIN) != 0, s18);
+  if (lane < 18) out18[(size_t)env * 18 + lane] = s18[lane];
+}
+
+// constructor state: qpos_init of Cassie2d.cpp:56-58, zero velocity, cold warm start, kin state = same
+__global__ void env_init_kernel(double* state, int n_envs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_envs * ENV_STRIDE) return;
+  int k = i % ENV_STRIDE;
+  double v = 0.0;
+  if (k < 13) v = cp_ctor_qinit[k];
+  else if (k >= ES_KQ && k < ES_KQ + 13) v = cp_ctor_qinit[k - ES_KQ];
+  else if (k >= ES_QSTATE && k < ES_QSTATE + 13) v = cp_env_qinit[k - ES_QSTATE];
+  state[i] = v;
+}
+
+__global__ void get_state_kernel(const double* state, int n_envs, double* qpos, double* qvel) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_envs * NV) return;
+  int e = i / NV, k = i % NV;
+  if (qpos) qpos[i] = state[(size_t)e * ENV_STRIDE + ES_Q + k];
+  if (qvel) qvel[i] = state[(size_t)e * ENV_STRIDE + ES_V + k];
+}
+
+}  // namespace cassie

@@ -1,0 +1,41 @@
+// cassie_vec_layout.h -- HBM layout of one environment and the kernel parameter block
+// (shared by cassie_kernels.hip and cassie_cabi.hip; not a public header).
+#ifndef CASSIE_VEC_LAYOUT_H_
+#define CASSIE_VEC_LAYOUT_H_
+#include <stdint.h>
+
+namespace cassie {
+
+// One environment = 88 doubles (704 B), array-of-structures so that the owning wavefront reads
+// and writes it with two coalesced wave accesses (lanes 0..63, then lanes 0..23).
+//   [ 0..12] qpos   [13..25] qvel   [26..38] qacc_warmstart
+//   [39..51] qpos at the last DynamicModel::setState   [52..64] qvel at the last setState   (quirk Q1/Q2)
+//   [65..77] self.qstate positions (written by reset only; quirk Q3)
+//   [78..83] last mj_data->ctrl (pre-clamp)   [84] env time   [85] PGS iterations of the last call   [86,87] pad
+constexpr int ENV_STRIDE = 88;
+enum { ES_Q = 0, ES_V = 13, ES_WS = 26, ES_KQ = 39, ES_KV = 52, ES_QSTATE = 65, ES_CTRL = 78, ES_TIME = 84, ES_NITER = 85 };
+
+// debug record (doubles) written by substep() when VecParams.debug != nullptr (tests only)
+enum {
+  DBG_M = 0, DBG_BIAS = 169, DBG_QS = 182, DBG_F0 = 195, DBG_B = 241, DBG_R = 287, DBG_AREF = 333, DBG_ADIAG = 379,
+  DBG_F = 425, DBG_QACC = 471, DBG_QACCH = 484, DBG_STRIDE = 512
+};
+
+enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2 };
+
+struct VecParams {
+  double* state;          // [n_envs][ENV_STRIDE]
+  const double* actions;  // [n_envs][adim] device
+  double* obs;            // [n_envs][26] or null (physics only)
+  double* reward;         // [n_envs]
+  uint8_t* done;          // [n_envs]
+  double* terminal_obs;   // [n_envs][26] or null
+  const double* traj_qpos;  // [traj_n][13]
+  double traj_tmax;
+  int traj_n;
+  double* debug;          // [n_envs][DBG_STRIDE] or null
+  int n_envs, adim, n_sub, flags, env_kind, auto_reset;
+};
+
+}  // namespace cassie
+#endif

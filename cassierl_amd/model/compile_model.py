@@ -497,6 +497,100 @@ def emit_planar_header(mj, m3s, consts, planars, path):
     o.append(ca("cp_act_dof", [a["dof"] for a in mj["acts"]], "%d", "int", 6))
     o.append(ca("cp_act_gear", [a["gear"] for a in mj["acts"]]))
     o.append(ca("cp_act_ctrlrange", [a["ctrlrange"] for a in mj["acts"]]))
+    # ---- lane tables for the wave-per-environment kernels
+    parent = [L["parent"] for L in pl["links"]]
+
+    def is_anc(a, l):
+        while l >= 0:
+            if l == a:
+                return True
+            l = parent[l]
+        return False
+    dof_link = [0, 0] + [None] * (m3.nv - 2)
+    for li, L in enumerate(pl["links"]):
+        dof_link[L["dof"]] = li
+    o.append("/* link lanes: bit k set <=> link k is an ancestor-or-self of this link */\n")
+    o.append(ca("cp_link_ancmask", [sum(1 << k for k in range(nl) if is_anc(k, li)) for li in range(nl)], "%d", "int", 11))
+    o.append("/* dof lanes: owning link, bit l set <=> link l is in the subtree moved by this dof */\n")
+    o.append(ca("cp_dof_link", dof_link, "%d", "int", 13))
+    o.append(ca("cp_dof_submask", [sum(1 << l for l in range(nl) if is_anc(dof_link[d], l)) for d in range(m3.nv)], "%d", "int", 13))
+    o.append(ca("cp_dof_sigma", [0.0, 0.0] + [pl["links"][dof_link[d]]["sigma"] for d in range(2, m3.nv)]))
+    rel = []
+    for r in range(m3.nv):
+        code = 0
+        for c in range(m3.nv):
+            if r < 2 or c < 2:
+                continue
+            if is_anc(dof_link[c], dof_link[r]):
+                code |= 1 << (2 * c)      # column's link is ancestor-or-self of the row's: deep = row
+            elif is_anc(dof_link[r], dof_link[c]):
+                code |= 2 << (2 * c)      # column's link is a strict descendant: deep = column
+        rel.append(code)
+    o.append("/* 2 bits per column: 1 = column dof is ancestor-or-self of the row dof, 2 = strict descendant, 0 = unrelated */\n")
+    o.append(ca("cp_dof_rel", rel, "%d", "int", 13))
+    act_of = [-1] * m3.nv
+    for a, A in enumerate(mj["acts"]):
+        act_of[A["dof"]] = a
+    o.append(ca("cp_dof_act", act_of, "%d", "int", 13))
+    # compact 8-entry Jacobian layout: [0..2] base dofs, [3..7] the five dofs of the row's leg
+    def pathmask8(li):
+        if li == 0:
+            return 0b111
+        leg0 = 3 if li <= 5 else 8
+        mk = 0b111
+        p = li
+        while p > 0:
+            mk |= 1 << (3 + pl["links"][p]["dof"] - leg0)
+            p = parent[p]
+        return mk
+    o.append(ca("cp_link_pathmask8", [pathmask8(li) for li in range(nl)], "%d", "int", 11))
+    LIMIT_DOFS = [d for d in range(m3.nv) if m3.joints[d]["limited"]]
+    assert LIMIT_DOFS == [3, 4, 5, 6, 8, 9, 10, 11]
+    nslot = 4 + 8 + 2 * len(pl["spheres"])
+    kind, leg, l1, l2, comp, ldof = [], [], [], [], [], []
+    d1 = {s_: [] for s_ in ("mj", "rbdl")}
+    d2 = {s_: [] for s_ in ("mj", "rbdl")}
+    rad, invw = [], []
+    for sl in range(nslot):
+        if sl < 4:
+            e, c = sl // 2, sl % 2
+            kind.append(0); leg.append(e); comp.append(c); ldof.append(-1)
+            l1.append(pl["eqs"][e]["link1"]); l2.append(pl["eqs"][e]["link2"])
+            for s_ in ("mj", "rbdl"):
+                d1[s_].append(planars[s_]["eqs"][e]["d1"]); d2[s_].append(planars[s_]["eqs"][e]["d2"])
+            rad.append(0.0); invw.append(pl["eqs"][e]["invweight"])
+        elif sl < 12:
+            d = LIMIT_DOFS[sl - 4]
+            kind.append(1); leg.append((sl - 4) // 4); comp.append(0); ldof.append(d)
+            l1.append(0); l2.append(0)
+            for s_ in ("mj", "rbdl"):
+                d1[s_].append([0.0, 0.0]); d2[s_].append([0.0, 0.0])
+            rad.append(0.0); invw.append(consts["mj"]["dof_invweight0"][d])
+        else:
+            c = (sl - 12) // 2
+            S = pl["spheres"][c]
+            kind.append(2 + (sl - 12) % 2); leg.append(0 if S["link"] <= 5 else 1); comp.append(1 - (sl - 12) % 2)
+            ldof.append(-1); l1.append(S["link"]); l2.append(0)
+            for s_ in ("mj", "rbdl"):
+                d1[s_].append(S["d"]); d2[s_].append([0.0, 0.0])
+            rad.append(S["r"]); invw.append(S["invweight"])
+    o.append("/* Cassie2dEnv.reset pose (rllab/envs/cassie2d.py:79-85) and Cassie2d ctor pose (Cassie2d.cpp:56-58) */\n")
+    o.append(ca("cp_env_qinit", [0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407,
+                                 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407]))
+    o.append(ca("cp_ctor_qinit", [0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407,
+                                  0.68111815, -1.40730353, 1.62972043, -1.77611107, -0.61968402]))
+    o.append("/* fixed constraint slots: 0-3 connect rows (Lx,Lz,Rx,Rz), 4-11 joint limits, 12.. contact (normal,tangent) pairs */\n")
+    o.append("#define CP_NSLOT %d\n" % nslot)
+    o.append(ca("cp_slot_kind", kind, "%d", "int", 23))
+    o.append(ca("cp_slot_leg", leg, "%d", "int", 23))
+    o.append(ca("cp_slot_comp", comp, "%d", "int", 23))
+    o.append(ca("cp_slot_dof", ldof, "%d", "int", 23))
+    o.append(ca("cp_slot_link1", l1, "%d", "int", 23))
+    o.append(ca("cp_slot_link2", l2, "%d", "int", 23))
+    o.append(ca("cp_slot_d1", [d1["mj"], d1["rbdl"]]))
+    o.append(ca("cp_slot_d2", [d2["mj"], d2["rbdl"]]))
+    o.append(ca("cp_slot_radius", rad))
+    o.append(ca("cp_slot_invweight", invw))
     o.append("#endif\n")
     with open(path, "w") as f:
         f.write("\n".join(o))

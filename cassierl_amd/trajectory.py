@@ -1,0 +1,58 @@
+"""Reference-gait table: host-side counterpart of rllab/envs/cassie2d_trajectory.py.
+
+`stepdata.bin` holds 1682 rows x 98 float64 (t, qpos35, qvel32, torque10, mpos10, mvel10)
+(cassie2d_trajectory.py:6-14).  The 3-D -> 2-D conversion keeps x, z, pitch (from the base
+quaternion) and hip/knee/ankle/toe + the conrod pitch of each leg (cassie2d_trajectory.py:31-134).
+The file itself is reference data and is not shipped; tests use the small golden fixture
+tests/golden/traj2d.npz generated from it.
+"""
+import numpy as np
+
+QPOS_DROP = [1, 3, 5, 6, 7, 8, 11, 14, 15, 16, 17, 19, 20, 21, 22, 25, 28, 29, 30, 31, 33, 34]
+QVEL_DROP = [1, 3, 5, 6, 7, 10, 13, 14, 15, 16, 18, 19, 20, 23, 26, 27, 28, 29, 31]
+TORQUE_DROP = [0, 1, 5, 6]
+
+
+def quat_pitch(w, x, y, z):
+    """Y angle of the ZYX Euler decomposition (quat2eul in cassie2d_trajectory.py:136-151)."""
+    t2 = 2.0 * (w * y - z * x)
+    t2 = np.clip(t2, -1.0, 1.0)
+    return np.arcsin(t2)
+
+
+class Cassie2dTraj:
+    def __init__(self, filepath=None, data=None):
+        if data is None:
+            data = np.fromfile(filepath, dtype=np.double).reshape((-1, 98))
+        self.time = data[:, 0].copy()
+        qpos = data[:, 1:36].copy()
+        qvel = data[:, 36:68].copy()
+        torque = data[:, 68:78].copy()
+        self.mpos = data[:, 78:88].copy()
+        self.mvel = data[:, 88:98].copy()
+        for base in (3, 17, 31):  # base, left conrod, right conrod quaternions -> pitch stored in slot +1
+            qpos[:, base + 1] = quat_pitch(qpos[:, base], qpos[:, base + 1], qpos[:, base + 2], qpos[:, base + 3])
+        self.qpos = np.delete(qpos, QPOS_DROP, axis=1)
+        self.qvel = np.delete(qvel, QVEL_DROP, axis=1)
+        self.torque = np.delete(torque, TORQUE_DROP, axis=1)
+
+    @classmethod
+    def from_arrays(cls, time, qpos, qvel=None, torque=None):
+        self = cls.__new__(cls)
+        self.time, self.qpos = np.asarray(time, dtype=np.float64), np.asarray(qpos, dtype=np.float64)
+        self.qvel = None if qvel is None else np.asarray(qvel, dtype=np.float64)
+        self.torque = None if torque is None else np.asarray(torque, dtype=np.float64)
+        self.mpos = self.mvel = None
+        return self
+
+    def index(self, t):
+        tmax = self.time[-1]
+        return int((t % tmax) / tmax * len(self.time))
+
+    def state(self, t):
+        i = self.index(t)
+        return (self.qpos[i], self.qvel[i])
+
+    def action(self, t):
+        i = self.index(t)
+        return (self.mpos[i], self.mvel[i], self.torque[i])

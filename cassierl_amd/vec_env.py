@@ -1,0 +1,170 @@
+"""Batched Cassie2d environment: host-side mirror of the reference's env classes
+(rllab/envs/cassie2d.py `Cassie2dEnv`, rllab/envs/cassie_stand2d.py) over the batched C-ABI
+(include/cassie_vec.h).  Same vocabulary -- reset() / step(action) / observation_space /
+action_space / control_mode -- but every array has a leading n_envs axis and lives in HBM
+(torch tensors on the MI355X; torch is only the allocator / stream provider here).
+
+No CPU fallback: constructing the env loads libcassie2d.so and needs a HIP device.
+"""
+import ctypes as ct
+
+import numpy as np
+
+from . import _lib
+
+CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2}
+ENV_KINDS = {"walk": 0, "stand": 1}
+FIX_STALE_KIN, FIX_STALE_QSTATE = 1, 2
+STATE_STRIDE = 88
+
+
+class Box:
+    """Minimal stand-in for rllab.spaces.Box (low/high arrays + sample)."""
+
+    def __init__(self, low, high):
+        self.low, self.high = np.asarray(low, dtype=np.float64), np.asarray(high, dtype=np.float64)
+        self.shape = self.low.shape
+
+    def sample(self, rng=np.random):
+        return rng.uniform(self.low, self.high)
+
+
+def action_space(control_mode):
+    """cassie2d.py:343-368."""
+    if control_mode == "OSC":
+        return Box(np.array([-2e1, -2e1, -2e1, 0, -2e1, 0, -2e1]), np.full(7, 2e1))
+    if control_mode == "Torque":
+        high = np.array([12.0, 12.0, 0.9, 12.0, 12.0, 0.9])
+        return Box(-high, high)
+    high = np.radians([80.0, -37.0, -30.0, 80.0, -37.0, -30.0])
+    low = np.radians([-50.0, -164.0, -140.0, -50.0, -164.0, -140.0])
+    return Box(low, high)
+
+
+class CassieVecEnv:
+    """N independent Cassie2d environments stepped by one kernel launch per Env.step."""
+
+    def __init__(self, n_envs, kind="walk", control_mode="PD", n_substeps=10, flags=0, auto_reset=True, device=0,
+                 trajectory=None):
+        assert control_mode in CONTROL_MODES, "Invalid Control Mode"  # cassie2d.py:53
+        self.L = _lib.load()
+        self.n_envs, self.kind, self.control_mode, self.n_substeps = n_envs, kind, control_mode, n_substeps
+        self.device = device
+        cfg = _lib.CassieVecConfig(ENV_KINDS[kind], CONTROL_MODES[control_mode], n_substeps, flags, int(auto_reset))
+        h = ct.c_void_p()
+        rc = self.L.CassieVecCreate(ct.byref(h), n_envs, device, ct.byref(cfg))
+        if rc != 0:
+            raise RuntimeError("CassieVecCreate failed (%d): no HIP device / allocation failure; there is no CPU path" % rc)
+        self.h = h
+        self.adim = self.L.CassieVecActionDim(self.h)
+        if trajectory is not None:
+            self.set_trajectory(trajectory.time, trajectory.qpos)
+        self._torch = None
+
+    # ---------------------------------------------------------------- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libcassie2d error %d: %s" % (rc, self.L.CassieVecLastError(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.CassieVecFree(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_trajectory(self, time, qpos):
+        t = np.ascontiguousarray(time, dtype=np.float64)
+        q = np.ascontiguousarray(qpos, dtype=np.float64)
+        assert q.shape == (len(t), 13)
+        self._chk(self.L.CassieVecSetTrajectory(self.h, t.ctypes.data, q.ctypes.data, len(t)))
+
+    def synchronize(self):
+        self._chk(self.L.CassieVecSynchronize(self.h))
+
+    @property
+    def observation_space(self):
+        high = np.full((26,), 1e20)  # cassie2d.py:337-341
+        return Box(-high, high)
+
+    @property
+    def action_space(self):
+        return action_space(self.control_mode)
+
+    # ---------------------------------------------------------------- host (numpy) API: tests, small batches
+    def reset_host(self):
+        import torch
+        obs = torch.empty((self.n_envs, 26), dtype=torch.float64, device="cuda:%d" % self.device)
+        self._chk(self.L.CassieVecReset(self.h, None, obs.data_ptr()))
+        self.synchronize()
+        return obs.cpu().numpy()
+
+    def step_host(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n_envs, self.adim)
+        obs, rew = np.empty((self.n_envs, 26)), np.empty(self.n_envs)
+        done = np.empty(self.n_envs, dtype=np.uint8)
+        self._chk(self.L.CassieVecStepHost(self.h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data))
+        return obs, rew, done.astype(bool)
+
+    def get_state_host(self):
+        q, v = np.empty((self.n_envs, 13)), np.empty((self.n_envs, 13))
+        self._chk(self.L.CassieVecGetStateHost(self.h, q.ctypes.data, v.ctypes.data))
+        return q, v
+
+    def get_full_state_host(self):
+        s = np.empty((self.n_envs, STATE_STRIDE))
+        self._chk(self.L.CassieVecGetFullStateHost(self.h, s.ctypes.data))
+        return s
+
+    def set_full_state_host(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n_envs, STATE_STRIDE)
+        self._chk(self.L.CassieVecSetStateHost(self.h, s.ctypes.data))
+
+    def debug_substep_host(self, control_mode, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        dbg = np.zeros((self.n_envs, 512))
+        self._chk(self.L.CassieVecDebugSubstepHost(self.h, CONTROL_MODES[control_mode], a.ctypes.data, dbg.ctypes.data))
+        return dbg
+
+    def substep_host(self, control_mode, actions, n_sub=1):
+        import torch
+        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float64), device="cuda:%d" % self.device)
+        self._chk(self.L.CassieVecSubstep(self.h, CONTROL_MODES[control_mode], a.data_ptr(), n_sub))
+        self.synchronize()
+
+    # ---------------------------------------------------------------- device (torch) API: rollouts
+    def alloc(self):
+        import torch
+        dev = "cuda:%d" % self.device
+        return dict(obs=torch.empty((self.n_envs, 26), dtype=torch.float64, device=dev),
+                    reward=torch.empty(self.n_envs, dtype=torch.float64, device=dev),
+                    done=torch.empty(self.n_envs, dtype=torch.uint8, device=dev))
+
+    def use_torch_stream(self):
+        import torch
+        self._chk(self.L.CassieVecSetStream(self.h, ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def reset(self, out=None, mask=None):
+        out = out or self.alloc()
+        self._chk(self.L.CassieVecReset(self.h, None if mask is None else mask.data_ptr(), out["obs"].data_ptr()))
+        return out["obs"]
+
+    def step(self, actions, out=None, terminal_obs=None):
+        """actions: float64 CUDA tensor [n_envs, adim].  Returns (obs, reward, done) tensors (views of `out`)."""
+        out = out or self.alloc()
+        assert actions.is_cuda and actions.dtype.is_floating_point and actions.element_size() == 8 and actions.is_contiguous()
+        self._chk(self.L.CassieVecStep(self.h, actions.data_ptr(), out["obs"].data_ptr(), out["reward"].data_ptr(),
+                                       out["done"].data_ptr(), None if terminal_obs is None else terminal_obs.data_ptr()))
+        return out["obs"], out["reward"], out["done"]
+
+    def time_steps(self, actions, steps, out=None):
+        """Average kernel time (ms) of `steps` back-to-back Env.steps, HIP events on the env's stream."""
+        out = out or self.alloc()
+        ms = ct.c_float()
+        self._chk(self.L.CassieVecTimeSteps(self.h, actions.data_ptr(), steps, out["obs"].data_ptr(), out["reward"].data_ptr(),
+                                            out["done"].data_ptr(), ct.byref(ms)))
+        return ms.value

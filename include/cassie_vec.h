@@ -1,0 +1,97 @@
+/* cassie_vec.h -- batched C-ABI of libcassie2d.so (new entry points).
+ *
+ * The reference steps ONE robot per ctypes call (rllab/envs/cassie2d.py:115-122 crosses the
+ * boundary ten times per Env.step).  These entry points are what a vectorised caller binds
+ * instead: N independent Cassie2d instances resident in HBM, one launch per Env.step.
+ * They replace, for a whole batch:
+ *   CassieVecReset     Cassie2dEnv.reset  (cassie2d.py:78-95)  -> Reset + GetOperationalSpaceState
+ *   CassieVecStep      Cassie2dEnv.step   (cassie2d.py:97-225; cassie_stand2d.py:86-137)
+ *   CassieVecSubstep   lib.StepPd / lib.StepTorque called n times (cassie2d.py:115-122)
+ *   CassieVecGetState / CassieVecGetOpState   lib.GetGeneralState / lib.GetOperationalSpaceState
+ * Plain pointers and sizes only.  Pointers named *_dev are DEVICE pointers (HBM-resident
+ * tensors of the caller, e.g. torch.Tensor.data_ptr()); *_host are host pointers and imply a
+ * synchronous copy.  All calls return 0 on success or a negative CASSIE_E* code;
+ * CassieVecLastError gives the message.  Work is enqueued on the handle's HIP stream.
+ */
+#ifndef CASSIE_VEC_H_
+#define CASSIE_VEC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CASSIE_OK 0
+#define CASSIE_EINVAL (-1)
+#define CASSIE_EHIP (-2)
+#define CASSIE_ENODEVICE (-3)
+
+/* control_mode (module-level `control_mode` string of cassie2d.py:52 / cassie_stand2d.py:50) */
+#define CASSIE_CTRL_PD 0
+#define CASSIE_CTRL_TORQUE 1
+#define CASSIE_CTRL_OSC 2
+/* env_kind */
+#define CASSIE_ENV_WALK 0  /* rllab/envs/cassie2d.py       */
+#define CASSIE_ENV_STAND 1 /* rllab/envs/cassie_stand2d.py */
+/* flags: 0 reproduces the reference bit-for-bit including its stale-state quirks */
+#define CASSIE_FIX_STALE_KIN 1
+#define CASSIE_FIX_STALE_QSTATE 2
+
+#define CASSIE_NQ 13
+#define CASSIE_NOBS 26
+#define CASSIE_STATE_STRIDE 88 /* doubles per environment in the resident state block */
+
+typedef struct CassieVec CassieVec;
+
+typedef struct {
+  int env_kind;      /* CASSIE_ENV_*  */
+  int control_mode;  /* CASSIE_CTRL_* */
+  int n_substeps;    /* physics substeps per Env.step (reference default n=10) */
+  int flags;         /* CASSIE_FIX_*  */
+  int auto_reset;    /* 1: envs that terminate are reset inside the step and return the reset observation */
+} CassieVecConfig;
+
+int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConfig* cfg);
+void CassieVecFree(CassieVec* h);
+const char* CassieVecLastError(const CassieVec* h);
+int CassieVecNumEnvs(const CassieVec* h);
+int CassieVecActionDim(const CassieVec* h);
+int CassieVecSetStream(CassieVec* h, void* hip_stream);
+int CassieVecSynchronize(CassieVec* h);
+
+/* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */
+int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* qpos_host, int n);
+
+/* masked reset to the Cassie2dEnv.reset pose; mask_dev == NULL resets every env; obs_dev may be NULL */
+int CassieVecReset(CassieVec* h, const uint8_t* mask_dev, double* obs_dev);
+/* Cassie2d::Reset with caller-provided states ([n][13] each, device) */
+int CassieVecResetTo(CassieVec* h, const uint8_t* mask_dev, const double* qpos_dev, const double* qvel_dev, double* obs_dev);
+
+/* one Env.step for every env: actions [n][adim] -> obs [n][26], reward [n], done [n]; terminal_obs_dev may be NULL */
+int CassieVecStep(CassieVec* h, const double* actions_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev,
+                  double* terminal_obs_dev);
+/* n_sub raw Step{Pd,Torque} calls per env, no observation */
+int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, int n_sub);
+
+int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev);      /* [n][13] each */
+int CassieVecGetOpState(CassieVec* h, double* x18_dev);                      /* [n][18], operational_state_to_array order */
+void* CassieVecStatePtr(CassieVec* h);                                       /* device pointer to [n][CASSIE_STATE_STRIDE] */
+
+/* host-pointer conveniences (synchronous) */
+int CassieVecStepHost(CassieVec* h, const double* actions_host, double* obs_host, double* reward_host, uint8_t* done_host);
+int CassieVecGetStateHost(CassieVec* h, double* qpos_host, double* qvel_host);
+int CassieVecSetStateHost(CassieVec* h, const double* state_host /*[n][88]*/);
+int CassieVecGetFullStateHost(CassieVec* h, double* state_host /*[n][88]*/);
+
+/* test hook: one substep for every env with a per-stage debug record ([n][512] doubles, host) */
+int CassieVecDebugSubstepHost(CassieVec* h, int control_mode, const double* actions_host, double* debug_host);
+/* kernel timing helper for bench.py: launches `steps` Env.steps back to back on the handle's stream and
+ * returns the average kernel time in milliseconds measured with HIP events on that stream */
+int CassieVecTimeSteps(CassieVec* h, const double* actions_dev, int steps, double* obs_dev, double* reward_dev,
+                       uint8_t* done_dev, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
