@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def traj():
+    d = np.load(os.path.join(GOLDEN, "traj2d.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def streams():
+    d = np.load(os.path.join(GOLDEN, "env_streams.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle_py
+    oracle_py.build()
+    return oracle_py
+
+
+def state_vec(q, v, ws=None, kq=None, kv=None, ctrl=None, qstate=None, time=0.0):
+    """88-double resident state record (cassie_vec_layout.h)."""
+    s = np.zeros(88)
+    s[0:13], s[13:26] = q, v
+    if ws is not None:
+        s[26:39] = ws
+    s[39:52] = q if kq is None else kq
+    s[52:65] = v if kv is None else kv
+    if qstate is not None:
+        s[65:78] = qstate
+    if ctrl is not None:
+        s[78:84] = ctrl
+    s[84] = time
+    return s

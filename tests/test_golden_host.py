@@ -1,0 +1,69 @@
+"""Host-side mirror (structs, converters, gait table) against golden vectors generated from the
+reference's importable Python modules (tests/golden/make_golden.py)."""
+import ctypes as ct
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from cassierl_amd import structs as S
+from cassierl_amd.trajectory import Cassie2dTraj
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(GOLDEN, "structs_kat.json")) as f:
+        return json.load(f)
+
+
+def test_struct_sizes_and_offsets(kat):
+    # RobotInterface.h:14-50 == cassie2d_structs.py:5-51 : 48/48/56/48/208/144 bytes, no padding
+    assert kat["sizes"] == {"ControllerTorque": 48, "ControllerForce": 48, "ControllerOsc": 56, "ControllerPd": 48,
+                            "StateGeneral": 208, "StateOperationalSpace": 144}
+    for name, size in kat["sizes"].items():
+        cls = getattr(S, name)
+        assert ct.sizeof(cls) == size
+        for field, off in kat["offsets"][name].items():
+            assert getattr(cls, field).offset == off
+
+
+def test_converters_match_reference(kat):
+    cv = S.InterfaceStructConverter()
+    for c in kat["cases"]:
+        g = cv.array_to_general_state(np.array(c["general_in"]))
+        got = [list(g.base_pos), list(g.base_vel), list(g.left_pos), list(g.left_vel), list(g.right_pos), list(g.right_vel)]
+        assert got == c["general_struct"]
+        assert cv.general_state_to_array(g).tolist() == c["general_roundtrip"]
+        x = S.StateOperationalSpace()
+        for k, f in enumerate(("body_x", "body_xd", "left_x", "left_xd", "right_x", "right_xd")):
+            for i in range(3):
+                getattr(x, f)[i] = c["op_vals"][3 * k + i]
+        arr = cv.operational_state_to_array(x)
+        assert arr.tolist() == c["op_array"]
+        assert cv.operational_state_array_to_pos_invariant_array(arr).tolist() == c["pos_invariant"]
+        a = np.array(c["action_in"])
+        osc = cv.array_to_operational_action(a)
+        assert [list(osc.body_xdd), list(osc.left_xdd), list(osc.right_xdd), osc.pitch_add] == c["osc"]
+        assert list(cv.array_to_pd_action(a).angles) == c["pd"]
+        assert list(cv.array_to_torque_action(a).torques) == c["torque"]
+
+
+def test_trajectory_lookup_semantics(kat, traj):
+    assert kat["traj"]["shape_qpos"] == [1682, 13] and kat["traj"]["shape_qvel"] == [1682, 13] and kat["traj"]["shape_torque"] == [1682, 6]
+    assert abs(kat["traj"]["tmax"] - 0.8405) < 1e-6
+    tr = Cassie2dTraj.from_arrays(traj["time"], traj["qpos"], traj["qvel"], traj["torque"])
+    np.testing.assert_allclose(tr.qpos[0], [0, 1.02381778, 0.03906015, 0.44288826, 0.95879775, 0.02641815, -0.28239858,
+                                            -1.57079633, 0.35547572, 0.99434882, -0.00622221, -0.10587036, -1.57079633], atol=5e-9)
+    for t, i, q in zip(traj["grid"], traj["grid_index"], traj["grid_qpos"]):
+        assert tr.index(t) == i  # includes wrap-around at tmax
+        assert np.array_equal(tr.state(t)[0], q)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/rllab/trajectory/stepdata.bin"), reason="reference data only in the build container")
+def test_trajectory_conversion_from_stepdata(traj):
+    tr = Cassie2dTraj("/root/reference/rllab/trajectory/stepdata.bin")
+    assert np.array_equal(tr.time, traj["time"])
+    np.testing.assert_allclose(tr.qpos, traj["qpos"], rtol=0, atol=1e-15)
+    assert np.array_equal(tr.qvel, traj["qvel"]) and np.array_equal(tr.torque, traj["torque"])

@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on the same seeded inputs.  -m gpu only.
+
+Tolerances (north_star: 1e-5 relative over 1000 steps):
+  * torque mode is non-chaotic -> 1000 free-running substeps, 1e-5 relative on (qpos, qvel)   [measured ~1e-13]
+  * the reference's PD law is chaotic (tests/test_oracle_physics.py::test_sensitivity_documented): a 1e-12
+    perturbation reaches O(1) within ~300 substeps in the oracle itself, so PD parity is asserted
+    (a) teacher-forced per step over 1000 substeps at 1e-9, (b) free-running over the first 100 substeps at 1e-6.
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, state_vec
+
+pytestmark = pytest.mark.gpu
+
+DBG = dict(M=0, BIAS=169, QS=182, F0=195, B=241, R=287, AREF=333, ADIAG=379, F=425, QACC=471, QACCH=484)
+PD_LO, PD_HI = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+TQ = np.array([12.0, 12.0, 0.9] * 2)
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from cassierl_amd.vec_env import CassieVecEnv
+    return CassieVecEnv
+
+
+def rel_err(sg, q1, v1):
+    return max(np.abs(sg[:13] - q1).max() / np.abs(q1).max(), np.abs(sg[13:26] - v1).max() / (1e-3 + np.abs(v1).max()))
+
+
+def test_stage_by_stage_against_planar_spec(vec):
+    from planar_proto import Planar
+    P = Planar()
+    rng = np.random.default_rng(0)
+    n = 6
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    q0 = env.get_full_state_host()[0, :13]
+    states, ctrls = [], []
+    for i in range(n):
+        q = q0 + rng.uniform(-0.05, 0.05, 13); q[1] -= 0.01 * i
+        states.append(state_vec(q, rng.uniform(-1, 1, 13), rng.uniform(-5, 5, 13)))
+        ctrls.append(rng.uniform(-1, 1, 6) * TQ)
+    env.set_full_state_host(np.array(states))
+    dbg = env.debug_substep_host("Torque", np.array(ctrls))
+    after = env.get_full_state_host()
+    for i in range(n):
+        s = states[i]
+        q2, v2, qacc, r = P.step(s[:13], s[13:26], s[26:39], ctrls[i])
+        d = dbg[i]
+        np.testing.assert_allclose(d[DBG["M"]:DBG["M"] + 169], r["M"].ravel(), atol=1e-13)
+        np.testing.assert_allclose(d[DBG["BIAS"]:DBG["BIAS"] + 13], r["bias"], atol=1e-11)
+        np.testing.assert_allclose(d[DBG["QS"]:DBG["QS"] + 13], r["qacc_smooth"], rtol=1e-10, atol=1e-9)
+        act = r["active"]
+        np.testing.assert_allclose(d[DBG["R"]:DBG["R"] + 46], np.where(act, r["R"], 0), rtol=1e-13)
+        np.testing.assert_allclose(d[DBG["ADIAG"]:DBG["ADIAG"] + 46], np.where(act, np.diag(r["A"]), 0), rtol=1e-11)
+        np.testing.assert_allclose(d[DBG["B"]:DBG["B"] + 46], np.where(act, r["b"], 0), rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(d[DBG["F0"]:DBG["F0"] + 46], r["f0"], rtol=1e-9, atol=1e-8)
+        np.testing.assert_allclose(d[DBG["F"]:DBG["F"] + 46], r["f"], rtol=1e-8, atol=1e-7)
+        np.testing.assert_allclose(after[i, :13], q2, atol=1e-14)
+        np.testing.assert_allclose(after[i, 13:26], v2, atol=1e-11)
+        np.testing.assert_allclose(after[i, 26:39], qacc, rtol=1e-9, atol=1e-8)
+        assert after[i, 85] == r["niter"]
+    env.close()
+
+
+def test_constructor_matches_cassie2d_ctor(vec, oracle_mod):
+    env = vec(3, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    s = env.get_full_state_host()
+    o = oracle_mod.Oracle()
+    q, v = o.state()
+    for i in range(3):
+        assert np.array_equal(s[i, :13], q) and np.array_equal(s[i, 13:26], v)
+        np.testing.assert_allclose(s[i, 26:39], o.warmstart(), rtol=1e-9, atol=1e-9)  # mj_forward in the ctor
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["Torque", "PD"])
+def test_teacher_forced_1000_substeps(vec, oracle_mod, mode):
+    rng = np.random.default_rng(1)
+    n = 2
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    worst, maxrows = 0.0, 0
+    for i in range(1000):
+        if i % 10 == 0:
+            a = rng.uniform(-1, 1, 6) * TQ if mode == "Torque" else rng.uniform(PD_LO, PD_HI)
+        qo, vo = o.state()
+        env.set_full_state_host(np.tile(state_vec(qo, vo, o.warmstart()), (n, 1)))
+        env.substep_host(mode, np.tile(a, (n, 1)), 1)
+        (o.step_torque if mode == "Torque" else o.step_pd)(a)
+        sg = env.get_full_state_host()
+        assert np.array_equal(sg[0], sg[1])
+        q1, v1 = o.state()
+        worst = max(worst, np.abs(sg[0, :13] - q1).max(), np.abs(sg[0, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+        maxrows = max(maxrows, o.nefc)
+    assert worst < 1e-9, worst
+    assert maxrows >= 18
+    env.close()
+
+
+def test_free_running_torque_1000_substeps(vec, oracle_mod):
+    rng = np.random.default_rng(2)
+    n = 8
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    oracles = [oracle_mod.Oracle() for _ in range(n)]
+    s0 = []
+    for o in oracles:
+        q, v = o.state()
+        s0.append(state_vec(q, v, o.warmstart()))
+    env.set_full_state_host(np.array(s0))
+    worst = 0.0
+    for t in range(100):
+        acts = rng.uniform(-1, 1, (n, 6)) * TQ
+        env.substep_host("Torque", acts, 10)
+        for i, o in enumerate(oracles):
+            for _ in range(10):
+                o.step_torque(acts[i])
+        sg = env.get_full_state_host()
+        for i, o in enumerate(oracles):
+            q1, v1 = o.state()
+            worst = max(worst, rel_err(sg[i], q1, v1))
+    assert worst < 1e-5, worst  # north_star tolerance; measured ~1e-13
+    env.close()
+
+
+def test_free_running_pd_first_100_substeps(vec, oracle_mod):
+    rng = np.random.default_rng(3)
+    n = 4
+    env = vec(n, kind="stand", control_mode="PD", n_substeps=1, auto_reset=False)
+    oracles = [oracle_mod.Oracle() for _ in range(n)]
+    env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in oracles]))
+    worst = 0.0
+    for t in range(10):
+        acts = rng.uniform(PD_LO, PD_HI, (n, 6))
+        env.substep_host("PD", acts, 10)
+        sg = env.get_full_state_host()
+        for i, o in enumerate(oracles):
+            for _ in range(10):
+                o.step_pd(acts[i])
+            worst = max(worst, rel_err(sg[i], *o.state()))
+    assert worst < 1e-6, worst
+    env.close()
+
+
+@pytest.mark.parametrize("tag,kind,mode", [("walk_pd", "walk", "PD"), ("walk_torque", "walk", "Torque"),
+                                          ("stand_torque", "stand", "Torque"), ("stand_pd", "stand", "PD")])
+def test_env_step_against_golden_streams(vec, streams, traj, tag, kind, mode):
+    """Env.step / reset / auto-reset through the batched ABI against streams recorded from the reference's own Python env."""
+    n = 3
+    env = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    obs0 = env.reset_host()
+    np.testing.assert_allclose(obs0, np.tile(streams[tag + "_obs0"], (n, 1)), atol=1e-12)
+    acts = streams[tag + "_actions"]
+    horizon = 40 if mode == "Torque" or kind == "walk" else 8  # PD stand runs free for 10*T substeps: chaos beyond ~100
+    for t in range(horizon):
+        obs, rew, done = env.step_host(np.tile(acts[t], (n, 1)))
+        d = bool(streams[tag + "_done"][t])
+        exp_obs = streams[tag + "_reset_obs"][t] if d else streams[tag + "_obs"][t]
+        assert (done == d).all()
+        np.testing.assert_allclose(rew, streams[tag + "_reward"][t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(obs, np.tile(exp_obs, (n, 1)), rtol=0, atol=2e-7)
+    env.close()
+
+
+def test_env_step_vs_oracle_env_with_quirk_fixes(vec, oracle_mod, traj):
+    tr = dict(time=traj["time"], qpos=traj["qpos"])
+    rng = np.random.default_rng(5)
+    for flags in (0, 1, 3):
+        n = 3
+        env = vec(n, kind="walk", control_mode="Torque", n_substeps=10, auto_reset=True, flags=flags)
+        env.set_trajectory(traj["time"], traj["qpos"])
+        oes = [oracle_mod.OracleEnv("walk", "Torque", flags=flags, traj=tr) for _ in range(n)]
+        np.testing.assert_allclose(env.reset_host(), np.array([e.reset() for e in oes]), atol=1e-12)
+        for t in range(15):
+            acts = rng.uniform(-1, 1, (n, 6)) * TQ
+            obs, rew, done = env.step_host(acts)
+            for i, e in enumerate(oes):
+                o, r, d = e.step(acts[i])
+                if d:
+                    o = e.reset()
+                assert d == done[i] and abs(r - rew[i]) < 1e-9
+                np.testing.assert_allclose(obs[i], o, atol=1e-7)
+        env.close()
+
+
+def test_edge_cases_limits_many_contacts_single_env(vec, oracle_mod):
+    # (a) n_envs = 1 (b) joint limits active (c) collapsed robot: many simultaneous contacts incl. pelvis/thigh/shin spheres
+    env = vec(1, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    maxcon, maxlim = 0, 0
+    push = np.array([12.2, -12.2, 0.9, 12.2, -12.2, 0.9])
+    for i in range(5000):
+        a = push if (i < 800) else np.zeros(6)   # drives all 8 limited joints into their limits, then collapses
+        if i == 1200:                             # second scenario: passive collapse from the reset pose (7 contacts)
+            o = oracle_mod.Oracle()
+        if i >= 1200:
+            a = np.zeros(6)
+        if i % 20 == 0:  # teacher-forced comparison every 25 substeps along a fall with limits and many contacts
+            q, v = o.state()
+            env.set_full_state_host(state_vec(q, v, o.warmstart())[None])
+            env.substep_host("Torque", a[None], 1)
+            o.step_torque(a)
+            sg = env.get_full_state_host()[0]
+            q1, v1 = o.state()
+            assert np.abs(sg[:13] - q1).max() < 1e-10 and np.abs(sg[13:26] - v1).max() < 1e-8 * (1 + np.abs(v1).max())
+            e = o.efc()
+            maxcon = max(maxcon, o.ncon); maxlim = max(maxlim, int((e["type"] == 1).sum()))
+        else:
+            o.step_torque(a)
+    assert maxcon >= 6 and maxlim >= 6, (maxcon, maxlim)
+    env.close()
+
+
+def test_full_size_properties_65536_envs(vec, traj):
+    """BASELINE full size: size-independent properties instead of the (too slow) oracle."""
+    import torch
+    n = 65536
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False)
+    out = env.alloc()
+    rng = np.random.default_rng(9)
+    base = rng.uniform(-1, 1, (64, 6)) * TQ
+    acts = np.tile(base, (n // 64, 1))
+    # mirror property: env 2k+1 gets the left/right-swapped action of env 2k
+    acts[1::2] = acts[0::2][:, [3, 4, 5, 0, 1, 2]]
+    a = torch.as_tensor(acts, device="cuda")
+    for _ in range(3):
+        env.step(a, out)
+    env.synchronize()
+    q, v = env.get_state_host()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    # determinism / index independence: envs with identical inputs are bit-identical wherever they sit in the grid
+    assert np.array_equal(q[:128], q[-128:]) and np.array_equal(v[:128], v[n // 2:n // 2 + 128])
+    # left/right mirror symmetry (PGS sweeps left rows first in both, so equality is to solver accuracy)
+    swap = np.r_[0:3, 8:13, 3:8]
+    np.testing.assert_allclose(q[1::2][:, swap], q[0::2], atol=2e-4)
+    assert np.abs(q[:, 1] - 0.939).max() < 0.2  # nobody exploded in 30 substeps
+    env.close()
+
+
+def test_legacy_abi_batch_of_one(oracle_mod):
+    """The ten reference symbols (Cassie2d.cpp:15-27), driven exactly like rllab/envs/cassie2d.py drives them."""
+    from cassierl_amd import _lib
+    from cassierl_amd import structs as S
+    L = _lib.load()
+    L.Reset.argtypes = [ct.c_void_p, ct.POINTER(S.StateGeneral)]
+    L.StepPd.argtypes = [ct.c_void_p, ct.POINTER(S.ControllerPd)]
+    L.StepTorque.argtypes = [ct.c_void_p, ct.POINTER(S.ControllerTorque)]
+    L.GetGeneralState.argtypes = [ct.c_void_p, ct.POINTER(S.StateGeneral)]
+    L.GetOperationalSpaceState.argtypes = [ct.c_void_p, ct.POINTER(S.StateOperationalSpace)]
+    L.Display.argtypes = [ct.c_void_p, ct.c_bool]
+    h = L.Cassie2dInit()
+    L.Display(h, True)
+    cv = S.InterfaceStructConverter()
+    qinit = np.array([0.0, 0.939, 0.0, 0.0, 0.0, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407, 0, 0, 0, 0, 0,
+                      0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407, 0, 0, 0, 0, 0])
+    L.Reset(h, cv.array_to_general_state(qinit))
+    o = oracle_mod.Oracle()
+    q, v = S.general_array_to_qpos_qvel(qinit)
+    o.reset(q, v)
+    xs = S.StateOperationalSpace()
+    L.GetOperationalSpaceState(h, ct.byref(xs))
+    np.testing.assert_allclose(cv.operational_state_to_array(xs), o.opstate(0), atol=1e-13)
+    rng = np.random.default_rng(6)
+    for t in range(30):
+        a = rng.uniform(-1, 1, 6) * TQ
+        L.StepTorque(h, ct.byref(cv.array_to_torque_action(a)))
+        o.step_torque(a)
+    qs = S.StateGeneral()
+    L.GetGeneralState(h, ct.byref(qs))
+    qg, vg = S.general_array_to_qpos_qvel(cv.general_state_to_array(qs))
+    q1, v1 = o.state()
+    np.testing.assert_allclose(qg, q1, atol=1e-11)
+    np.testing.assert_allclose(vg, v1, atol=1e-9)
+    L.GetOperationalSpaceState(h, ct.byref(xs))
+    np.testing.assert_allclose(cv.operational_state_to_array(xs), o.opstate(0), atol=1e-10)
+    L.Render(h)
