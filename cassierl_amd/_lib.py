@@ -27,7 +27,8 @@ EXPORTS = [
 
 
 def lib_path():
-    return _build.LIB
+    # CASSIE2D_LIB lets experiments (A/B kernel builds) point at another build of the same HIP extension
+    return os.environ.get("CASSIE2D_LIB", _build.LIB)
 
 
 def load():

@@ -72,8 +72,14 @@ cassie::VecParams make_params(CassieVec* h) {
 
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   dim3 grid(h->n), block(64);
-  if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL(cassie::env_step_kernel<0>, grid, block, 0, h->stream, p);
-  else if (mode == CASSIE_CTRL_TORQUE) hipLaunchKernelGGL(cassie::env_step_kernel<1>, grid, block, 0, h->stream, p);
+  const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
+  if (mode == CASSIE_CTRL_PD) {
+    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<0, 4>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<0, 3>), grid, block, 0, h->stream, p);
+  } else if (mode == CASSIE_CTRL_TORQUE) {
+    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3>), grid, block, 0, h->stream, p);
+  }
   else return fail(h, CASSIE_EINVAL, "control mode %d has no HIP kernel in this build (OSC / Jacobian: later round)", mode);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;

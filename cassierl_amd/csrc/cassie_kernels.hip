@@ -242,6 +242,8 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
   if (c.dvalid && c.grp == 0) { sm.s1x[c.d] = s1x; sm.s1z[c.d] = s1z; sm.s2[c.d] = s2; }
   lds_sync();
   // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal)
+  double tau, qs;
+  {
   double Mr[NV];
   static_for<0, NV>([&](auto cc) {
     constexpr int C = decltype(cc)::value;
@@ -291,9 +293,10 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
   // ---- smooth forces and unconstrained acceleration
   double v_d = sm.v[c.d < NV ? c.d : 0];
   double u = ctrl < c.clo ? c.clo : (ctrl > c.chi ? c.chi : ctrl);
-  double tau = -c.damping * v_d - bias + c.gear * u;
-  double qs = 0.0;
+  tau = -c.damping * v_d - bias + c.gear * u;
+  qs = 0.0;
   static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mr[C] * row_bcast<C>(tau); });
+  }  // Mr dies here; the inverse rows are re-read from LDS after the solve
   if (c.dvalid && c.grp == 0) { sm.tau[c.d] = tau; sm.qs[c.d] = qs; }
   lds_sync();
   if (dbg && c.dvalid && c.grp == 0) dbg[DBG_QS + c.d] = qs;
@@ -425,10 +428,13 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     dbg[DBG_AREF + lane] = active ? aref : 0.0; dbg[DBG_ADIAG + lane] = active ? Adiag : 0.0;
   }
   // ---- PGS (mj_solPGS, elliptic cones): residual per lane, delta broadcast by v_readlane
+  // Divisions by loop-invariant quantities are replaced by multiplications with reciprocals computed once per
+  // substep (1/A_nn, 1/A_tt); the only per-iteration division left is the ray step's 1/denom.
   const double scale = 1.0 / (CP_MEANINERTIA * NV);
+  const double AttInv = 1.0 / Apart;
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
-    double acc = 0.0;
+    double improvement = 0.0;  // wave-uniform: every row's cost change is read back from its owner lane
     // single-row constraints: connect (0..3) and joint limits (4..11)
     static_for<0, SLOT_CON>([&](auto ss) {
       constexpr int S = decltype(ss)::value;
@@ -439,7 +445,8 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
         double chg = d * (0.5 * d * Adiag + res);
         if (chg > 1e-10) { d = 0.0; chg = 0.0; }
         double Dd = rdlane(d, S);
-        if (lane == S) { f += d; acc -= chg; }
+        improvement -= rdlane(chg, S);
+        if (lane == S) f += d;
         res += Ar[S] * Dd;
       }
     });
@@ -460,33 +467,30 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
           double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
           if (denom >= MINVAL) {
             double x = -(fn * rn + ft * rt) / denom;
-            if (fn + x * fn < 0) x = -1.0;
-            double fn0 = fn;
-            fn = fn0 + x * fn0; ft = ft + x * ft;
+            x = x < -1.0 ? -1.0 : x;  // keep the normal force non-negative: fn + x fn >= 0
+            fn = fn + x * fn; ft = ft + x * ft;
           }
         }
         if (fn >= MINVAL) {
           double bc = rt - Att * ot + Ant * (fn - on);
-          double x0 = -bc / Att;
-          double v1 = x0 / mu;
+          double x0 = -bc * AttInv;
+          // QCQP on one friction dimension (mu = CP_CONTACT_MU): unconstrained minimiser unless it leaves the cone
+          double v1 = x0 * (1.0 / mu);
           double val = v1 * v1 - fn * fn;
           ft = x0;
-          if (val >= 1e-10) {
-            double delta = val * Att * mu * mu / (2.0 * v1 * v1);
-            if (delta >= 1e-10) ft = (x0 > 0 ? 1.0 : (x0 < 0 ? -1.0 : 0.0)) * mu * fn;
-          }
+          if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
         }
         double dn = fn - on, dt = ft - ot;
         double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
         if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
         double Dn = rdlane(dn, S), Dt = rdlane(dt, S);
-        if (lane == S) { f += dn; acc -= chg; }
+        improvement -= rdlane(chg, S);
+        if (lane == S) f += dn;
         if (lane == S + 1) f += Dt;
         res += Ar[S] * Dn + Ar[S + 1] * Dt;
       }
     });
     niter = iter + 1;
-    double improvement = wave_sum(acc);
     if (improvement * scale < CP_TOLERANCE) break;
   }
   out.niter = niter;
@@ -505,7 +509,10 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     }
   });
   double acc_d = 0.0;  // group 0: qacc = M^-1 g ; group 1: (M + hB)^-1 g
-  static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; acc_d += Mr[C] * row_bcast<C>(g); });
+  {
+    const double* mrow = (c.grp == 1 ? sm.mhinv : sm.minv) + (c.d < NV ? c.d : 0) * NV;
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; acc_d += mrow[C] * row_bcast<C>(g); });
+  }
   if (dbg && c.dvalid) dbg[(c.grp == 0 ? DBG_QACC : DBG_QACCH) + c.d] = acc_d;
   lds_sync();
   if (c.dvalid && c.grp == 0) sm.ws[c.d] = acc_d;  // qacc_warmstart <- qacc
@@ -554,8 +561,10 @@ __device__ __forceinline__ void opstate18(Smem& sm, const LaneConst& c, int lane
 
 // ---------------------------------------------------------------- the fused Env.step kernel
 // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
-template <int MODE>
-__global__ void __launch_bounds__(64) env_step_kernel(VecParams p) {
+// WPS: waves per SIMD the register allocation is sized for.  4 (128 VGPRs, some spills) wins when the grid is only
+// ~4 waves per SIMD deep (4096 envs); 3 (168 VGPRs, fewer spills) wins on deep grids (measured, profiles/r01_b_*).
+template <int MODE, int WPS>
+__global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   __shared__ Smem sm;
   __shared__ double s18[18];
   const int env = blockIdx.x;
