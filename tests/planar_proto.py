@@ -358,3 +358,157 @@ class Planar:
             s[12 + i] = (x[3][i] + x[4][i]) / 2; s[15 + i] = (xd[3][i] + xd[4][i]) / 2
         s[2], s[5] = q[2], v[2]
         return s
+
+
+# ====================================================================== controllers (planar restatement)
+class PlanarControllers:
+    """Planar form of DynamicState + Cassie2d::StepJacobian / StepOsc (RBDL-semantics tables), as the HIP
+    controller kernels compute them.  y rows/columns of the reference's 3-D matrices are identically zero here and
+    are dropped; the OSC QP is solved in a reduced box-constrained form."""
+
+    W_COM, W_STANCE, W_REST, W_F, MU_OSC = 5.0, 10.0, 0.1, 1e-4, 0.5
+
+    def __init__(self, tables=None):
+        self.P = Planar(tables, sem="rbdl")
+        T = self.P.T
+        self.gear = np.array(T["act"]["gear"]); self.adof = T["act"]["dof"]
+        self.clo = np.array([r[0] for r in T["act"]["ctrlrange"]]); self.chi = np.array([r[1] for r in T["act"]["ctrlrange"]])
+
+    def dyn(self, q, v):
+        P = self.P
+        k = P.fk(q, v)
+        M, bias = P.mass_bias(k)
+        bias = bias + P.damping * v                      # DynamicState.cpp:49-52 (bias -= passive)
+        Jeq, jdq = np.zeros((4, NV)), np.zeros(4)
+        oa = self._origin_acc(k)
+        for e, E in enumerate(P.eqs):
+            p1 = P.point(k, E["link1"], E["d1"]); p2 = P.point(k, E["link2"], E["d2"])
+            Jeq[2 * e:2 * e + 2] = P.jac_point(k, E["link1"], p1) - P.jac_point(k, E["link2"], p2)
+            jdq[2 * e:2 * e + 2] = self._pacc(k, oa, E["link1"], p1) - self._pacc(k, oa, E["link2"], p2)
+        Js, acc = np.zeros((10, NV)), np.zeros(10)
+        for i, sid in enumerate((1, 2, 3, 4, 5)):
+            S = P.sites[sid]
+            p = P.point(k, S["link"], S["d"])
+            Js[2 * i:2 * i + 2] = P.jac_point(k, S["link"], p)
+            acc[2 * i:2 * i + 2] = self._pacc(k, oa, S["link"], p)
+        return dict(M=M, bias=bias, Jeq=Jeq, jdq=jdq, Js=Js, sacc=acc, k=k)
+
+    def _origin_acc(self, k):
+        """velocity-product acceleration of every link origin WITHOUT gravity (RBDL CalcPointAcceleration, qddot=0)."""
+        P = self.P
+        oa = np.zeros((NL, 2))
+        for li, L in enumerate(P.links):
+            p = L["parent"]
+            if p >= 0:
+                oa[li] = oa[p] - k["w"][p] ** 2 * (k["o"][li] - k["o"][p])
+        return oa
+
+    def _pacc(self, k, oa, link, p):
+        return oa[link] - k["w"][link] ** 2 * (p - k["o"][link])
+
+    @staticmethod
+    def pinv_sym(A, tol):
+        w, V = np.linalg.eigh(A)
+        inv = np.where(np.abs(w) > tol, 1.0 / np.where(w == 0, 1, w), 0.0)
+        return (V * inv) @ V.T
+
+    def projector(self, d):
+        Hinv = np.linalg.inv(d["M"])
+        JH = d["Jeq"] @ Hinv
+        P4 = self.pinv_sym(JH @ d["Jeq"].T, 1e-3)
+        Nc = np.eye(NV) - d["Jeq"].T @ P4 @ JH
+        gamma = d["Jeq"].T @ P4 @ d["jdq"]
+        return Hinv, Nc, gamma
+
+    def Bt(self):
+        B = np.zeros((NV, NU))
+        for a in range(NU):
+            B[self.adof[a], a] = self.gear[a]
+        return B
+
+    def ctrl_jacobian(self, q, v, force6):
+        d = self.dyn(q, v)
+        Hinv, Nc, gamma = self.projector(d)
+        # Jc6' f : per foot mean of the two site Jacobians; f = (My, Fx, Fz) -> rows (angular y, linear x, linear z)
+        k, P = d["k"], self.P
+        Jtf = np.zeros(NV)
+        for foot, sids in enumerate(((2, 3), (4, 5))):
+            Fx, Fz, My = force6[3 * foot + 0], force6[3 * foot + 1], force6[3 * foot + 2]
+            for sid in sids:
+                S = P.sites[sid]
+                p = P.point(k, S["link"], S["d"])
+                J = P.jac_point(k, S["link"], p)
+                Jw = np.zeros(NV)
+                for dd in P.path[S["link"]]:
+                    if dd >= 2:
+                        Jw[dd] = P.sigma[dd]  # angular velocity about +y per unit joint rate
+                Jtf += 0.5 * (J[0] * Fx + J[1] * Fz + Jw * My)
+        NcBt = Nc @ self.Bt()
+        U, s, Vt = np.linalg.svd(NcBt, full_matrices=False)
+        sinv = np.where(s > 1e-4, 1.0 / s, 0.0)
+        pinv = (Vt.T * sinv) @ U.T
+        return pinv @ (Nc @ (d["bias"] - Jtf) + gamma)
+
+    def osc_qp(self, q, v, act7):
+        d = self.dyn(q, v)
+        Hinv, Nc, gamma = self.projector(d)
+        mu = self.MU_OSC
+        # targets: rows (site1 x,z), (site2..5 x,z), pitch
+        A = np.vstack([d["Js"], np.eye(NV)[2:3]])
+        adq = np.concatenate([d["sacc"], [0.0]])
+        xdd = np.array([act7[0], act7[1], act7[2], act7[3], act7[2], act7[3], act7[4], act7[5], act7[4], act7[5], act7[6]])
+        W = np.array([self.W_COM] * 2 + [self.W_STANCE] * 8 + [self.W_REST])
+        ce = -Nc @ d["bias"] - gamma
+        cols = [Nc @ self.Bt()[:, a] for a in range(NU)]
+        for c in range(4):  # contact sites 2..5 = Js rows 2+2c (x), 3+2c (z)
+            jx, jz = d["Js"][2 + 2 * c], d["Js"][3 + 2 * c]
+            cols.append(Nc @ (mu * jx + jz)); cols.append(Nc @ (-mu * jx + jz))
+        PQ = Hinv @ np.array(cols).T                    # 13 x 14 : qdd = PQ z + q0
+        q0 = Hinv @ ce
+        T = A @ PQ; t0 = A @ q0 + adq - xdd
+        G = 2 * T.T @ (W[:, None] * T)
+        for c in range(4):
+            blk = self.W_F * np.array([[mu * mu + 1, 1 - mu * mu], [1 - mu * mu, mu * mu + 1]])
+            G[6 + 2 * c:8 + 2 * c, 6 + 2 * c:8 + 2 * c] += blk
+        cvec = 2 * T.T @ (W * t0)
+        lo = np.concatenate([self.clo, np.zeros(8)]); hi = np.concatenate([self.chi, np.full(8, np.inf)])
+        z, iters = box_qp(G, cvec, lo, hi)
+        return z[:6], z, iters, dict(G=G, c=cvec, PQ=PQ, q0=q0)
+
+
+def box_qp(G, c, lo, hi, z0=None, max_iter=60):
+    """min 1/2 z'Gz + c'z, lo <= z <= hi, G SPD.  Primal active-set with masked full-size solves (what the kernel
+    does): a working set of variables held at a bound; one change of the working set per iteration.  A full Newton
+    step on the working set lands exactly on its minimiser, so optimality is decided from multiplier signs only
+    (G is ill-conditioned -- force-regulariser directions have eigenvalues ~5e-5 against 2e7 -- which rules out a
+    small-step test; those weak directions do not influence the motor commands)."""
+    n = len(c)
+    z = np.clip(np.zeros(n) if z0 is None else z0, lo, hi)
+    bound = (z <= lo) | (z >= hi)
+    for it in range(max_iter):
+        g = G @ z + c
+        Gm = G.copy(); rhs = -g.copy()
+        for i in range(n):
+            if bound[i]:
+                Gm[i, :] = 0; Gm[:, i] = 0; Gm[i, i] = 1; rhs[i] = 0
+        d = np.linalg.solve(Gm, rhs)
+        alpha, blk = 1.0, -1
+        for i in range(n):
+            if bound[i]:
+                continue
+            if d[i] > 0 and np.isfinite(hi[i]) and (hi[i] - z[i]) < alpha * d[i]:
+                alpha, blk = (hi[i] - z[i]) / d[i], i
+            elif d[i] < 0 and (lo[i] - z[i]) > alpha * d[i]:
+                alpha, blk = (lo[i] - z[i]) / d[i], i
+        z = z + alpha * d
+        if blk >= 0:
+            z[blk] = hi[blk] if d[blk] > 0 else lo[blk]
+            bound[blk] = True
+            continue
+        g = G @ z + c
+        viol = np.where(bound, np.where(z <= lo, -g, g), -np.inf)   # > 0: the bound is not wanted
+        i = int(np.argmax(viol))
+        if viol[i] <= 1e-9:
+            return z, it + 1
+        bound[i] = False
+    return z, max_iter
