@@ -20,7 +20,7 @@ EXPORTS = [
     # batched ABI (include/cassie_vec.h)
     "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
     "CassieVecSetStream", "CassieVecSynchronize", "CassieVecSetTrajectory", "CassieVecReset", "CassieVecResetTo",
-    "CassieVecStep", "CassieVecSubstep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
+    "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
 ]
@@ -63,6 +63,7 @@ def load():
     L.CassieVecResetTo.argtypes = [vp, u8p, dp, dp, dp]
     L.CassieVecStep.argtypes = [vp, dp, dp, dp, u8p, dp]
     L.CassieVecSubstep.argtypes = [vp, ct.c_int, dp, ct.c_int]
+    L.CassieVecStandingStep.argtypes = [vp, ct.c_int, dp, dp, ct.c_int]
     L.CassieVecGetState.argtypes = [vp, dp, dp]
     L.CassieVecGetOpState.argtypes = [vp, dp]
     L.CassieVecStatePtr.argtypes = [vp]

@@ -14,6 +14,7 @@
 #include "../../include/cassie2d.h"
 #include "../../include/cassie_vec.h"
 #include "cassie_kernels.hip"
+#include "cassie_ctrl.hip"
 
 static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
 static_assert(sizeof(StateGeneral) == 208 && sizeof(StateOperationalSpace) == 144 && sizeof(ControllerOsc) == 56 &&
@@ -80,7 +81,11 @@ int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
     if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3>), grid, block, 0, h->stream, p);
   }
-  else return fail(h, CASSIE_EINVAL, "control mode %d has no HIP kernel in this build (OSC / Jacobian: later round)", mode);
+  else if (mode == CASSIE_CTRL_OSC) {
+    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<2, false>), grid, block, 0, h->stream, p, (const double*)nullptr, (const double*)nullptr);
+  } else if (mode == CASSIE_CTRL_JACOBIAN) {
+    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<3, false>), grid, block, 0, h->stream, p, (const double*)nullptr, (const double*)nullptr);
+  } else return fail(h, CASSIE_EINVAL, "unknown control mode %d", mode);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -192,6 +197,19 @@ int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, 
   cassie::VecParams p = make_params(h);
   p.actions = actions_dev; p.adim = adim_of(control_mode); p.n_sub = n_sub; p.obs = nullptr;
   return launch_step(h, control_mode, p);
+}
+
+int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev, const double* zvel_dev, int n_sub) {
+  if (!h || !zpos_dev || !zvel_dev || n_sub <= 0) return fail(h, CASSIE_EINVAL, "bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  cassie::VecParams p = make_params(h);
+  p.actions = nullptr; p.n_sub = n_sub; p.obs = nullptr;
+  dim3 grid(h->n), block(64);
+  if (control_mode == CASSIE_CTRL_OSC) hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<2, true>), grid, block, 0, h->stream, p, zpos_dev, zvel_dev);
+  else if (control_mode == CASSIE_CTRL_JACOBIAN) hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<3, true>), grid, block, 0, h->stream, p, zpos_dev, zvel_dev);
+  else return fail(h, CASSIE_EINVAL, "standing controllers exist for OSC and Jacobian modes only");
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
 }
 
 int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev) {
@@ -328,7 +346,7 @@ static void legacy_step(Cassie2d* c, int mode, const double* a, int adim) {
 void StepTorque(Cassie2d* c, ControllerTorque* a) { legacy_step(c, CASSIE_CTRL_TORQUE, a->torques, 6); }
 void StepPd(Cassie2d* c, ControllerPd* a) { legacy_step(c, CASSIE_CTRL_PD, a->angles, 6); }
 void StepOsc(Cassie2d* c, ControllerOsc* a) { legacy_step(c, CASSIE_CTRL_OSC, a->body_xdd, 7); }
-void StepJacobian(Cassie2d* c, ControllerForce* a) { legacy_step(c, 3, a->left_force, 6); }
+void StepJacobian(Cassie2d* c, ControllerForce* a) { legacy_step(c, CASSIE_CTRL_JACOBIAN, a->left_force, 6); }
 
 void GetGeneralState(Cassie2d* c, StateGeneral* s) {
   double q[13], v[13];

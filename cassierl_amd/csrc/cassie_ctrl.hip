@@ -1,0 +1,512 @@
+// cassie_ctrl.hip -- in-loop controllers on the MI355X path (included by cassie_cabi.hip after cassie_kernels.hip).
+//
+//   Cassie2d::StepJacobian        src/Cassie2d/Cassie2d.cpp:119-177   (Jacobian-transpose force controller)
+//   Cassie2d::StepOsc             src/Cassie2d/Cassie2d.cpp:179-209   -> OSC_RBDL::RunPTSC / SolveQP (src/OSC_RBDL.cpp:114-291)
+//   DynamicState::UpdateDynamicState  src/DynamicState.cpp:45-91     (M, bias, Bt, Jc, Jeq, JeqdotQdot; RBDL semantics)
+//   pseudoinverse                 src/HelperFunctions.h:8-29
+//   standing_controller_osc / _jacobian   rllab/envs/cassie2d.py:263-331
+//
+// Planar form: the world-y rows/columns of the reference's matrices are identically zero for this mechanism and are
+// dropped.  The OSC QP (39 variables, 13 equalities, 32 pyramid rows, bounds) is solved in the equivalent reduced form
+//   z = (u[6], lambda[8]),  qdd = Hinv (Nc Bt u + Nc Jc' F(lambda) + ce)   (equality block eliminated, M invertible)
+//   contact force of site c:  fx = mu (l1 - l2), fz = l1 + l2, l >= 0        (generators of the 2-D friction cone)
+//   min (T z + t0)' W (T z + t0) + 1/2 1e-4 sum (fx^2 + fz^2),  u in ctrlrange, lambda >= 0
+// i.e. a 14-variable box-constrained strictly convex QP, solved by a primal active-set method whose linear systems are
+// 14x14 masked Gauss-Jordan solves with rows on lanes (tests/planar_proto.py::box_qp is the executable spec; the oracle
+// solves the reference's literal 39-variable formulation, so parity also checks this reduction).
+#ifndef CASSIE_CTRL_HIP_
+#define CASSIE_CTRL_HIP_
+
+namespace cassie {
+
+constexpr int NCR = 15;  // controller rows: 0..3 Jeq (Lx,Lz,Rx,Rz), 4..13 target sites 1..5 (x,z), 14 pitch
+constexpr int NZ = 14;   // QP variables
+constexpr double OSC_W_COM = 5.0, OSC_W_STANCE = 10.0, OSC_W_REST = 0.1, OSC_W_F = 1e-4, OSC_MU = 0.5;  // OSC_RBDL.h:92-98, RobotInterface.h:64
+
+struct CtrlSmem {
+  double Jd[NCR][NV];  // dense controller rows
+  double acc[16];      // JdotQdot of each row (velocity-product acceleration, no gravity)
+  double JH[4][NV];    // Jeq Hinv
+  double S4[16];       // Jeq Hinv Jeq' (4x4)
+  double T[NZ][12];    // T[var][target row]
+  double t0[12];
+  double bias[16];     // NonlinearEffects + damping*qvel (DynamicState.cpp:47-52)
+  double y[16];
+  double U[6][NV];     // Nc Bt columns (Jacobian controller)
+  double act[8];       // controller input (7 accelerations or 6 forces)
+  double u[8];         // controller output
+  double s18[18];
+};
+
+// all-reduce inside every 16-lane row (DPP row rotations)
+template <int CTRLCODE> __device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRLCODE, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRLCODE, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum(double x) {
+  x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x); x += dpp_mov<0x121>(x);
+  return x;
+}
+__device__ __forceinline__ double row_min(double x) {
+  x = fmin(x, dpp_mov<0x128>(x)); x = fmin(x, dpp_mov<0x124>(x)); x = fmin(x, dpp_mov<0x122>(x)); x = fmin(x, dpp_mov<0x121>(x));
+  return x;
+}
+__device__ __forceinline__ double row_max(double x) {
+  x = fmax(x, dpp_mov<0x128>(x)); x = fmax(x, dpp_mov<0x124>(x)); x = fmax(x, dpp_mov<0x122>(x)); x = fmax(x, dpp_mov<0x121>(x));
+  return x;
+}
+
+// pseudoinverse of a symmetric 4x4 (singular values = |eigenvalues|, threshold tol): cyclic Jacobi on wave-uniform registers
+__device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double tol, double (&P)[16]) {
+  double a[4][4], V[4][4];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = 0.5 * (Sin[4 * i + j] + Sin[4 * j + i]); V[i][j] = i == j ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 10; sweep++) {
+    double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[0][3]) + fabs(a[1][2]) + fabs(a[1][3]) + fabs(a[2][3]);
+    double dia = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]) + fabs(a[3][3]);
+    if (off <= 1e-17 * dia) break;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        double apq = a[p][q];
+        if (fabs(apq) > 1e-300) {
+          double th = (a[q][q] - a[p][p]) / (2.0 * apq);
+          double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
+          double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { double kp = a[k][p], kq = a[k][q]; a[k][p] = cs * kp - sn * kq; a[k][q] = sn * kp + cs * kq; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) { double pk = a[p][k], qk = a[q][k]; a[p][k] = cs * pk - sn * qk; a[q][k] = sn * pk + cs * qk; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) { double vp = V[k][p], vq = V[k][q]; V[k][p] = cs * vp - sn * vq; V[k][q] = sn * vp + cs * vq; }
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { double w = a[k][k]; s += fabs(w) > tol ? V[i][k] * V[j][k] / w : 0.0; }
+      P[4 * i + j] = s;
+    }
+}
+
+// ---------------------------------------------------------------- DynamicState + constraint projector (both controllers)
+// Leaves in LDS: sm.minv = Hinv (RBDL semantics), cs.Jd, cs.acc, cs.JH, cs.bias; returns the wave-uniform P4 = (Jeq Hinv Jeq')^+
+// and g4 = P4 * JeqdotQdot.
+__device__ __forceinline__ void ctrl_dyn(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, double (&P4)[16], double (&g4)[4]) {
+  planar_fk<1>(sm, sm.q, sm.v, c, lane);
+  {
+    double Mr[NV], bias;
+    mass_rows<1>(sm, c, lane, Mr, bias, false);
+    gauss_jordan_rows<NV>(Mr, lane);
+    if (c.dvalid && c.grp == 0) {
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
+      cs.bias[c.d] = bias + c.damping * sm.v[c.d];
+    }
+  }
+  // controller rows
+  double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double racc = 0.0;
+  int leg = 0;
+  if (lane < 4) {
+    leg = lane >> 1;
+    const int comp = lane & 1;
+    const int l1 = cp_slot_link1[lane], l2 = cp_slot_link2[lane];
+    double p1x, p1z, p2x, p2z;
+    link_point(sm, l1, cp_slot_d1[1][lane][0], cp_slot_d1[1][lane][1], p1x, p1z);
+    link_point(sm, l2, cp_slot_d2[1][lane][0], cp_slot_d2[1][lane][1], p2x, p2z);
+    const int lb = leg == 0 ? 1 : 6;
+    jac_compact(sm, cp_link_pathmask8[l1], lb, comp, p1x, p1z, 1.0, J);
+    jac_compact(sm, cp_link_pathmask8[l2], lb, comp, p2x, p2z, -1.0, J);
+    double w1 = sm.lw[l1], w2 = sm.lw[l2];
+    double a1 = comp == 0 ? sm.lax[l1] - w1 * w1 * (p1x - sm.lox[l1]) : sm.laz[l1] - w1 * w1 * (p1z - sm.loz[l1]);
+    double a2 = comp == 0 ? sm.lax[l2] - w2 * w2 * (p2x - sm.lox[l2]) : sm.laz[l2] - w2 * w2 * (p2z - sm.loz[l2]);
+    racc = a1 - a2;  // the gravity offset of laz cancels in the difference
+  } else if (lane < 14) {
+    const int sid = 1 + ((lane - 4) >> 1), comp = (lane - 4) & 1;
+    const int l = cp_site_link[sid];
+    leg = l <= 5 ? 0 : 1;
+    double px, pz;
+    link_point(sm, l, cp_site_d[1][sid][0], cp_site_d[1][sid][1], px, pz);
+    jac_compact(sm, cp_link_pathmask8[l], leg == 0 ? 1 : 6, comp, px, pz, 1.0, J);
+    double w = sm.lw[l];
+    racc = comp == 0 ? sm.lax[l] - w * w * (px - sm.lox[l]) : (sm.laz[l] - CP_GRAVITY) - w * w * (pz - sm.loz[l]);
+  } else if (lane == 14) {
+    J[2] = 1.0;  // AddQDDIdx(2): body pitch (Cassie2d.cpp:41)
+  }
+  const int vbase = leg == 0 ? 3 : 8;
+  if (lane < NCR) {
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      double val = 0.0;
+      if constexpr (C < 3) val = J[C];
+      else {
+        int k = C - vbase;
+        static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; if (k == K) val = J[3 + K]; });
+      }
+      cs.Jd[lane][C] = val;
+    });
+    cs.acc[lane] = racc;
+  }
+  lds_sync();
+  // JH = Jeq Hinv (rows 0..3) and S4 = JH Jeq'
+  if (lane < 4) {
+    double X[NV];
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      double s = sm.minv[C * NV + 0] * J[0] + sm.minv[C * NV + 1] * J[1] + sm.minv[C * NV + 2] * J[2];
+      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; s += sm.minv[C * NV + vbase + K] * J[3 + K]; });
+      X[C] = s;
+      cs.JH[lane][C] = s;
+    });
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      double d = 0;
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; d += X[C] * cs.Jd[s4][C]; });
+      cs.S4[4 * lane + s4] = d;
+    }
+  }
+  lds_sync();
+  pinv_sym4(cs.S4, 1e-3, P4);  // pseudoinverse(Jeq*Hinv*Jeq', 1e-3)  (Cassie2d.cpp:134, OSC_RBDL.cpp:171)
+#pragma unroll
+  for (int r = 0; r < 4; r++) g4[r] = P4[4 * r] * cs.acc[0] + P4[4 * r + 1] * cs.acc[1] + P4[4 * r + 2] * cs.acc[2] + P4[4 * r + 3] * cs.acc[3];
+}
+
+// y = Nc w (+ gamma when add_gamma):  Nc = I - Jeq' P4 Jeq Hinv,  gamma = Jeq' P4 JeqdotQdot
+__device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[16], const double (&g4)[4], bool add_gamma, double (&w)[NV]) {
+  double t4[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double s = 0;
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += cs.JH[r][C] * w[C]; });
+    t4[r] = s;
+  }
+  double s4[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    s4[r] = P4[4 * r] * t4[0] + P4[4 * r + 1] * t4[1] + P4[4 * r + 2] * t4[2] + P4[4 * r + 3] * t4[3];
+    if (add_gamma) s4[r] -= g4[r];
+  }
+  static_for<0, NV>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    w[C] -= cs.Jd[0][C] * s4[0] + cs.Jd[1][C] * s4[1] + cs.Jd[2][C] * s4[2] + cs.Jd[3][C] * s4[3];
+  });
+}
+
+// ---------------------------------------------------------------- Cassie2d::StepOsc controller: cs.act[7] -> cs.u[6]
+__device__ __forceinline__ void ctrl_osc(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane) {
+  double P4[16], g4[4];
+  ctrl_dyn(sm, cs, c, lane, P4, g4);
+  // ---- column lanes: 0..5 motors, 6..13 friction-cone generators of contact sites 2..5, 14 the bias column
+  {
+    double w[NV];
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = 0.0; });
+    if (lane < 6) {
+      const int dof = cp_act_dof[lane];
+      const double gear = cp_act_gear[lane];
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = dof == C ? gear : 0.0; });
+    } else if (lane < 14) {
+      const int cidx = (lane - 6) >> 1;
+      const double sg = (lane & 1) ? -OSC_MU : OSC_MU;
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = sg * cs.Jd[6 + 2 * cidx][C] + cs.Jd[7 + 2 * cidx][C]; });
+    } else if (lane == 14) {
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = cs.bias[C]; });
+    }
+    apply_nc(cs, P4, g4, lane == 14, w);  // lane 14: Nc bias + gamma = -ce
+    // x = Hinv y ;  T column = A x  (A = controller rows 4..14)
+    double x[NV];
+    static_for<0, NV>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      double s = 0;
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += sm.minv[R * NV + C] * w[C]; });
+      x[R] = s;
+    });
+    if (lane < 15) {
+#pragma unroll
+      for (int r = 0; r < 11; r++) {
+        double s = 0;
+        static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += cs.Jd[4 + r][C] * x[C]; });
+        if (lane < 14) cs.T[lane][r] = s;
+        else {
+          // t0 = A q0 + AdotQdot - xdd, q0 = Hinv ce = -x ; xdd packing of Cassie2d.cpp:185-193
+          double xdd;
+          if (r == 10) xdd = cs.act[6];
+          else if (r < 2) xdd = cs.act[r];
+          else xdd = r < 6 ? cs.act[2 + (r & 1)] : cs.act[4 + (r & 1)];
+          cs.t0[r] = -s + (r < 10 ? cs.acc[4 + r] : 0.0) - xdd;
+        }
+      }
+    }
+  }
+  lds_sync();
+  // ---- QP data: row i of G and c_i on lane i (< 14)
+  double G[NZ], cq = 0.0;
+  {
+    const int i = lane < NZ ? lane : 0;
+    double Ti[11];
+#pragma unroll
+    for (int r = 0; r < 11; r++) {
+      double wr = r < 2 ? OSC_W_COM : (r < 10 ? OSC_W_STANCE : OSC_W_REST);  // all four contacts desired (Cassie2d.cpp:199)
+      Ti[r] = 2.0 * wr * cs.T[i][r];
+      cq += Ti[r] * cs.t0[r];
+    }
+    static_for<0, NZ>([&](auto jj) {
+      constexpr int Jv = decltype(jj)::value;
+      double s = 0;
+#pragma unroll
+      for (int r = 0; r < 11; r++) s += Ti[r] * cs.T[Jv][r];
+      if (Jv >= 6) {
+        if (lane == Jv) s += OSC_W_F * (OSC_MU * OSC_MU + 1.0);
+        if (lane == (Jv ^ 1) && lane >= 6) s += OSC_W_F * (1.0 - OSC_MU * OSC_MU);
+      }
+      G[Jv] = s;
+    });
+  }
+  const bool isvar = (lane & 15) < NZ && lane < 16;
+  const double lo = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][0] : 0.0;
+  const double hi = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][1] : 1.7976931348623157e308;
+  // ---- primal active-set iterations
+  double z = 0.0;
+  bool bound = lane >= 6, atlo = true;
+  for (int it = 0; it < 60; it++) {
+    double g = cq;
+    static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g += G[Jv] * row_bcast<Jv>(z); });
+    const unsigned bm = (unsigned)(__ballot(bound && isvar) & 0xFFFFu);
+    double Mr[NZ];
+    static_for<0, NZ>([&](auto jj) {
+      constexpr int Jv = decltype(jj)::value;
+      double val = G[Jv];
+      if (bound || ((bm >> Jv) & 1)) val = 0.0;
+      if (Jv == (lane & 15) && (bound || !isvar)) val = 1.0;
+      if (!isvar) val = (Jv == (lane & 15)) ? 1.0 : 0.0;
+      Mr[Jv] = val;
+    });
+    gauss_jordan_rows<NZ>(Mr, lane);
+    const double rhs = (bound || !isvar) ? 0.0 : -g;
+    double d = 0.0;
+    static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; d += Mr[Jv] * row_bcast<Jv>(rhs); });
+    // ratio test
+    double t = 2.0;
+    if (isvar && !bound) {
+      if (d > 0 && lane < 6) t = (hi - z) / d;
+      else if (d < 0) t = (lo - z) / d;
+      if (t < 0) t = 0;
+    }
+    double tmin = rdlane(row_min(t), 0);  // wave-uniform decision taken from the row that holds the QP
+    double alpha = tmin < 1.0 ? tmin : 1.0;
+    z += alpha * d;
+    if (tmin < 1.0) {
+      unsigned hit = (unsigned)(__ballot(isvar && !bound && t == tmin) & 0xFFFFu);
+      int blk = __ffs(hit) - 1;
+      if (lane == blk) { bound = true; atlo = d < 0; z = atlo ? lo : hi; }
+      continue;
+    }
+    // full step: multipliers of the working set at the new point
+    g = cq;
+    static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g += G[Jv] * row_bcast<Jv>(z); });
+    double viol = (bound && isvar) ? (atlo ? -g : g) : -1.0e300;
+    double vmax = rdlane(row_max(viol), 0);
+    if (vmax <= 1e-9) break;
+    unsigned hit = (unsigned)(__ballot(isvar && bound && viol == vmax) & 0xFFFFu);
+    int rel = __ffs(hit) - 1;
+    if (lane == rel) bound = false;
+  }
+  if (lane < 6) cs.u[lane] = z;
+  lds_sync();
+}
+
+// ---------------------------------------------------------------- Cassie2d::StepJacobian controller: cs.act[6] -> cs.u[6]
+__device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, double* dbg = nullptr) {
+  double P4[16], g4[4];
+  ctrl_dyn(sm, cs, c, lane, P4, g4);
+  if (dbg && lane == 0) {
+    for (int i = 0; i < 13; i++) dbg[97 + i] = cs.bias[i];
+    for (int i = 0; i < 4; i++) dbg[110 + i] = g4[i];
+    for (int i = 0; i < 16; i++) dbg[114 + i] = P4[i];
+    for (int i = 0; i < NCR * NV; i++) dbg[130 + i] = cs.Jd[i / NV][i % NV];
+  }
+  // Jc6' f on the dof lanes: per foot the mean of the two 6-D site Jacobians; f = (My, Fx, Fz) (Cassie2d.cpp:139-163)
+  if (c.dvalid && c.grp == 0) {
+    double jtf = 0.0;
+#pragma unroll
+    for (int foot = 0; foot < 2; foot++) {
+      double Fx = cs.act[3 * foot + 0], Fz = cs.act[3 * foot + 1], My = cs.act[3 * foot + 2];
+      // controller rows 6..9 (left foot sites 2,3) / 10..13 (right foot sites 4,5)
+      int r0 = 6 + 4 * foot;
+      double jx = 0.5 * (cs.Jd[r0][c.d] + cs.Jd[r0 + 2][c.d]), jz = 0.5 * (cs.Jd[r0 + 1][c.d] + cs.Jd[r0 + 3][c.d]);
+      // angular Jacobian about +y of the toe link: sigma_d for every hinge on its path
+      int toe = foot == 0 ? 4 : 9;
+      int pm = cp_link_pathmask8[toe];
+      int k = foot == 0 ? c.kL : c.kR;
+      double jw = (k >= 2 && ((pm >> k) & 1)) ? c.sigma : 0.0;
+      jtf += jx * Fx + jz * Fz + jw * My;
+    }
+    cs.y[c.d] = cs.bias[c.d] - jtf;
+  }
+  lds_sync();
+  {
+    double w[NV];
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = 0.0; });
+    if (lane < 6) {
+      const int dof = cp_act_dof[lane];
+      const double gear = cp_act_gear[lane];
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = dof == C ? gear : 0.0; });
+    } else if (lane == 6) {
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = cs.y[C]; });
+    }
+    apply_nc(cs, P4, g4, lane == 6, w);
+    lds_sync();
+    if (lane < 6) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; cs.U[lane][C] = w[C]; }); }
+    if (lane == 6) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; cs.y[C] = w[C]; }); }
+  }
+  lds_sync();
+  // ---- u = pseudoinverse(Nc Bt, 1e-4) * rhs : one-sided Jacobi SVD, row r of U (13x6) and of V (6x6) on lane r
+  const bool rowU = lane < NV, rowV = lane < 6;
+  double Ur[6], Vr[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { Ur[k] = rowU ? cs.U[k][lane < NV ? lane : 0] : 0.0; Vr[k] = (rowV && lane == k) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0.0;  // wave-uniform: rotation parameters are taken from the 16-lane row that holds the matrix
+    static_for<0, 5>([&](auto pp) {
+      constexpr int Pp = decltype(pp)::value;
+      static_for<Pp + 1, 6>([&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        double a = rdlane(row_sum(Ur[Pp] * Ur[Pp]), 0), b = rdlane(row_sum(Ur[Q] * Ur[Q]), 0), cc = rdlane(row_sum(Ur[Pp] * Ur[Q]), 0);
+        if (fabs(cc) > 1e-300 && fabs(cc) > 1e-17 * sqrt(a * b)) {
+          off += fabs(cc) / sqrt(a * b);
+          double zeta = (b - a) / (2.0 * cc);
+          double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          double cs_ = 1.0 / sqrt(1.0 + t * t), sn = cs_ * t;
+          double up = Ur[Pp], uq = Ur[Q];
+          Ur[Pp] = cs_ * up - sn * uq; Ur[Q] = sn * up + cs_ * uq;
+          double vp = Vr[Pp], vq = Vr[Q];
+          Vr[Pp] = cs_ * vp - sn * vq; Vr[Q] = sn * vp + cs_ * vq;
+        }
+      });
+    });
+    if (off < 1e-15) break;
+  }
+  double rhs = rowU ? cs.y[lane < NV ? lane : 0] : 0.0;
+  double u = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double s2 = rdlane(row_sum(Ur[k] * Ur[k]), 0);
+    double pr = rdlane(row_sum(Ur[k] * rhs), 0);
+    double coef = sqrt(s2) > 1e-4 ? pr / s2 : 0.0;
+    u += Vr[k] * coef;
+  }
+  if (lane < 6) cs.u[lane] = u;
+  lds_sync();
+  if (dbg && lane == 0) {
+    for (int i = 0; i < 13; i++) dbg[i] = cs.y[i];
+    for (int i = 0; i < 78; i++) dbg[13 + i] = cs.U[i / NV][i % NV];
+    for (int i = 0; i < 6; i++) dbg[91 + i] = cs.u[i];
+  }
+}
+
+// ---------------------------------------------------------------- scripted standing controllers (cassie2d.py:263-331)
+// Reads the operational-space state exactly as the Python does (GetOperationalSpaceState before the step: stale kinematics).
+template <int CTRL>
+__device__ __forceinline__ void scripted_targets(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, bool fix_kin, double zpos, double zvel) {
+  opstate18(sm, c, lane, fix_kin, cs.s18);
+  if (lane == 0) {
+    const double* s = cs.s18;  // body_x 0..2, body_xd 3..5, left_x 6..8, left_xd 9..11, right_x 12..14, right_xd 15..17
+    if (CTRL == 2) {
+      const double stance_kp = 100.0, com_kp = 100.0, com_kd = 20.0, pitch_kp = 20.0, pitch_kd = 10.0;
+      double xpos_target = (s[6] + s[12]) / 2.0;
+      cs.act[0] = com_kp * (xpos_target - s[0]) + com_kd * (0.0 - s[3]);
+      cs.act[1] = com_kp * (zpos - s[1]) + com_kd * (zvel - s[4]);
+      cs.act[2] = 0.0; cs.act[3] = stance_kp * (-5e-3 - s[7]);
+      cs.act[4] = 0.0; cs.act[5] = stance_kp * (-5e-3 - s[13]);
+      cs.act[6] = pitch_kp * (0.0 - s[2]) + pitch_kd * (0.0 - s[5]);
+    } else {
+      const double com_kp = 200.0, com_kd = 50.0, pitch_kp = 100.0, pitch_kd = 10.0;
+      double xpos_target = (s[6] + s[12]) / 2.0;
+      double fx = com_kp * (xpos_target - s[0]) + com_kd * (0.0 - s[3]);
+      double fz = 0.5 * 9.806 * 31.0 + com_kp * (zpos - s[1]) + com_kd * (zvel - s[4]);
+      double my = pitch_kp * (0.0 - s[2]) + pitch_kd * (0.0 - s[5]);
+      if (fz < 0.0) fz = 0.0;
+      cs.act[0] = fx; cs.act[1] = fz; cs.act[2] = my;
+      cs.act[3] = fx; cs.act[4] = fz; cs.act[5] = my;
+    }
+  }
+  lds_sync();
+}
+
+// ---------------------------------------------------------------- fused controller + physics kernel
+// CTRL: 2 = OSC (StepOsc), 3 = Jacobian (StepJacobian).  SCRIPTED: targets come from standing_controller_* instead of actions.
+template <int CTRL, bool SCRIPTED>
+__global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const double* zpos, const double* zvel) {
+  __shared__ Smem sm;
+  __shared__ CtrlSmem cs;
+  __shared__ double s18[18];
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (env >= p.n_envs) return;
+  double* st = p.state + (size_t)env * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, lane);
+  double s1 = load_state(st, sm, lane);
+  double qstate_l = s1;
+  double time = rdlane(s1, 20);
+  constexpr int ADIM = CTRL == 2 ? 7 : 6;
+  if (!SCRIPTED && lane < ADIM) cs.act[lane] = p.actions[(size_t)env * ADIM + lane];
+  const double zp = SCRIPTED ? zpos[env] : 0.0, zv = SCRIPTED ? zvel[env] : 0.0;
+  lds_sync();
+  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+  StepOut so; so.niter = 0; so.active = 0;
+  int niter_sum = 0;
+  double ctrl = 0.0;
+  for (int sub = 0; sub < p.n_sub; sub++) {
+    if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, fix_kin, zp, zv);
+    if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
+    lds_sync();
+    if (CTRL == 2) ctrl_osc(sm, cs, c, lane);
+    else ctrl_jacobian(sm, cs, c, lane, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
+    ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
+    substep<true>(sm, c, lane, ctrl, so, nullptr);
+    niter_sum += so.niter;
+    time += 0.0005;
+  }
+  if (c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;
+  lds_sync();
+  if (p.obs) {
+    // Env.step of cassie_stand2d.py (control_mode 'OSC'): observation, reward, termination
+    opstate18(sm, c, lane, fix_kin, s18);
+    double sp = 0.0;
+    if (lane < 17) sp = s18[lane + 1];
+    if (lane == 5 || lane == 11) sp -= s18[0];
+    double a2 = 0.0;
+    for (int i = 0; i < ADIM; i++) { double a = SCRIPTED ? 0.0 : p.actions[(size_t)env * ADIM + i]; a2 += a * a; }
+    double z = s18[1];
+    double m = (rdlane(sp, 5) + rdlane(sp, 11)) / 2.0;
+    double reward = 0.0;
+    reward -= 2 * (0.9 - z) * (0.9 - z);
+    reward -= 2 * m * m;
+    reward += 1;
+    reward -= 0.001 * a2;
+    int done = z < 0.5;
+    if (p.terminal_obs && lane < 26) p.terminal_obs[(size_t)env * 26 + lane] = sp;
+    if (done && p.auto_reset) {
+      if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }
+      if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
+      time = 0.0;
+      lds_sync();
+      substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+      opstate18(sm, c, lane, fix_kin, s18);
+      sp = 0.0;
+      if (lane < 17) sp = s18[lane + 1];
+      if (lane == 5 || lane == 11) sp -= s18[0];
+    }
+    if (lane < 26) p.obs[(size_t)env * 26 + lane] = sp;
+    if (lane == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
+  }
+  store_state(st, sm, lane, qstate_l, time, niter_sum);
+}
+
+}  // namespace cassie
+#endif

@@ -219,32 +219,26 @@ __device__ __forceinline__ void store_state(double* st, const Smem& sm, int lane
   }
 }
 
-struct StepOut { int niter; unsigned long long active; };
-
-// ---------------------------------------------------------------- one mj_forward (+ optional Euler integration)
-// On entry sm.q/v/ws hold the state; ctrl is this dof lane's actuator command (pre-clamp).
-template <bool INTEGRATE>
-__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg) {
-  // ---- kinematics
-  planar_fk<0>(sm, sm.q, sm.v, c, lane);
-  // ---- per-dof subtree sums (dof lanes, both groups)
-  double msub = 0, s1x = 0, s1z = 0, s2 = 0, bias = 0;
+// ---------------------------------------------------------------- mass matrix rows and bias on the dof lanes
+// Needs planar_fk<SEM> results in LDS.  Lane (d = lane&15) gets row d of M (+ armature, + h*damping when add_hb) and
+// bias_d = C(q,v) + g(q) (RNE with qacc = 0).  Uses sm.s1x/s1z/s2 as exchange buffers.
+template <int SEM>
+__device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, int lane, double (&Mr)[NV], double& bias, bool add_hb) {
+  double msub = 0, s1x = 0, s1z = 0, s2 = 0;
+  bias = 0;
   const double odx = sm.lox[c.dlink], odz = sm.loz[c.dlink];
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     double rx = sm.lcx[l] - odx, rz = sm.lcz[l] - odz;
     double m = cp_link_mass[l], fx = sm.lfx[l], fz = sm.lfz[l];
     if ((c.submask >> l) & 1) {
-      msub += m; s1x += m * rx; s1z += m * rz; s2 += m * (rx * rx + rz * rz) + cp_link_inertia[0][l];
+      msub += m; s1x += m * rx; s1z += m * rz; s2 += m * (rx * rx + rz * rz) + cp_link_inertia[SEM][l];
       bias += c.d == 0 ? fx : (c.d == 1 ? fz : c.sigma * (fx * rz - fz * rx));
     }
   }
+  lds_sync();  // previous readers of s1x/s1z/s2 are done
   if (c.dvalid && c.grp == 0) { sm.s1x[c.d] = s1x; sm.s1z[c.d] = s1z; sm.s2[c.d] = s2; }
   lds_sync();
-  // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal)
-  double tau, qs;
-  {
-  double Mr[NV];
   static_for<0, NV>([&](auto cc) {
     constexpr int C = decltype(cc)::value;
     double val;
@@ -262,22 +256,24 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
       double slide = SC * (c.d == 0 ? c1z : -c1x);
       val = c.d < 2 ? slide : c.sigma * SC * hh;
     }
-    if (C == c.d) val += c.armature + (c.grp == 1 ? H * c.damping : 0.0);
+    if (C == c.d) val += c.armature + (add_hb ? H * c.damping : 0.0);
     Mr[C] = val;
   });
-  if (dbg && c.dvalid && c.grp == 0) {
-    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dbg[DBG_M + c.d * NV + C] = Mr[C]; });
-    dbg[DBG_BIAS + c.d] = bias;
-  }
   if (!c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mr[C] = (C == (lane & 15)) ? 1.0 : 0.0; }); }
-  // ---- in-register Gauss-Jordan inverse, rows on lanes, both 16-lane groups at once
-  static_for<0, NV>([&](auto kk) {
+}
+
+// In-register Gauss-Jordan inverse of an N x N SPD matrix (N <= 16) held one row per lane inside every 16-lane row of the
+// wave; the four rows of the wave are independent problems executed by the same instruction stream (DPP row_newbcast).
+// Lanes with (lane&15) >= N must hold a zero row.
+template <int N>
+__device__ __forceinline__ void gauss_jordan_rows(double (&Mr)[N], int lane) {
+  static_for<0, N>([&](auto kk) {
     constexpr int K = decltype(kk)::value;
     double piv = row_bcast<K>(Mr[K]);
     double inv = 1.0 / piv;
     double t = Mr[K] * inv;
     bool isk = (lane & 15) == K;
-    static_for<0, NV>([&](auto cc) {
+    static_for<0, N>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
       if constexpr (C != K) {
         double pk = row_bcast<K>(Mr[C]);
@@ -286,6 +282,27 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     });
     Mr[K] = isk ? inv : -t;
   });
+}
+
+struct StepOut { int niter; unsigned long long active; };
+
+// ---------------------------------------------------------------- one mj_forward (+ optional Euler integration)
+// On entry sm.q/v/ws hold the state; ctrl is this dof lane's actuator command (pre-clamp).
+template <bool INTEGRATE>
+__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg) {
+  // ---- kinematics
+  planar_fk<0>(sm, sm.q, sm.v, c, lane);
+  // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal), then both inverses at once
+  double tau, qs;
+  {
+  double Mr[NV];
+  double bias;
+  mass_rows<0>(sm, c, lane, Mr, bias, c.grp == 1);
+  if (dbg && c.dvalid && c.grp == 0) {
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dbg[DBG_M + c.d * NV + C] = Mr[C]; });
+    dbg[DBG_BIAS + c.d] = bias;
+  }
+  gauss_jordan_rows<NV>(Mr, lane);
   if (c.dvalid) {
     double* dst = c.grp == 0 ? sm.minv : sm.mhinv;
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dst[c.d * NV + C] = Mr[C]; });

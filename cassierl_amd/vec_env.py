@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 
-CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2}
+CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2, "Jacobian": 3}
 ENV_KINDS = {"walk": 0, "stand": 1}
 FIX_STALE_KIN, FIX_STALE_QSTATE = 1, 2
 STATE_STRIDE = 88
@@ -134,6 +134,15 @@ class CassieVecEnv:
         import torch
         a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.float64), device="cuda:%d" % self.device)
         self._chk(self.L.CassieVecSubstep(self.h, CONTROL_MODES[control_mode], a.data_ptr(), n_sub))
+        self.synchronize()
+
+    def standing_step_host(self, control_mode, zpos, zvel, n_sub=1):
+        """standing_controller_osc / standing_controller_jacobian (cassie2d.py:263-331) for every env."""
+        import torch
+        dev = "cuda:%d" % self.device
+        zp = torch.as_tensor(np.broadcast_to(np.asarray(zpos, dtype=np.float64), (self.n_envs,)).copy(), device=dev)
+        zv = torch.as_tensor(np.broadcast_to(np.asarray(zvel, dtype=np.float64), (self.n_envs,)).copy(), device=dev)
+        self._chk(self.L.CassieVecStandingStep(self.h, CONTROL_MODES[control_mode], zp.data_ptr(), zv.data_ptr(), n_sub))
         self.synchronize()
 
     # ---------------------------------------------------------------- device (torch) API: rollouts

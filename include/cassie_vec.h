@@ -31,6 +31,7 @@ extern "C" {
 #define CASSIE_CTRL_PD 0
 #define CASSIE_CTRL_TORQUE 1
 #define CASSIE_CTRL_OSC 2
+#define CASSIE_CTRL_JACOBIAN 3 /* lib.StepJacobian (cassie2d.py:331); only through CassieVecSubstep / CassieVecStandingStep */
 /* env_kind */
 #define CASSIE_ENV_WALK 0  /* rllab/envs/cassie2d.py       */
 #define CASSIE_ENV_STAND 1 /* rllab/envs/cassie_stand2d.py */
@@ -71,8 +72,12 @@ int CassieVecResetTo(CassieVec* h, const uint8_t* mask_dev, const double* qpos_d
 /* one Env.step for every env: actions [n][adim] -> obs [n][26], reward [n], done [n]; terminal_obs_dev may be NULL */
 int CassieVecStep(CassieVec* h, const double* actions_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev,
                   double* terminal_obs_dev);
-/* n_sub raw Step{Pd,Torque} calls per env, no observation */
+/* n_sub raw Step{Pd,Torque,Osc,Jacobian} calls per env with a constant action ([n][6], OSC [n][7]), no observation */
 int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, int n_sub);
+/* n_sub calls of standing_controller_osc / standing_controller_jacobian (cassie2d.py:263-331) per env:
+ * zpos_dev / zvel_dev [n] are the CoM height / vertical velocity targets held during the call (squatting.py:14-16
+ * changes them every call, so a squat is n_sub = 1 with new targets per call) */
+int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev, const double* zvel_dev, int n_sub);
 
 int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev);      /* [n][13] each */
 int CassieVecGetOpState(CassieVec* h, double* x18_dev);                      /* [n][18], operational_state_to_array order */

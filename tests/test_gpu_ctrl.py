@@ -1,0 +1,160 @@
+"""In-loop controllers on the HIP path (StepOsc / StepJacobian / standing controllers) against the oracle.  -m gpu only.
+The oracle solves the reference's literal 39-variable OSC QP; the kernel solves the reduced 14-variable box QP, so these
+tests also check that reduction on the device."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+from conftest import state_vec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from cassierl_amd.vec_env import CassieVecEnv
+    return CassieVecEnv
+
+
+def osc_action(rng, scale=1.0):
+    a = rng.uniform(-1, 1, 7) * np.array([3, 3, 1, 1, 1, 1, 3.0]) * scale
+    a[3], a[5] = abs(a[3]), abs(a[5])
+    return a
+
+
+def jac_action(rng):
+    return np.array([rng.uniform(-50, 50), 150 + rng.uniform(-60, 60), rng.uniform(-20, 20)] * 2) + rng.uniform(-5, 5, 6)
+
+
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_teacher_forced_controller_substeps(vec, oracle_mod, mode):
+    rng = np.random.default_rng(21)
+    n = 2
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    worst_state, worst_u = 0.0, 0.0
+    for i in range(400):
+        scale = 1.0 if i < 250 else 8.0
+        a = osc_action(rng, scale) if mode == "OSC" else jac_action(rng)
+        qo, vo = o.state()
+        env.set_full_state_host(np.tile(state_vec(qo, vo, o.warmstart()), (n, 1)))
+        env.substep_host(mode, np.tile(a, (n, 1)), 1)
+        (o.step_osc if mode == "OSC" else o.step_jacobian)(a)
+        sg = env.get_full_state_host()
+        assert np.array_equal(sg[0], sg[1])
+        q1, v1 = o.state()
+        worst_state = max(worst_state, np.abs(sg[0, :13] - q1).max(), np.abs(sg[0, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+        worst_u = max(worst_u, np.abs(sg[0, 78:84] - o.ctrl()).max())
+    assert worst_u < 1e-6, worst_u
+    assert worst_state < 1e-8, worst_state
+    env.close()
+
+
+def test_env_step_osc_golden_stream(vec, streams, traj):
+    n = 2
+    env = vec(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
+    obs0 = env.reset_host()
+    np.testing.assert_allclose(obs0, np.tile(streams["stand_osc_obs0"], (n, 1)), atol=1e-12)
+    acts = streams["stand_osc_actions"]
+    for t in range(40):
+        obs, rew, done = env.step_host(np.tile(acts[t], (n, 1)))
+        assert (done == bool(streams["stand_osc_done"][t])).all()
+        np.testing.assert_allclose(rew, streams["stand_osc_reward"][t], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(obs, np.tile(streams["stand_osc_obs"][t], (n, 1)), rtol=0, atol=1e-5)
+    env.close()
+
+
+def _py_standing_osc(o, zpos, zvel):
+    s = o.opstate(0)
+    act = np.zeros(7)
+    act[2] = 0.0; act[3] = 100.0 * (-5e-3 - s[7])
+    act[4] = 0.0; act[5] = 100.0 * (-5e-3 - s[13])
+    xt = (s[6] + s[12]) / 2.0
+    act[0] = 100.0 * (xt - s[0]) + 20.0 * (0.0 - s[3])
+    act[1] = 100.0 * (zpos - s[1]) + 20.0 * (zvel - s[4])
+    act[6] = 20.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+    o.step_osc(act)
+
+
+def _py_standing_jac(o, zpos, zvel):
+    s = o.opstate(0)
+    xt = (s[6] + s[12]) / 2.0
+    fx = 200.0 * (xt - s[0]) + 50.0 * (0.0 - s[3])
+    fz = 0.5 * 9.806 * 31.0 + 200.0 * (zpos - s[1]) + 50.0 * (zvel - s[4])
+    my = 100.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+    fz = max(fz, 0.0)
+    o.step_jacobian(np.array([fx, fz, my, fx, fz, my]))
+
+
+def test_standing_controller_osc_free_running(vec, oracle_mod):
+    """config 3 building block: standing_controller_osc(0.9, 0) in the loop, closed loop is stable -> free-running parity."""
+    n = 3
+    env = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    env.reset_host()
+    o = oracle_mod.Oracle()
+    q0 = np.array([0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407] + [0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407])
+    o.reset(q0, np.zeros(13))
+    worst = 0.0
+    for blk in range(60):
+        env.standing_step_host("OSC", 0.9, 0.0, 10)
+        for _ in range(10):
+            _py_standing_osc(o, 0.9, 0.0)
+        sg = env.get_full_state_host()
+        q1, v1 = o.state()
+        worst = max(worst, np.abs(sg[0, :13] - q1).max(), np.abs(sg[0, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+    assert worst < 1e-5, worst
+    assert 0.8 < sg[0, 1] < 1.0
+    env.close()
+
+
+def test_squatting_jacobian_controller(vec, oracle_mod):
+    """config 1 (squatting.py): z target 0.7 + 0.25 sin(w t), w = 0.5*3.1415, via standing_controller_jacobian."""
+    env = vec(1, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    env.reset_host()
+    o = oracle_mod.Oracle()
+    q0 = np.array([0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407] + [0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407])
+    o.reset(q0, np.zeros(13))
+    w, t = 0.5 * 3.1415, 0.0
+    worst, zs = 0.0, []
+    for i in range(1200):
+        zt, zv = 0.7 + 0.25 * np.sin(w * t), 0.25 * np.cos(w * t)
+        env.standing_step_host("Jacobian", zt, zv, 1)
+        _py_standing_jac(o, zt, zv)
+        t += 0.0005
+        if i % 50 == 49:
+            sg = env.get_full_state_host()[0]
+            q1, v1 = o.state()
+            worst = max(worst, np.abs(sg[:13] - q1).max(), np.abs(sg[13:26] - v1).max() / (1 + np.abs(v1).max()))
+            zs.append(sg[1])
+    assert worst < 1e-5, worst
+    assert 0.4 < min(zs) and max(zs) < 1.05  # stays up (README acceptance: "Cassie squats")
+    env.close()
+
+
+def test_legacy_abi_osc_and_jacobian(oracle_mod):
+    from cassierl_amd import _lib
+    from cassierl_amd import structs as S
+    L = _lib.load()
+    L.StepOsc.argtypes = [ct.c_void_p, ct.POINTER(S.ControllerOsc)]
+    L.StepJacobian.argtypes = [ct.c_void_p, ct.POINTER(S.ControllerForce)]
+    L.GetGeneralState.argtypes = [ct.c_void_p, ct.POINTER(S.StateGeneral)]
+    h = L.Cassie2dInit()
+    o = oracle_mod.Oracle()
+    cv = S.InterfaceStructConverter()
+    rng = np.random.default_rng(8)
+    for t in range(20):
+        a = osc_action(rng)
+        L.StepOsc(h, ct.byref(cv.array_to_operational_action(a)))
+        o.step_osc(a)
+    for t in range(20):
+        f = jac_action(rng)
+        fs = S.ControllerForce(); fs.left_force[:] = list(f[:3]); fs.right_force[:] = list(f[3:])
+        L.StepJacobian(h, ct.byref(fs))
+        o.step_jacobian(f)
+    qs = S.StateGeneral()
+    L.GetGeneralState(h, ct.byref(qs))
+    qg, vg = S.general_array_to_qpos_qvel(cv.general_state_to_array(qs))
+    q1, v1 = o.state()
+    np.testing.assert_allclose(qg, q1, atol=1e-7)
+    np.testing.assert_allclose(vg, v1, atol=1e-5)
