@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Minimal driver for profiling the dominant kernel (not a test): N Env.steps of the bench workload."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cassierl_amd.vec_env import CassieVecEnv
+from cassierl_amd import rollout as R
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+d = np.load(os.path.join(ROOT, "tests", "golden", "traj2d.npz"))
+env = CassieVecEnv(n, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True)
+env.set_trajectory(d["time"], d["qpos"])
+out = env.alloc(); env.reset(out)
+ids = torch.arange(n, device="cuda")
+for t in range(steps):
+    env.step(R.random_actions(1, ids, t, env.action_space.low, env.action_space.high), out)
+env.synchronize()
+print("done", float(out["reward"].sum()))
