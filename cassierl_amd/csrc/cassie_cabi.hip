@@ -31,6 +31,7 @@ struct CassieVec {
   int traj_n = 0;
   // scratch for the host-pointer conveniences
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
+  double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
   uint8_t* d_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -56,6 +57,11 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
+constexpr int MAXACT = 32;                              // register-resident active constraint columns per row lane
+constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
+constexpr int MAXACT_DBG = 8;                            // debug build of the substep: forces the overflow path in tests
+constexpr int OVF_STRIDE_DBG = (cassie::NSLOT - MAXACT_DBG) * 64;
+
 cassie::VecParams make_params(CassieVec* h) {
   cassie::VecParams p{};
   p.state = h->state;
@@ -68,18 +74,24 @@ cassie::VecParams make_params(CassieVec* h) {
   p.traj_qpos = h->traj_qpos;
   p.traj_tmax = h->traj_tmax;
   p.traj_n = h->traj_n;
+  p.ovf = h->ovf;
+  p.ovf_stride = OVF_STRIDE;
   return p;
 }
 
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   dim3 grid(h->n), block(64);
   const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
-  if (mode == CASSIE_CTRL_PD) {
-    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<0, 4>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<0, 3>), grid, block, 0, h->stream, p);
+  if (p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
+    // test hook: same code with only MAXACT_DBG register-resident columns, so that the workspace path is exercised
+    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::env_step_kernel<0, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
+  } else if (mode == CASSIE_CTRL_PD) {
+    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<0, 4, MAXACT>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<0, 3, MAXACT>), grid, block, 0, h->stream, p);
   } else if (mode == CASSIE_CTRL_TORQUE) {
-    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3>), grid, block, 0, h->stream, p);
+    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4, MAXACT>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3, MAXACT>), grid, block, 0, h->stream, p);
   }
   else if (mode == CASSIE_CTRL_OSC) {
     hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<2, false>), grid, block, 0, h->stream, p, (const double*)nullptr, (const double*)nullptr);
@@ -133,6 +145,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->d_done, n) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->d_q, n * 18 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->d_v, n * 13 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->ovf, n * OVF_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   hipLaunchKernelGGL(cassie::env_init_kernel, dim3((n_envs * cassie::ENV_STRIDE + 255) / 256), dim3(256), 0, h->stream, h->state, n_envs);
@@ -146,7 +159,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;
@@ -276,10 +289,12 @@ int CassieVecDebugSubstepHost(CassieVec* h, int control_mode, const double* a, d
   size_t n = h->n;
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->d_dbg) HIPCHK(h, hipMalloc(&h->d_dbg, n * cassie::DBG_STRIDE * sizeof(double)));
+  if (!h->ovf_dbg) HIPCHK(h, hipMalloc(&h->ovf_dbg, n * OVF_STRIDE_DBG * sizeof(double)));
   HIPCHK(h, hipMemsetAsync(h->d_dbg, 0, n * cassie::DBG_STRIDE * sizeof(double), h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_act, a, n * adim_of(control_mode) * sizeof(double), hipMemcpyHostToDevice, h->stream));
   cassie::VecParams p = make_params(h);
   p.actions = h->d_act; p.adim = adim_of(control_mode); p.n_sub = 1; p.obs = nullptr; p.debug = h->d_dbg;
+  if (control_mode == CASSIE_CTRL_PD || control_mode == CASSIE_CTRL_TORQUE) { p.ovf = h->ovf_dbg; p.ovf_stride = OVF_STRIDE_DBG; }
   int rc = launch_step(h, control_mode, p);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(dbg_host, h->d_dbg, n * cassie::DBG_STRIDE * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -100,12 +100,14 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
 __device__ __forceinline__ void ctrl_dyn(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, double (&P4)[16], double (&g4)[4]) {
   planar_fk<1>(sm, sm.q, sm.v, c, lane);
   {
+    DofConst dc;
+    load_dof_const(dc, c);
     double Mr[NV], bias;
-    mass_rows<1>(sm, c, lane, Mr, bias, false);
+    mass_rows<1>(sm, c, dc, lane, Mr, bias, false);
     gauss_jordan_rows<NV>(Mr, lane);
     if (c.dvalid && c.grp == 0) {
       static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
-      cs.bias[c.d] = bias + c.damping * sm.v[c.d];
+      cs.bias[c.d] = bias + dc.damping * sm.v[c.d];
     }
   }
   // controller rows
@@ -342,7 +344,7 @@ __device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const Lane
       int toe = foot == 0 ? 4 : 9;
       int pm = cp_link_pathmask8[toe];
       int k = foot == 0 ? c.kL : c.kR;
-      double jw = (k >= 2 && ((pm >> k) & 1)) ? c.sigma : 0.0;
+      double jw = (k >= 2 && ((pm >> k) & 1)) ? (c.d == 2 ? 1.0 : -1.0) : 0.0;  // sigma of the hinge
       jtf += jx * Fx + jz * Fz + jw * My;
     }
     cs.y[c.d] = cs.bias[c.d] - jtf;
@@ -458,6 +460,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   const double zp = SCRIPTED ? zpos[env] : 0.0, zv = SCRIPTED ? zvel[env] : 0.0;
   lds_sync();
   const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+  double* ovf = p.ovf + (size_t)env * p.ovf_stride;
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
   double ctrl = 0.0;
@@ -468,7 +471,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
     if (CTRL == 2) ctrl_osc(sm, cs, c, lane);
     else ctrl_jacobian(sm, cs, c, lane, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
     ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
-    substep<true>(sm, c, lane, ctrl, so, nullptr);
+    substep<true, 32>(sm, c, lane, ctrl, so, nullptr, ovf);
     niter_sum += so.niter;
     time += 0.0005;
   }
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
       if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
       time = 0.0;
       lds_sync();
-      substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+      substep<false, 32>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf);
       opstate18(sm, c, lane, fix_kin, s18);
       sp = 0.0;
       if (lane < 17) sp = s18[lane + 1];

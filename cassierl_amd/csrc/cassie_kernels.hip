@@ -75,43 +75,48 @@ struct Smem {
   double site[2][6][4];
 };
 
+// Loop-invariant per-lane ROLE data.  Only small integers stay in registers for the whole kernel; the double-precision
+// per-lane constants are re-read from the (L2-resident) constant tables inside the phase that uses them, through an
+// index the optimiser cannot see through, so that they are never hoisted out of the substep loop and spilled
+// (round-1 PMC profile: 3.5 GB of scratch traffic per launch came from exactly that).
 struct LaneConst {
-  // link role
-  int ancmask;
-  double comx, comz, mass;
-  // dof role
-  int d, grp, dvalid, dlink, submask, rel, act;
-  double sigma, damping, armature, gear, clo, chi;
-  int kL, kR;
-  // row role
-  int kind, leg, comp, rdof, link1, link2, pm1, pm2;
-  double d1x, d1z, d2x, d2z, radius, invw, lim_lo, lim_hi;
-  double solref0, solref1, simp0, simp1, simp2;
+  int ancmask;                                          // link role
+  int d, grp, dvalid, dlink, submask, rel, act, kL, kR; // dof role
+  int kind, leg, comp, rdof, link1, link2, pm1, pm2;    // row role
 };
+struct DofConst { double sigma, damping, armature, gear, clo, chi; };
+struct RowConst { double d1x, d1z, d2x, d2z, radius, invw, lim_lo, lim_hi, solref0, solref1, simp0, simp1, simp2; };
+
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ void load_lane_const(LaneConst& c, int lane) {
   int l = lane < NL ? lane : 0;
   c.ancmask = lane < NL ? cp_link_ancmask[l] : 0;
-  c.comx = cp_link_com[0][l][0]; c.comz = cp_link_com[0][l][1]; c.mass = cp_link_mass[l];
   c.d = lane & 15; c.grp = lane >> 4; c.dvalid = (c.d < NV) && (lane < 32);
   int d = c.d < NV ? c.d : 0;
   c.dlink = cp_dof_link[d]; c.submask = cp_dof_submask[d]; c.rel = cp_dof_rel[d]; c.act = cp_dof_act[d];
-  c.sigma = cp_dof_sigma[d]; c.damping = cp_dof_damping[d]; c.armature = cp_dof_armature[d];
-  int a = c.act >= 0 ? c.act : 0;
-  c.gear = c.act >= 0 ? cp_act_gear[a] : 0.0; c.clo = cp_act_ctrlrange[a][0]; c.chi = cp_act_ctrlrange[a][1];
   c.kL = d < 8 ? d : -1;                     // compact index of this dof in a left-leg row
   c.kR = d < 3 ? d : (d >= 8 ? d - 5 : -1);  // ... in a right-leg row
   int s = lane < NSLOT ? lane : 0;
   c.kind = lane < NSLOT ? cp_slot_kind[s] : -1; c.leg = cp_slot_leg[s]; c.comp = cp_slot_comp[s]; c.rdof = cp_slot_dof[s];
   c.link1 = cp_slot_link1[s]; c.link2 = cp_slot_link2[s];
   c.pm1 = cp_link_pathmask8[c.link1]; c.pm2 = cp_link_pathmask8[c.link2];
-  c.d1x = cp_slot_d1[0][s][0]; c.d1z = cp_slot_d1[0][s][1]; c.d2x = cp_slot_d2[0][s][0]; c.d2z = cp_slot_d2[0][s][1];
-  c.radius = cp_slot_radius[s]; c.invw = cp_slot_invweight[s];
-  int rd = c.rdof >= 0 ? c.rdof : 0;
-  c.lim_lo = cp_jnt_range[rd][0]; c.lim_hi = cp_jnt_range[rd][1];
+}
+__device__ __forceinline__ void load_dof_const(DofConst& k, const LaneConst& c) {
+  int d = opaque(c.d < NV ? c.d : 0);
+  k.sigma = cp_dof_sigma[d]; k.damping = cp_dof_damping[d]; k.armature = cp_dof_armature[d];
+  int a = opaque(c.act >= 0 ? c.act : 0);
+  k.gear = c.act >= 0 ? cp_act_gear[a] : 0.0; k.clo = cp_act_ctrlrange[a][0]; k.chi = cp_act_ctrlrange[a][1];
+}
+__device__ __forceinline__ void load_row_const(RowConst& r, const LaneConst& c, int lane) {
+  int s = opaque(lane < NSLOT ? lane : 0);
+  r.d1x = cp_slot_d1[0][s][0]; r.d1z = cp_slot_d1[0][s][1]; r.d2x = cp_slot_d2[0][s][0]; r.d2z = cp_slot_d2[0][s][1];
+  r.radius = cp_slot_radius[s]; r.invw = cp_slot_invweight[s];
+  int rd = opaque(c.rdof >= 0 ? c.rdof : 0);
+  r.lim_lo = cp_jnt_range[rd][0]; r.lim_hi = cp_jnt_range[rd][1];
   const double* sr = c.kind == 0 ? cp_eq_solref[s >> 1] : (c.kind == 1 ? cp_limit_solref : cp_contact_solref);
   const double* si = c.kind == 0 ? cp_eq_solimp[s >> 1] : (c.kind == 1 ? cp_limit_solimp : cp_contact_solimp);
-  c.solref0 = sr[0]; c.solref1 = sr[1]; c.simp0 = si[0]; c.simp1 = si[1]; c.simp2 = si[2];
+  r.solref0 = sr[0]; r.solref1 = sr[1]; r.simp0 = si[0]; r.simp1 = si[1]; r.simp2 = si[2];
 }
 
 __device__ __forceinline__ double impedance(double d0, double d1, double width, double x) {
@@ -154,11 +159,13 @@ __device__ __forceinline__ void planar_fk(Smem& sm, const double* qsrc, const do
     }
   }
   if (lane < NL) {
-    double cx0 = SEM == 0 ? c.comx : cp_link_com[SEM][lane][0], cz0 = SEM == 0 ? c.comz : cp_link_com[SEM][lane][1];
+    const int lo_ = opaque(lane);
+    double cx0 = cp_link_com[SEM][lo_][0], cz0 = cp_link_com[SEM][lo_][1];
+    const double lmass = cp_link_mass[lo_];
     double rx = cs * cx0 + sn * cz0, rz = -sn * cx0 + cs * cz0;
     sm.lox[lane] = ox; sm.loz[lane] = oz; sm.lvx[lane] = vx; sm.lvz[lane] = vz; sm.lax[lane] = ax; sm.laz[lane] = az;
     sm.lcx[lane] = ox + rx; sm.lcz[lane] = oz + rz;
-    sm.lfx[lane] = c.mass * (ax - w * w * rx); sm.lfz[lane] = c.mass * (az - w * w * rz);
+    sm.lfx[lane] = lmass * (ax - w * w * rx); sm.lfz[lane] = lmass * (az - w * w * rz);
   }
   lds_sync();
 }
@@ -223,7 +230,7 @@ __device__ __forceinline__ void store_state(double* st, const Smem& sm, int lane
 // Needs planar_fk<SEM> results in LDS.  Lane (d = lane&15) gets row d of M (+ armature, + h*damping when add_hb) and
 // bias_d = C(q,v) + g(q) (RNE with qacc = 0).  Uses sm.s1x/s1z/s2 as exchange buffers.
 template <int SEM>
-__device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, int lane, double (&Mr)[NV], double& bias, bool add_hb) {
+__device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, const DofConst& dc, int lane, double (&Mr)[NV], double& bias, bool add_hb) {
   double msub = 0, s1x = 0, s1z = 0, s2 = 0;
   bias = 0;
   const double odx = sm.lox[c.dlink], odz = sm.loz[c.dlink];
@@ -233,7 +240,7 @@ __device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, int lane
     double m = cp_link_mass[l], fx = sm.lfx[l], fz = sm.lfz[l];
     if ((c.submask >> l) & 1) {
       msub += m; s1x += m * rx; s1z += m * rz; s2 += m * (rx * rx + rz * rz) + cp_link_inertia[SEM][l];
-      bias += c.d == 0 ? fx : (c.d == 1 ? fz : c.sigma * (fx * rz - fz * rx));
+      bias += c.d == 0 ? fx : (c.d == 1 ? fz : dc.sigma * (fx * rz - fz * rx));
     }
   }
   lds_sync();  // previous readers of s1x/s1z/s2 are done
@@ -243,7 +250,7 @@ __device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, int lane
     constexpr int C = decltype(cc)::value;
     double val;
     if constexpr (C < 2) {
-      val = c.d < 2 ? (c.d == C ? msub : 0.0) : c.sigma * (C == 0 ? s1z : -s1x);
+      val = c.d < 2 ? (c.d == C ? msub : 0.0) : dc.sigma * (C == 0 ? s1z : -s1x);
     } else {
       constexpr int LC = C == 2 ? 0 : C - 2;
       constexpr double SC = C == 2 ? 1.0 : -1.0;
@@ -254,9 +261,9 @@ __device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, int lane
       double deep_col = c2 + (ocx - odx) * c1x + (ocz - odz) * c1z;
       double hh = code == 1 ? deep_row : (code == 2 ? deep_col : 0.0);
       double slide = SC * (c.d == 0 ? c1z : -c1x);
-      val = c.d < 2 ? slide : c.sigma * SC * hh;
+      val = c.d < 2 ? slide : dc.sigma * SC * hh;
     }
-    if (C == c.d) val += c.armature + (add_hb ? H * c.damping : 0.0);
+    if (C == c.d) val += dc.armature + (add_hb ? H * dc.damping : 0.0);
     Mr[C] = val;
   });
   if (!c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mr[C] = (C == (lane & 15)) ? 1.0 : 0.0; }); }
@@ -286,18 +293,30 @@ __device__ __forceinline__ void gauss_jordan_rows(double (&Mr)[N], int lane) {
 
 struct StepOut { int niter; unsigned long long active; };
 
+// A[i][S] = X_i . J_S for a wave-uniform slot S (compact Jacobian of S read from LDS at a uniform address)
+__device__ __forceinline__ double arow_entry(const Smem& sm, const double (&X)[NV], int S) {
+  const double* js = sm.rowJ[S];
+  const int legS = S < SLOT_LIM ? (S >> 1) : (S < SLOT_CON ? ((S - SLOT_LIM) >> 2) : (((S - SLOT_CON) >> 1) <= 8 ? 0 : 1));
+  double a = X[0] * js[0] + X[1] * js[1] + X[2] * js[2];
+  if (legS == 0) a += X[3] * js[3] + X[4] * js[4] + X[5] * js[5] + X[6] * js[6] + X[7] * js[7];
+  else a += X[8] * js[3] + X[9] * js[4] + X[10] * js[5] + X[11] * js[6] + X[12] * js[7];
+  return a;
+}
+
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler integration)
 // On entry sm.q/v/ws hold the state; ctrl is this dof lane's actuator command (pre-clamp).
-template <bool INTEGRATE>
-__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg) {
+template <bool INTEGRATE, int MAXACT>
+__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg, double* ovf) {
   // ---- kinematics
   planar_fk<0>(sm, sm.q, sm.v, c, lane);
   // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal), then both inverses at once
   double tau, qs;
   {
+  DofConst dc;
+  load_dof_const(dc, c);
   double Mr[NV];
   double bias;
-  mass_rows<0>(sm, c, lane, Mr, bias, c.grp == 1);
+  mass_rows<0>(sm, c, dc, lane, Mr, bias, c.grp == 1);
   if (dbg && c.dvalid && c.grp == 0) {
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; dbg[DBG_M + c.d * NV + C] = Mr[C]; });
     dbg[DBG_BIAS + c.d] = bias;
@@ -309,32 +328,38 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
   }
   // ---- smooth forces and unconstrained acceleration
   double v_d = sm.v[c.d < NV ? c.d : 0];
-  double u = ctrl < c.clo ? c.clo : (ctrl > c.chi ? c.chi : ctrl);
-  tau = -c.damping * v_d - bias + c.gear * u;
+  double u = ctrl < dc.clo ? dc.clo : (ctrl > dc.chi ? dc.chi : ctrl);
+  tau = -dc.damping * v_d - bias + dc.gear * u;
   qs = 0.0;
   static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mr[C] * row_bcast<C>(tau); });
-  }  // Mr dies here; the inverse rows are re-read from LDS after the solve
+  }  // Mr and the dof constants die here; the inverse rows are re-read from LDS after the solve
   if (c.dvalid && c.grp == 0) { sm.tau[c.d] = tau; sm.qs[c.d] = qs; }
   lds_sync();
   if (dbg && c.dvalid && c.grp == 0) dbg[DBG_QS + c.d] = qs;
   // ---- constraint rows on the row lanes (fixed slots)
+  double b, jar, R;
+  bool active = false;
+  unsigned long long amask;
+  double X[NV];
+  {
+  RowConst rc;
+  load_row_const(rc, c, lane);
   double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double pos = 0.0;
-  bool active = false;
   const int legbase = c.leg == 0 ? 1 : 6;
   const int vbase = c.leg == 0 ? 3 : 8;
   const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
   if (c.kind == 0) {
     double p1x, p1z, p2x, p2z;
-    link_point(sm, c.link1, c.d1x, c.d1z, p1x, p1z);
-    link_point(sm, c.link2, c.d2x, c.d2z, p2x, p2z);
+    link_point(sm, c.link1, rc.d1x, rc.d1z, p1x, p1z);
+    link_point(sm, c.link2, rc.d2x, rc.d2z, p2x, p2z);
     jac_compact(sm, c.pm1, legbase, c.comp, p1x, p1z, 1.0, J);
     jac_compact(sm, c.pm2, legbase, c.comp, p2x, p2z, -1.0, J);
     pos = c.comp == 0 ? p1x - p2x : p1z - p2z;
     active = true;
   } else if (c.kind == 1) {
     double qd = sm.q[c.rdof];
-    double dlo = qd - c.lim_lo, dhi = c.lim_hi - qd;
+    double dlo = qd - rc.lim_lo, dhi = rc.lim_hi - qd;
     int k = 3 + c.rdof - vbase;
     double sgn = 0.0;
     if (dlo < 0) { active = true; pos = dlo; sgn = 1.0; }
@@ -342,8 +367,8 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     static_for<3, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; J[K] = (k == K) ? sgn : 0.0; });
   } else if (c.kind >= 2) {
     double cx, cz;
-    link_point(sm, c.link1, c.d1x, c.d1z, cx, cz);
-    double dist = basez + cz - c.radius;
+    link_point(sm, c.link1, rc.d1x, rc.d1z, cx, cz);
+    double dist = basez + cz - rc.radius;
     if (dist < 0) {
       active = true;
       double pz = 0.5 * dist - basez;
@@ -351,8 +376,7 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
       pos = dist;  // both rows of the pair keep the normal distance (shared regulariser); the tangent row's own pos is 0
     }
   }
-  const unsigned long long amask = __ballot(active);
-  out.active = amask;
+  amask = __ballot(active);
   // row velocity, impedance, regulariser, reference acceleration
   double vel = J[0] * sm.v[0] + J[1] * sm.v[1] + J[2] * sm.v[2];
   double bq = J[0] * sm.qs[0] + J[1] * sm.qs[1] + J[2] * sm.qs[2];
@@ -361,56 +385,68 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     constexpr int K = decltype(kk)::value;
     vel += J[3 + K] * sm.v[vbase + K]; bq += J[3 + K] * sm.qs[vbase + K]; jw += J[3 + K] * sm.ws[vbase + K];
   });
-  double tc = c.solref0 < 2.0 * H ? 2.0 * H : c.solref0;
-  double kk_ = 1.0 / (c.simp1 * c.simp1 * tc * tc * c.solref1 * c.solref1), bb_ = 2.0 / (c.simp1 * tc);
-  double imp = impedance(c.simp0, c.simp1, c.simp2, pos);
-  double R = (1.0 - imp) / imp * c.invw;
+  double tc = rc.solref0 < 2.0 * H ? 2.0 * H : rc.solref0;
+  double kk_ = 1.0 / (rc.simp1 * rc.simp1 * tc * tc * rc.solref1 * rc.solref1), bb_ = 2.0 / (rc.simp1 * tc);
+  double imp = impedance(rc.simp0, rc.simp1, rc.simp2, pos);
+  R = (1.0 - imp) / imp * rc.invw;
   R = R > MINVAL ? R : MINVAL;
   double own_pos = c.kind == 3 ? 0.0 : pos;
-  double imp_own = c.kind == 3 ? impedance(c.simp0, c.simp1, c.simp2, 0.0) : imp;
+  double imp_own = c.kind == 3 ? impedance(rc.simp0, rc.simp1, rc.simp2, 0.0) : imp;
   double aref = -bb_ * vel - kk_ * imp_own * own_pos;
-  double b = active ? bq - aref : 0.0;
-  double jar = jw - aref;
+  b = active ? bq - aref : 0.0;
+  jar = jw - aref;
+  if (dbg && lane < NSLOT) { dbg[DBG_R + lane] = active ? R : 0.0; dbg[DBG_AREF + lane] = active ? aref : 0.0; }
   if (lane < NSLOT) { static_for<0, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; sm.rowJ[lane][K] = J[K]; }); }
   // ---- X = M^-1 J' (13 values per row lane)
-  double X[NV];
   {
     const double* mi = sm.minv;
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
-      double s = mi[C * NV + 0] * J[0] + mi[C * NV + 1] * J[1] + mi[C * NV + 2] * J[2];
-      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; s += mi[C * NV + vbase + K] * J[3 + K]; });
-      X[C] = s;
+      double sx = mi[C * NV + 0] * J[0] + mi[C * NV + 1] * J[1] + mi[C * NV + 2] * J[2];
+      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; sx += mi[C * NV + vbase + K] * J[3 + K]; });
+      X[C] = sx;
     });
   }
+  }  // row constants and J die here
+  out.active = amask;
   lds_sync();
-  // ---- A row: A[i][s] = X_i . J_s for active slots (static slot -> static leg -> static register indices)
-  double Ar[NSLOT];
-  static_for<0, NSLOT>([&](auto ss) {
-    constexpr int S = decltype(ss)::value;
-    constexpr int LEG = S < 4 ? S / 2 : (S < 12 ? (S - 4) / 4 : ((S - 12) / 2 <= 8 ? 0 : 1));
-    constexpr int VB = LEG == 0 ? 3 : 8;
-    double a = 0.0;
-    if ((amask >> S) & 1) {
-      const double* js = sm.rowJ[S];
-      a = X[0] * js[0] + X[1] * js[1] + X[2] * js[2] + X[VB] * js[3] + X[VB + 1] * js[4] + X[VB + 2] * js[5] + X[VB + 3] * js[6] +
-          X[VB + 4] * js[7];
-      if (lane == S) a += R;
+  // ---- A row in COMPACT column order: Ac[k] = A[this row][k-th active slot].  Only active columns occupy registers
+  // (MAXACT of them); the slot of column k is recovered by a scalar bit scan of the activity mask, so the unrolled
+  // loops keep static register indices while slots, legs and kinds are wave-uniform run-time values.
+  const int nact = __popcll(amask);
+  double Ac[MAXACT];
+  double Adiag = 1.0, Ant = 0.0;
+  {
+    unsigned long long m = amask;
+    static_for<0, MAXACT>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      double a = 0.0;
+      if (K < nact) {
+        const int S = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        a = arow_entry(sm, X, S);
+        if (lane == S) { a += R; Adiag = a; }
+        if (S >= SLOT_CON && (S & 1) && lane == S - 1) Ant = a;  // A[n][t] on the normal lane of a contact pair
+      }
+      Ac[K] = a;
+    });
+    // columns beyond MAXACT (only when more than MAXACT rows are active): global workspace, slow path
+    for (int k = MAXACT; k < nact; k++) {
+      const int S = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      double a = arow_entry(sm, X, S);
+      if (lane == S) { a += R; Adiag = a; }
+      if (S >= SLOT_CON && (S & 1) && lane == S - 1) Ant = a;
+      ovf[(size_t)(k - MAXACT) * 64 + lane] = a;
     }
-    Ar[S] = a;
-  });
-  // diagonal element and partner data
-  double Adiag = 1.0;
-  static_for<0, NSLOT>([&](auto ss) { constexpr int S = decltype(ss)::value; if (lane == S && active) Adiag = Ar[S]; });
+  }
   double Ainv = 1.0 / Adiag;
   double Apart = swap1(Adiag);  // for a normal lane: A_tt of its tangent partner
-  double Ant = 0.0;             // for a normal lane: A[n][t]
-  static_for<0, (NSLOT - SLOT_CON) / 2>([&](auto pp) { constexpr int S = SLOT_CON + 2 * decltype(pp)::value; if (lane == S) Ant = Ar[S + 1]; });
   // ---- warm start: forces from qacc_warmstart (mj_constraintUpdate), kept only if the dual cost beats zero
   const double mu = CP_CONTACT_MU;
-  double D = 1.0 / R;
   double f = 0.0;
   {
+    double D = 1.0 / R;
     double pj = swap1(jar);
     if (active) {
       if (c.kind == 0) f = -D * jar;
@@ -431,82 +467,99 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     }
   }
   double res = 0.0;  // (A f)_i
-  static_for<0, NSLOT>([&](auto ss) {
-    constexpr int S = decltype(ss)::value;
-    if ((amask >> S) & 1) res += Ar[S] * rdlane(f, S);
-  });
+  {
+    unsigned long long m = amask;
+    static_for<0, MAXACT>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      if (K < nact) { const int S = __ffsll((long long)m) - 1; m &= m - 1; res += Ac[K] * rdlane(f, S); }
+    });
+    for (int k = MAXACT; k < nact; k++) { const int S = __ffsll((long long)m) - 1; m &= m - 1; res += ovf[(size_t)(k - MAXACT) * 64 + lane] * rdlane(f, S); }
+  }
   {
     double cost = wave_sum(active ? f * (0.5 * res + b) : 0.0);
     if (cost > 0) { f = 0.0; res = 0.0; }
   }
   res += b;
-  if (dbg && lane < NSLOT) {
-    dbg[DBG_F0 + lane] = f; dbg[DBG_B + lane] = b; dbg[DBG_R + lane] = active ? R : 0.0;
-    dbg[DBG_AREF + lane] = active ? aref : 0.0; dbg[DBG_ADIAG + lane] = active ? Adiag : 0.0;
-  }
+  if (dbg && lane < NSLOT) { dbg[DBG_F0 + lane] = f; dbg[DBG_B + lane] = b; dbg[DBG_ADIAG + lane] = active ? Adiag : 0.0; }
   // ---- PGS (mj_solPGS, elliptic cones): residual per lane, delta broadcast by v_readlane
   // Divisions by loop-invariant quantities are replaced by multiplications with reciprocals computed once per
   // substep (1/A_nn, 1/A_tt); the only per-iteration division left is the ray step's 1/denom.
   const double scale = 1.0 / (CP_MEANINERTIA * NV);
   const double AttInv = 1.0 / Apart;
+  double improvement;
+  // one single-row update (connect or joint limit) of slot S whose A column is aS
+  auto update_single = [&](int S, double aS) {
+    double cand = f - res * Ainv;
+    if (S >= SLOT_LIM) cand = cand < 0 ? 0.0 : cand;
+    double d = cand - f;
+    double chg = d * (0.5 * d * Adiag + res);
+    if (chg > 1e-10) { d = 0.0; chg = 0.0; }
+    double Dd = rdlane(d, S);
+    improvement -= rdlane(chg, S);
+    if (lane == S) f += d;
+    res += aS * Dd;
+  };
+  // one elliptic contact pair: normal row on the even lane S (A column aN), tangent on S+1 (A column aT)
+  auto update_pair = [&](int S, double aN, double aT) {
+    // lane S gathers the pair locally: its own (res,f) are the normal's; the partner's via DPP
+    double rt = swap1(res), ot = swap1(f);
+    double rn = res, on = f;
+    double Ann = Adiag, Att = Apart;
+    double fn = on, ft = ot;
+    const bool ray = (__ballot(on >= MINVAL) >> S) & 1;  // wave-uniform: decided by the owner lane
+    if (!ray) {
+      fn = fn - rn * Ainv;
+      fn = fn < 0 ? 0.0 : fn;
+      ft = 0.0;
+    } else {
+      double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
+      if (denom >= MINVAL) {
+        double x = -(fn * rn + ft * rt) / denom;
+        x = x < -1.0 ? -1.0 : x;  // keep the normal force non-negative: fn + x fn >= 0
+        fn = fn + x * fn; ft = ft + x * ft;
+      }
+    }
+    if (fn >= MINVAL) {
+      double bc = rt - Att * ot + Ant * (fn - on);
+      double x0 = -bc * AttInv;
+      // QCQP on one friction dimension (mu = CP_CONTACT_MU): unconstrained minimiser unless it leaves the cone
+      double v1 = x0 * (1.0 / mu);
+      double val = v1 * v1 - fn * fn;
+      ft = x0;
+      if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
+    }
+    double dn = fn - on, dt = ft - ot;
+    double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+    if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
+    double Dn = rdlane(dn, S), Dt = rdlane(dt, S);
+    improvement -= rdlane(chg, S);
+    if (lane == S) f += dn;
+    if (lane == S + 1) f += Dt;
+    res += aN * Dn + aT * Dt;
+  };
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
-    double improvement = 0.0;  // wave-uniform: every row's cost change is read back from its owner lane
-    // single-row constraints: connect (0..3) and joint limits (4..11)
-    static_for<0, SLOT_CON>([&](auto ss) {
-      constexpr int S = decltype(ss)::value;
-      if ((amask >> S) & 1) {
-        double cand = f - res * Ainv;
-        if constexpr (S >= SLOT_LIM) cand = cand < 0 ? 0.0 : cand;
-        double d = cand - f;
-        double chg = d * (0.5 * d * Adiag + res);
-        if (chg > 1e-10) { d = 0.0; chg = 0.0; }
-        double Dd = rdlane(d, S);
-        improvement -= rdlane(chg, S);
-        if (lane == S) f += d;
-        res += Ar[S] * Dd;
+    improvement = 0.0;  // wave-uniform: every row's cost change is read back from its owner lane
+    unsigned long long m = amask;
+    static_for<0, MAXACT>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      if (K < nact) {
+        const int S = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (S < SLOT_CON) update_single(S, Ac[K]);
+        else if (!(S & 1)) {
+          if constexpr (K + 1 < MAXACT) update_pair(S, Ac[K], Ac[K + 1]);
+          else update_pair(S, Ac[K], ovf[lane]);  // pair straddles the register/workspace boundary
+        }
       }
     });
-    // contact pairs: normal on the even lane S, tangent on S+1
-    static_for<0, (NSLOT - SLOT_CON) / 2>([&](auto pp) {
-      constexpr int S = SLOT_CON + 2 * decltype(pp)::value;
-      if ((amask >> S) & 1) {
-        // lane S gathers the pair locally: its own (res,f) are the normal's; the partner's via DPP
-        double rt = swap1(res), ot = swap1(f);
-        double rn = res, on = f;
-        double Ann = Adiag, Att = Apart;
-        double fn = on, ft = ot;
-        if (fn < MINVAL) {
-          fn = fn - rn * Ainv;
-          fn = fn < 0 ? 0.0 : fn;
-          ft = 0.0;
-        } else {
-          double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
-          if (denom >= MINVAL) {
-            double x = -(fn * rn + ft * rt) / denom;
-            x = x < -1.0 ? -1.0 : x;  // keep the normal force non-negative: fn + x fn >= 0
-            fn = fn + x * fn; ft = ft + x * ft;
-          }
-        }
-        if (fn >= MINVAL) {
-          double bc = rt - Att * ot + Ant * (fn - on);
-          double x0 = -bc * AttInv;
-          // QCQP on one friction dimension (mu = CP_CONTACT_MU): unconstrained minimiser unless it leaves the cone
-          double v1 = x0 * (1.0 / mu);
-          double val = v1 * v1 - fn * fn;
-          ft = x0;
-          if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
-        }
-        double dn = fn - on, dt = ft - ot;
-        double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
-        if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
-        double Dn = rdlane(dn, S), Dt = rdlane(dt, S);
-        improvement -= rdlane(chg, S);
-        if (lane == S) f += dn;
-        if (lane == S + 1) f += Dt;
-        res += Ar[S] * Dn + Ar[S + 1] * Dt;
-      }
-    });
+    for (int k = MAXACT; k < nact; k++) {
+      const int S = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const double* col = ovf + (size_t)(k - MAXACT) * 64 + lane;
+      if (S < SLOT_CON) update_single(S, col[0]);
+      else if (!(S & 1)) update_pair(S, col[0], col[64]);
+    }
     niter = iter + 1;
     if (improvement * scale < CP_TOLERANCE) break;
   }
@@ -580,7 +633,7 @@ __device__ __forceinline__ void opstate18(Smem& sm, const LaneConst& c, int lane
 // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
 // WPS: waves per SIMD the register allocation is sized for.  4 (128 VGPRs, some spills) wins when the grid is only
 // ~4 waves per SIMD deep (4096 envs); 3 (168 VGPRs, fewer spills) wins on deep grids (measured, profiles/r01_b_*).
-template <int MODE, int WPS>
+template <int MODE, int WPS, int MAXACT>
 __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   __shared__ Smem sm;
   __shared__ double s18[18];
@@ -598,6 +651,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   double act_l = 0.0;
   if (p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[(size_t)env * p.adim + c.act];
   double* dbg = p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr;
+  double* ovf = p.ovf + (size_t)env * p.ovf_stride;
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
   for (int sub = 0; sub < p.n_sub; sub++) {
@@ -611,7 +665,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
       ctrl = act_l;
     }
     lds_sync();
-    substep<true>(sm, c, lane, ctrl, so, dbg);
+    substep<true, MAXACT>(sm, c, lane, ctrl, so, dbg, ovf);
     niter_sum += so.niter;
     time += 0.0005;
     if (sub == p.n_sub - 1 && c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;  // mj_data->ctrl
@@ -670,7 +724,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
       if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
       time = 0.0;
       lds_sync();
-      substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+      substep<false, MAXACT>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf);
       opstate18(sm, c, lane, fix_kin, s18);
       sp = 0.0;
       if (lane < 17) sp = s18[lane + 1];
@@ -703,7 +757,7 @@ __global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_
   lds_sync();
   double qstate_l = (lane >= 1 && lane < 14) ? sm.q[lane - 1] : 0.0;
   StepOut so;
-  substep<false>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr);
+  substep<false, 32>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, p.ovf + (size_t)env * p.ovf_stride);
   if (p.obs) {
     opstate18(sm, c, lane, (p.flags & FLAG_FIX_STALE_KIN) != 0, s18);
     double sp = 0.0;

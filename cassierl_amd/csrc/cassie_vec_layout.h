@@ -34,6 +34,8 @@ struct VecParams {
   double traj_tmax;
   int traj_n;
   double* debug;          // [n_envs][DBG_STRIDE] or null
+  double* ovf;            // [n_envs][ovf_stride]: A columns beyond the register-resident ones (rare slow path)
+  int ovf_stride;
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };
 
