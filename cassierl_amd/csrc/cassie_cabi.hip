@@ -14,6 +14,7 @@
 #include "../../include/cassie2d.h"
 #include "../../include/cassie_vec.h"
 #include "cassie_kernels.hip"
+#include "cassie_kernels_g16.hip"
 #include "cassie_ctrl.hip"
 
 static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
@@ -32,6 +33,8 @@ struct CassieVec {
   // scratch for the host-pointer conveniences
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
+  int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
+  bool g16 = true;                           // CASSIE2D_G16=0 selects the wave-per-environment kernel only (A/B)
   uint8_t* d_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -82,7 +85,17 @@ cassie::VecParams make_params(CassieVec* h) {
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   dim3 grid(h->n), block(64);
   const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
-  if (p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
+  if (h->g16 && !p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
+    // fast path: 4 environments per wavefront; environments with more than 16 active constraint rows are finished
+    // by the wave-per-environment kernel, which returns immediately for every other environment
+    dim3 grid4((h->n + 3) / 4);
+    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::g16::env_step_g16_kernel<0>), grid4, block, 0, h->stream, p, h->pending);
+    else hipLaunchKernelGGL((cassie::g16::env_step_g16_kernel<1>), grid4, block, 0, h->stream, p, h->pending);
+    cassie::VecParams pc = p;
+    pc.pending = h->pending;
+    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::env_step_kernel<0, 3, MAXACT>), grid, block, 0, h->stream, pc);
+    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3, MAXACT>), grid, block, 0, h->stream, pc);
+  } else if (p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
     // test hook: same code with only MAXACT_DBG register-resident columns, so that the workspace path is exercised
     if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::env_step_kernel<0, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((cassie::env_step_kernel<1, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
@@ -146,6 +159,9 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->d_q, n * 18 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->d_v, n * 13 * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->ovf, n * OVF_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->pending, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMemset(h->pending, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   hipLaunchKernelGGL(cassie::env_init_kernel, dim3((n_envs * cassie::ENV_STRIDE + 255) / 256), dim3(256), 0, h->stream, h->state, n_envs);
@@ -159,7 +175,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;

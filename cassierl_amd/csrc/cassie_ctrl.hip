@@ -38,25 +38,6 @@ struct CtrlSmem {
   double s18[18];
 };
 
-// all-reduce inside every 16-lane row (DPP row rotations)
-template <int CTRLCODE> __device__ __forceinline__ double dpp_mov(double x) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRLCODE, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRLCODE, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_sum(double x) {
-  x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x); x += dpp_mov<0x121>(x);
-  return x;
-}
-__device__ __forceinline__ double row_min(double x) {
-  x = fmin(x, dpp_mov<0x128>(x)); x = fmin(x, dpp_mov<0x124>(x)); x = fmin(x, dpp_mov<0x122>(x)); x = fmin(x, dpp_mov<0x121>(x));
-  return x;
-}
-__device__ __forceinline__ double row_max(double x) {
-  x = fmax(x, dpp_mov<0x128>(x)); x = fmax(x, dpp_mov<0x124>(x)); x = fmax(x, dpp_mov<0x122>(x)); x = fmax(x, dpp_mov<0x121>(x));
-  return x;
-}
-
 // pseudoinverse of a symmetric 4x4 (singular values = |eigenvalues|, threshold tol): cyclic Jacobi on wave-uniform registers
 __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double tol, double (&P)[16]) {
   double a[4][4], V[4][4];

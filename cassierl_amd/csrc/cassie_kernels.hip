@@ -56,6 +56,25 @@ __device__ __forceinline__ double swap1(double x) {
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// all-reduce inside every 16-lane row (DPP row rotations)
+template <int CTRLCODE> __device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRLCODE, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRLCODE, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum(double x) {
+  x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x); x += dpp_mov<0x121>(x);
+  return x;
+}
+__device__ __forceinline__ double row_min(double x) {
+  x = fmin(x, dpp_mov<0x128>(x)); x = fmin(x, dpp_mov<0x124>(x)); x = fmin(x, dpp_mov<0x122>(x)); x = fmin(x, dpp_mov<0x121>(x));
+  return x;
+}
+__device__ __forceinline__ double row_max(double x) {
+  x = fmax(x, dpp_mov<0x128>(x)); x = fmax(x, dpp_mov<0x124>(x)); x = fmax(x, dpp_mov<0x122>(x)); x = fmax(x, dpp_mov<0x121>(x));
+  return x;
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
@@ -130,8 +149,8 @@ __device__ __forceinline__ double impedance(double d0, double d1, double width, 
 
 // ---------------------------------------------------------------- planar forward kinematics on the link lanes
 // Reads sm.q/sm.v-like arrays (qsrc, vsrc), writes link arrays.  SEM selects the model semantics table.
-template <int SEM>
-__device__ __forceinline__ void planar_fk(Smem& sm, const double* qsrc, const double* vsrc, const LaneConst& c, int lane) {
+template <int SEM, class SM>
+__device__ __forceinline__ void planar_fk(SM& sm, const double* qsrc, const double* vsrc, const LaneConst& c, int lane) {
   double th = 0.0, w = 0.0;
 #pragma unroll
   for (int k = 0; k < NL; k++) {
@@ -171,14 +190,16 @@ __device__ __forceinline__ void planar_fk(Smem& sm, const double* qsrc, const do
 }
 
 // point on a link (relative to the pelvis origin)
-__device__ __forceinline__ void link_point(const Smem& sm, int link, double dx, double dz, double& px, double& pz) {
+template <class SM>
+__device__ __forceinline__ void link_point(const SM& sm, int link, double dx, double dz, double& px, double& pz) {
   double cs = sm.lc[link], sn = sm.ls[link];
   px = sm.lox[link] + cs * dx + sn * dz;
   pz = sm.loz[link] - sn * dx + cs * dz;
 }
 
 // compact Jacobian row (component comp: 0 = x, 1 = z) of a point on `link`; legbase = 1 (left) or 6 (right)
-__device__ __forceinline__ void jac_compact(const Smem& sm, int pm, int legbase, int comp, double px, double pz, double sgn, double* J) {
+template <class SM>
+__device__ __forceinline__ void jac_compact(const SM& sm, int pm, int legbase, int comp, double px, double pz, double sgn, double* J) {
   // base slides
   J[0] += sgn * (comp == 0 ? 1.0 : 0.0);
   J[1] += sgn * (comp == 1 ? 1.0 : 0.0);
@@ -229,8 +250,8 @@ __device__ __forceinline__ void store_state(double* st, const Smem& sm, int lane
 // ---------------------------------------------------------------- mass matrix rows and bias on the dof lanes
 // Needs planar_fk<SEM> results in LDS.  Lane (d = lane&15) gets row d of M (+ armature, + h*damping when add_hb) and
 // bias_d = C(q,v) + g(q) (RNE with qacc = 0).  Uses sm.s1x/s1z/s2 as exchange buffers.
-template <int SEM>
-__device__ __forceinline__ void mass_rows(Smem& sm, const LaneConst& c, const DofConst& dc, int lane, double (&Mr)[NV], double& bias, bool add_hb) {
+template <int SEM, class SM>
+__device__ __forceinline__ void mass_rows(SM& sm, const LaneConst& c, const DofConst& dc, int lane, double (&Mr)[NV], double& bias, bool add_hb) {
   double msub = 0, s1x = 0, s1z = 0, s2 = 0;
   bias = 0;
   const double odx = sm.lox[c.dlink], odz = sm.loz[c.dlink];
@@ -596,7 +617,8 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
 
 // ---------------------------------------------------------------- operational-space state (Cassie2d.cpp:218-237)
 // kinematics of the LAST setState (kq,kv; quirk Q1/Q2) with the RBDL-semantics tables; pitch from the current state.
-__device__ __forceinline__ void opstate18(Smem& sm, const LaneConst& c, int lane, bool fix_stale, double* s18 /*LDS*/) {
+template <class SM>
+__device__ __forceinline__ void opstate18(SM& sm, const LaneConst& c, int lane, bool fix_stale, double* s18 /*LDS*/) {
   const double* qk = fix_stale ? sm.q : sm.kq;
   const double* vk = fix_stale ? sm.v : sm.kv;
   planar_fk<1>(sm, qk, vk, c, lane);
@@ -654,7 +676,10 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   double* ovf = p.ovf + (size_t)env * p.ovf_stride;
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
-  for (int sub = 0; sub < p.n_sub; sub++) {
+  // clean-up pass of the 4-envs-per-wave kernel: only envs it could not finish, only their remaining substeps
+  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
+  if (n_sub == 0) return;
+  for (int sub = 0; sub < n_sub; sub++) {
     // DynamicModel::setState: remember the pre-step state (kinematics used by GetOperationalSpaceState)
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }
     double ctrl;
@@ -668,7 +693,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
     substep<true, MAXACT>(sm, c, lane, ctrl, so, dbg, ovf);
     niter_sum += so.niter;
     time += 0.0005;
-    if (sub == p.n_sub - 1 && c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;  // mj_data->ctrl
+    if (sub == n_sub - 1 && c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;  // mj_data->ctrl
   }
   lds_sync();
   // ---- observation, reward, termination (Cassie2dEnv.step) -- optional

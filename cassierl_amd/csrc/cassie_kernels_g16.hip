@@ -1,0 +1,471 @@
+// cassie_kernels_g16.hip -- 4 environments per wavefront (one per 16-lane DPP row).
+//
+// Round-1 PMC profile of the wave-per-environment kernel (profiles/r01_b_pmc, r01_c_pmc): the SIMDs are ~70 % busy issuing
+// FP64 VALU instructions, and in the dominant PGS loop each of those instructions carries ONE useful lane (the owner of the
+// constraint row being updated).  This kernel packs four environments into a wavefront so that one instruction stream
+// updates four rows -- one per environment -- at a time:
+//   * the 16 lanes of a DPP row own one environment; every cross-lane move inside an environment is a DPP row operation
+//     (row_newbcast of the pivot row / of a force delta, quad_perm for the normal<->tangent partner, row_ror reductions);
+//   * active constraint rows are COMPACTED onto the 16 lanes in MuJoCo order (4 connect rows, active joint limits, a pad
+//     row so that contact pairs start on an even lane, active contact (normal,tangent) pairs); lane i keeps the 16 entries
+//     of row i of A in registers;
+//   * step K of a PGS sweep updates row K of all four environments; row kinds may differ between environments, so both the
+//     single-row and the contact-pair code run under wave-uniform branches with per-environment predicates;
+//   * an environment with more than 16 active rows (robot on the ground with many contacts/limits) is NOT handled here: its
+//     state is left untouched from that substep on and `pending[env]` tells the wave-per-environment kernel
+//     (env_step_kernel, clean-up pass) how many substeps are left.  Results are identical either way.
+// Same reference call sites as cassie_kernels.hip (Cassie2d::StepPd/Step + mj_step + Cassie2dEnv.step).
+#ifndef CASSIE_KERNELS_G16_HIP_
+#define CASSIE_KERNELS_G16_HIP_
+
+namespace cassie {
+namespace g16 {
+
+constexpr int MAXR = 16;
+enum { RK_SKIP = 0, RK_EQ = 1, RK_LIM = 2, RK_CN = 3, RK_CT = 4 };
+
+struct EnvLds {
+  double q[16], v[16], ws[16], kq[16], kv[16], ctrl[8];
+  double lc[12], ls[12], lw[12], lox[12], loz[12], lvx[12], lvz[12], lax[12], laz[12], lcx[12], lcz[12], lfx[12], lfz[12];
+  double s1x[16], s1z[16], s2[16];
+  double tau[16], qs[16];
+  double minv[NV * NV + 7];
+  double rowJ[MAXR][8];
+  int rowleg[MAXR];
+  double site[2][6][4];
+  double s18[18];
+  double obs[26];
+};
+
+template <int K> __device__ __forceinline__ int row_bcast_int(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xF, 0xF, false);
+}
+
+// position of the n-th set bit of mask (n counted from 0); -1 if there is none
+__device__ __forceinline__ int nth_set_bit(unsigned mask, int n) {
+  int found = -1, cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 17; i++) {
+    if ((mask >> i) & 1u) { if (cnt == n) found = i; cnt++; }
+  }
+  return found;
+}
+
+struct G16Out { int niter; bool overflow; };
+
+// ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
+// l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
+template <bool INTEGRATE>
+__device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, int g, double ctrl, bool live, G16Out& out) {
+  // ---- kinematics, mass matrix, both inverses
+  planar_fk<0>(sm, sm.q, sm.v, c, l);
+  double Mi[NV], Mh[NV];  // rows of M^-1 and (M + h B)^-1 on the dof lanes
+  double tau, qs;
+  {
+    DofConst dc;
+    load_dof_const(dc, c);
+    double bias;
+    mass_rows<0>(sm, c, dc, l, Mi, bias, false);
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mh[C] = Mi[C] + ((C == c.d && c.dvalid) ? H * dc.damping : 0.0); });
+    gauss_jordan_rows<NV>(Mi, l);
+    gauss_jordan_rows<NV>(Mh, l);
+    if (c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mi[C]; }); }
+    double v_d = sm.v[c.d < NV ? c.d : 0];
+    double u = ctrl < dc.clo ? dc.clo : (ctrl > dc.chi ? dc.chi : ctrl);
+    tau = -dc.damping * v_d - bias + dc.gear * u;
+    qs = 0.0;
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mi[C] * row_bcast<C>(tau); });
+  }
+  if (c.dvalid) { sm.tau[c.d] = tau; sm.qs[c.d] = qs; }
+  lds_sync();
+  // ---- which constraints are active: limits on lanes 0..7, collision spheres on lanes 0..15 (+ sphere 16 on lane 0)
+  const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+  bool lim_act = false;
+  if (l < 8) {
+    const int dof = opaque(cp_slot_dof[SLOT_LIM + l]);
+    double qd = sm.q[dof];
+    lim_act = (qd - cp_jnt_range[dof][0] < 0) || (cp_jnt_range[dof][1] - qd < 0);
+  }
+  auto sphere_active = [&](int sph) {
+    const int so = opaque(sph);
+    const int lk = cp_sph_link[so];
+    double cx, cz;
+    link_point(sm, lk, cp_sph_d[so][0], cp_sph_d[so][1], cx, cz);
+    return basez + cz - cp_sph_r[so] < 0;
+  };
+  const bool con_act0 = sphere_active(l);
+  const bool con_act1 = (l == 0) ? sphere_active(16) : false;
+  const unsigned long long bl = __ballot(lim_act), b0 = __ballot(con_act0), b1 = __ballot(con_act1);
+  const unsigned lim_mask = (unsigned)(bl >> (16 * g)) & 0xFFu;
+  const unsigned con_mask = ((unsigned)(b0 >> (16 * g)) & 0xFFFFu) | ((((unsigned)(b1 >> (16 * g))) & 1u) << 16);
+  const int nlim = __popc(lim_mask), ncon = __popc(con_mask);
+  const int cbase = (4 + nlim + 1) & ~1;  // contact pairs start on an even row
+  const int nrows = cbase + 2 * ncon;
+  const bool ovf_here = live && nrows > MAXR;
+  out.overflow = ovf_here;
+  const bool go = live && !ovf_here;  // this environment is processed in this substep
+  // ---- the row owned by this lane
+  int kind = RK_SKIP, slot = 0;
+  if (go) {
+    if (l < 4) { kind = RK_EQ; slot = l; }
+    else if (l < 4 + nlim) { kind = RK_LIM; slot = SLOT_LIM + nth_set_bit(lim_mask, l - 4); }
+    else if (l >= cbase && l < nrows) {
+      int j = (l - cbase) >> 1, odd = (l - cbase) & 1;
+      kind = odd ? RK_CT : RK_CN;
+      slot = SLOT_CON + 2 * nth_set_bit(con_mask, j) + odd;
+    }
+  }
+  double b = 0.0, jar = 0.0, R = 1.0;
+  const bool active = kind != RK_SKIP;
+  double X[NV];
+  int leg = 0;
+  {
+    const int so = opaque(slot);
+    leg = cp_slot_leg[so];
+    const int comp = cp_slot_comp[so], rdof = cp_slot_dof[so], link1 = cp_slot_link1[so], link2 = cp_slot_link2[so];
+    const int pm1 = cp_link_pathmask8[link1], pm2 = cp_link_pathmask8[link2];
+    const double d1x = cp_slot_d1[0][so][0], d1z = cp_slot_d1[0][so][1], d2x = cp_slot_d2[0][so][0], d2z = cp_slot_d2[0][so][1];
+    const double radius = cp_slot_radius[so], invw = cp_slot_invweight[so];
+    const double* sr = kind == RK_EQ ? cp_eq_solref[so >> 1] : (kind == RK_LIM ? cp_limit_solref : cp_contact_solref);
+    const double* si = kind == RK_EQ ? cp_eq_solimp[so >> 1] : (kind == RK_LIM ? cp_limit_solimp : cp_contact_solimp);
+    const double solref0 = sr[0], solref1 = sr[1], simp0 = si[0], simp1 = si[1], simp2 = si[2];
+    double J[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double pos = 0.0;
+    const int legbase = leg == 0 ? 1 : 6;
+    const int vbase = leg == 0 ? 3 : 8;
+    if (kind == RK_EQ) {
+      double p1x, p1z, p2x, p2z;
+      link_point(sm, link1, d1x, d1z, p1x, p1z);
+      link_point(sm, link2, d2x, d2z, p2x, p2z);
+      jac_compact(sm, pm1, legbase, comp, p1x, p1z, 1.0, J);
+      jac_compact(sm, pm2, legbase, comp, p2x, p2z, -1.0, J);
+      pos = comp == 0 ? p1x - p2x : p1z - p2z;
+    } else if (kind == RK_LIM) {
+      const int rd = rdof >= 0 ? rdof : 0;
+      double qd = sm.q[rd];
+      double dlo = qd - cp_jnt_range[rd][0], dhi = cp_jnt_range[rd][1] - qd;
+      int k = 3 + rd - vbase;
+      double sgn = 0.0;
+      if (dlo < 0) { pos = dlo; sgn = 1.0; }
+      else if (dhi < 0) { pos = dhi; sgn = -1.0; }
+      static_for<3, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; J[K] = (k == K) ? sgn : 0.0; });
+    } else if (kind == RK_CN || kind == RK_CT) {
+      double cx, cz;
+      link_point(sm, link1, d1x, d1z, cx, cz);
+      double dist = basez + cz - radius;
+      double pz = 0.5 * dist - basez;
+      jac_compact(sm, pm1, legbase, comp, cx, pz, 1.0, J);
+      pos = dist;
+    }
+    double vel = J[0] * sm.v[0] + J[1] * sm.v[1] + J[2] * sm.v[2];
+    double bq = J[0] * sm.qs[0] + J[1] * sm.qs[1] + J[2] * sm.qs[2];
+    double jw = J[0] * sm.ws[0] + J[1] * sm.ws[1] + J[2] * sm.ws[2];
+    static_for<0, 5>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      vel += J[3 + K] * sm.v[vbase + K]; bq += J[3 + K] * sm.qs[vbase + K]; jw += J[3 + K] * sm.ws[vbase + K];
+    });
+    double tc = solref0 < 2.0 * H ? 2.0 * H : solref0;
+    double kk_ = 1.0 / (simp1 * simp1 * tc * tc * solref1 * solref1), bb_ = 2.0 / (simp1 * tc);
+    double imp = impedance(simp0, simp1, simp2, pos);
+    R = (1.0 - imp) / imp * invw;
+    R = R > MINVAL ? R : MINVAL;
+    double own_pos = kind == RK_CT ? 0.0 : pos;
+    double imp_own = kind == RK_CT ? impedance(simp0, simp1, simp2, 0.0) : imp;
+    double aref = -bb_ * vel - kk_ * imp_own * own_pos;
+    b = active ? bq - aref : 0.0;
+    jar = jw - aref;
+    static_for<0, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; sm.rowJ[l][K] = active ? J[K] : 0.0; });
+    sm.rowleg[l] = leg;
+    const double* mi = sm.minv;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      double sx = mi[C * NV + 0] * J[0] + mi[C * NV + 1] * J[1] + mi[C * NV + 2] * J[2];
+      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; sx += mi[C * NV + vbase + K] * J[3 + K]; });
+      X[C] = sx;
+    });
+  }
+  lds_sync();
+  // ---- row of A = J M^-1 J' + R in registers (16 columns = the 16 row lanes of this environment)
+  double Ac[MAXR];
+  double Adiag = 1.0, Ant = 0.0;
+  static_for<0, MAXR>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    const double* js = sm.rowJ[K];
+    const int lg = sm.rowleg[K];
+    double a = X[0] * js[0] + X[1] * js[1] + X[2] * js[2];
+    double al = X[3] * js[3] + X[4] * js[4] + X[5] * js[5] + X[6] * js[6] + X[7] * js[7];
+    double ar = X[8] * js[3] + X[9] * js[4] + X[10] * js[5] + X[11] * js[6] + X[12] * js[7];
+    a += lg == 0 ? al : ar;
+    if (!active) a = 0.0;
+    if (l == K && active) { a += R; Adiag = a; }
+    if (l + 1 == K && kind == RK_CN) Ant = a;
+    Ac[K] = a;
+  });
+  const double Ainv = 1.0 / Adiag;
+  const double Apart = swap1(Adiag);
+  // ---- warm start (mj_constraintUpdate) kept only if its dual cost beats zero force
+  const double mu = CP_CONTACT_MU;
+  double f = 0.0;
+  {
+    double D = 1.0 / R;
+    double pj = swap1(jar);
+    if (kind == RK_EQ) f = -D * jar;
+    else if (kind == RK_LIM) f = jar < 0 ? -D * jar : 0.0;
+    else if (kind == RK_CN || kind == RK_CT) {
+      double jn = kind == RK_CN ? jar : pj, jt = kind == RK_CN ? pj : jar;
+      double N = jn * mu, U1 = jt * mu, T = fabs(U1);
+      double fn, ft;
+      if (N >= mu * T || (T <= 0 && N >= 0)) { fn = 0; ft = 0; }
+      else if (mu * N + T <= 0 || (T <= 0 && N < 0)) { fn = -D * jn; ft = -D * jt; }
+      else {
+        double Dm = D / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+        fn = -Dm * NmT * mu;
+        ft = -fn / T * U1 * mu;
+      }
+      f = kind == RK_CN ? fn : ft;
+    }
+  }
+  double res = 0.0;
+  static_for<0, MAXR>([&](auto kk) { constexpr int K = decltype(kk)::value; res += Ac[K] * row_bcast<K>(f); });
+  {
+    double cost = row_sum(active ? f * (0.5 * res + b) : 0.0);
+    if (cost > 0) { f = 0.0; res = 0.0; }
+  }
+  res += b;
+  // ---- PGS sweeps; step K updates row K of every environment of the wave
+  const double scale = 1.0 / (CP_MEANINERTIA * NV);
+  const double AttInv = 1.0 / Apart;
+  bool sweeping = go;       // uniform inside a row: this environment still iterates
+  int niter = 0;
+  for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+    if (__ballot(sweeping) == 0) break;
+    double improvement = 0.0;
+    static_for<0, MAXR>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      const int kindK = row_bcast_int<K>(kind);  // kind of row K of MY environment
+      const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
+      const bool doP = sweeping && kindK == RK_CN;
+      if (__ballot(doS) != 0) {
+        double cand = f - res * Ainv;
+        if (kind == RK_LIM) cand = cand < 0 ? 0.0 : cand;
+        double d = cand - f;
+        double chg = d * (0.5 * d * Adiag + res);
+        if (chg > 1e-10) { d = 0.0; chg = 0.0; }
+        if (!doS) { d = 0.0; chg = 0.0; }
+        double Dd = row_bcast<K>(d);
+        improvement -= row_bcast<K>(chg);
+        if (l == K) f += d;
+        res += Ac[K] * Dd;
+      }
+      if constexpr ((K & 1) == 0 && K + 1 < MAXR) {
+        if (__ballot(doP) != 0) {
+          double rt = swap1(res), ot = swap1(f);
+          double rn = res, on = f;
+          double Ann = Adiag, Att = Apart;
+          double fn = on, ft = ot;
+          if (on < MINVAL) {
+            fn = fn - rn * Ainv;
+            fn = fn < 0 ? 0.0 : fn;
+            ft = 0.0;
+          } else {
+            double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
+            if (denom >= MINVAL) {
+              double x = -(fn * rn + ft * rt) / denom;
+              x = x < -1.0 ? -1.0 : x;
+              fn = fn + x * fn; ft = ft + x * ft;
+            }
+          }
+          if (fn >= MINVAL) {
+            double bc = rt - Att * ot + Ant * (fn - on);
+            double x0 = -bc * AttInv;
+            double v1 = x0 * (1.0 / mu);
+            double val = v1 * v1 - fn * fn;
+            ft = x0;
+            if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
+          }
+          double dn = fn - on, dt = ft - ot;
+          double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+          if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
+          if (!doP) { dn = 0.0; dt = 0.0; chg = 0.0; }
+          double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
+          improvement -= row_bcast<K>(chg);
+          if (l == K) f += dn;
+          if (l == K + 1) f += Dt;
+          res += Ac[K] * Dn + Ac[K + 1] * Dt;
+        }
+      }
+    });
+    if (sweeping) {
+      niter = iter + 1;
+      if (improvement * scale < CP_TOLERANCE) sweeping = false;
+    }
+  }
+  out.niter = niter;
+  // ---- g = tau + J' f on the dof lanes, both accelerations, integration
+  double gg = tau;
+  {
+    const int kL = c.kL, kR = c.kR;
+    static_for<0, MAXR>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      const int k = sm.rowleg[K] == 0 ? kL : kR;
+      double js = sm.rowJ[K][k < 0 ? 0 : k];
+      gg += (k < 0 ? 0.0 : js) * row_bcast<K>(f);
+    });
+  }
+  double qacc = 0.0, qacch = 0.0;
+  static_for<0, NV>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    double gc = row_bcast<C>(gg);
+    qacc += Mi[C] * gc; qacch += Mh[C] * gc;
+  });
+  lds_sync();
+  if (c.dvalid && go) {
+    sm.ws[c.d] = qacc;
+    if (INTEGRATE) {
+      double vn = sm.v[c.d] + H * qacch;
+      sm.v[c.d] = vn;
+      sm.q[c.d] = sm.q[c.d] + H * vn;
+    }
+  }
+  lds_sync();
+}
+
+// ---------------------------------------------------------------- fused Env.step, 4 envs per wave
+// MODE: 0 PD, 1 torque.  pending[env] = substeps this kernel did NOT do (0 in the normal case).
+template <int MODE>
+__global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* pending) {
+  __shared__ EnvLds sm4[4];
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int env = blockIdx.x * 4 + g;
+  const bool valid = env < p.n_envs;
+  EnvLds& sm = sm4[g];
+  const size_t e = valid ? (size_t)env : 0;
+  double* st = p.state + e * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, l);  // roles are per 16-lane row
+  c.grp = 0; c.dvalid = l < NV;
+  // ---- state load (strided inside the 704-byte record; the four records of a wave are adjacent)
+  double qstate_l = 0.0;
+  if (l < NV) {
+    sm.q[l] = st[ES_Q + l]; sm.v[l] = st[ES_V + l]; sm.ws[l] = st[ES_WS + l];
+    sm.kq[l] = st[ES_KQ + l]; sm.kv[l] = st[ES_KV + l];
+    qstate_l = st[ES_QSTATE + l];
+  }
+  if (l < NU) sm.ctrl[l] = st[ES_CTRL + l];
+  double time = st[ES_TIME];
+  double act_l = 0.0;
+  if (p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[e * p.adim + c.act];
+  lds_sync();
+  bool live = valid;
+  int pend = 0, niter_sum = 0;
+  double ctrl = 0.0;
+  G16Out so; so.niter = 0; so.overflow = false;
+  for (int sub = 0; sub < p.n_sub; sub++) {
+    if (l < NV && live) { sm.kq[l] = sm.q[l]; sm.kv[l] = sm.v[l]; }  // DynamicModel::setState
+    double cnew;
+    if (MODE == 0) {
+      int dd = c.d < NV ? c.d : 0;
+      cnew = 10.0 * (act_l - sm.q[dd]) + 5.0 * (0.0 - sm.v[dd]);
+    } else {
+      cnew = act_l;
+    }
+    lds_sync();
+    substep<true>(sm, c, l, g, cnew, live, so);
+    if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
+    if (live) { ctrl = cnew; niter_sum += so.niter; time += 0.0005; }
+    if (__ballot(live) == 0) break;
+  }
+  if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = ctrl;
+  lds_sync();
+  // ---- observation, reward, termination for the environments that completed all substeps
+  if (p.obs) {
+    const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+    opstate18(sm, c, l, fix_kin, sm.s18);
+    double sp = 0.0;
+    if (l < 16) {
+      // obs index l and l+16 (26 values per env)
+      double a0 = l + 1 < 18 ? sm.s18[l + 1] : 0.0;
+      if (l == 5 || l == 11) a0 -= sm.s18[0];
+      sm.obs[l] = a0;
+      if (l + 16 < 26) sm.obs[l + 16] = (l + 16 < 17) ? sm.s18[l + 17] : 0.0;
+    }
+    lds_sync();
+    double reward = 0.0;
+    int done = 0;
+    if (p.env_kind == 0) {
+      double tmax = p.traj_tmax;
+      int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
+      const double* rq = p.traj_qpos + (size_t)idx * NV;
+      if (l < 9) {
+        int col = l < 5 ? l : (l == 5 ? 6 : (l == 6 ? 8 : (l == 7 ? 9 : 11)));
+        sm.obs[17 + l] = rq[col];
+      }
+      lds_sync();
+      const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
+      // qstate joint sum: lanes hold qstate[l]; gather the six values through LDS-free DPP broadcasts
+      double qv = fixq ? sm.q[l < NV ? l : 0] : qstate_l;
+      double j = row_bcast<3>(qv) + row_bcast<4>(qv) + row_bcast<6>(qv);
+      j += row_bcast<8>(qv) + row_bcast<9>(qv) + row_bcast<11>(qv);
+      double sum = 0.0;
+      for (int i = 20; i < 26; i++) sum += sm.obs[i];
+      j -= sum; j = exp(-(j * j));
+      double pp = sm.s18[0] + sm.s18[1];
+      pp -= sm.obs[17] + sm.obs[18]; pp = exp(-(pp * pp));
+      double oo = sm.s18[2];
+      oo -= sm.obs[19]; oo = exp(-(oo * oo));
+      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+      done = (sm.s18[1] < 0.6) || (sm.s18[1] > 1.2) || (reward < 0.6);
+    } else {
+      double a2 = 0.0;
+      for (int i = 0; i < p.adim; i++) { double a = p.actions[e * p.adim + i]; a2 += a * a; }
+      double z = sm.s18[1];
+      double m = (sm.obs[5] + sm.obs[11]) / 2.0;
+      reward = 0.0;
+      reward -= 2 * (0.9 - z) * (0.9 - z);
+      reward -= 2 * m * m;
+      reward += 1;
+      reward -= 0.001 * a2;
+      done = z < 0.5;
+    }
+    if (live && p.terminal_obs) { if (l < 16) p.terminal_obs[e * 26 + l] = sm.obs[l]; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = sm.obs[16 + l]; }
+    const bool do_reset = live && done && p.auto_reset;
+    if (__ballot(do_reset) != 0) {
+      // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
+      if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; qstate_l = cp_env_qinit[l]; }
+      if (do_reset) time = 0.0;
+      lds_sync();
+      G16Out ro; ro.niter = 0; ro.overflow = false;
+      substep<false>(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, ro);
+      // (the reset pose has 12 active rows, it cannot overflow)
+      // reset observation from the stale kinematics -- only the resetting environments may overwrite their buffers
+      lds_sync();
+      // opstate18 recomputes for every environment of the wave; non-resetting ones get their own value back
+      opstate18(sm, c, l, fix_kin, sm.s18);
+      if (do_reset && l < 16) {
+        double a0 = l + 1 < 18 ? sm.s18[l + 1] : 0.0;
+        if (l == 5 || l == 11) a0 -= sm.s18[0];
+        sm.obs[l] = a0;
+        if (l + 16 < 26) sm.obs[l + 16] = (l + 16 < 17) ? sm.s18[l + 17] : 0.0;
+      }
+      lds_sync();
+    }
+    if (live) {
+      if (l < 16) p.obs[e * 26 + l] = sm.obs[l];
+      if (l < 10) p.obs[e * 26 + 16 + l] = sm.obs[16 + l];
+      if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
+    }
+  }
+  // ---- state write-back
+  if (valid) {
+    if (l < NV) {
+      st[ES_Q + l] = sm.q[l]; st[ES_V + l] = sm.v[l]; st[ES_WS + l] = sm.ws[l];
+      st[ES_KQ + l] = sm.kq[l]; st[ES_KV + l] = sm.kv[l]; st[ES_QSTATE + l] = qstate_l;
+    }
+    if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
+    if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
+  }
+}
+
+}  // namespace g16
+}  // namespace cassie
+#endif

@@ -36,6 +36,7 @@ struct VecParams {
   double* debug;          // [n_envs][DBG_STRIDE] or null
   double* ovf;            // [n_envs][ovf_stride]: A columns beyond the register-resident ones (rare slow path)
   int ovf_stride;
+  const int* pending;     // [n_envs] substeps left per env (clean-up pass after the 4-envs-per-wave kernel) or null
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };
 
