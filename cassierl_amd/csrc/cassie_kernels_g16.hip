@@ -24,17 +24,19 @@ namespace g16 {
 constexpr int MAXR = 16;
 enum { RK_SKIP = 0, RK_EQ = 1, RK_LIM = 2, RK_CN = 3, RK_CT = 4 };
 
+// LDS of one environment (3.9 KB; 4 per wavefront).  Buffers whose lifetimes do not overlap inside a substep share storage.
 struct EnvLds {
-  double q[16], v[16], ws[16], kq[16], kv[16], ctrl[8];
-  double lc[12], ls[12], lw[12], lox[12], loz[12], lvx[12], lvz[12], lax[12], laz[12], lcx[12], lcz[12], lfx[12], lfz[12];
-  double s1x[16], s1z[16], s2[16];
-  double tau[16], qs[16];
-  double minv[NV * NV + 7];
-  double rowJ[MAXR][8];
-  int rowleg[MAXR];
-  double site[2][6][4];
-  double s18[18];
-  double obs[26];
+  double q[16], v[16], ws[16], ctrl[8];
+  double lc[12], ls[12], lw[12], lox[12], loz[12], lcx[12], lcz[12], lfx[12], lfz[12];
+  double qs[16];
+  union {
+    struct { double s1x[16], s1z[16], s2[16]; };          // mass_rows exchange (dead once the M rows are built)
+    struct { double rowJ[MAXR][8]; int rowleg[MAXR]; };   // constraint rows (from the row build to the end of the substep)
+  };
+  union {
+    struct { double minv[NV * NV + 7]; };                 // M^-1 (from the Gauss-Jordan to the end of the substep)
+    struct { double lvx[12], lvz[12], lax[12], laz[12], site[2][6][4], s18[18], kq[16], kv[16]; };  // FK by-products / post-step
+  };
 };
 
 template <int K> __device__ __forceinline__ int row_bcast_int(int x) {
@@ -52,6 +54,17 @@ __device__ __forceinline__ int nth_set_bit(unsigned mask, int n) {
 }
 
 struct G16Out { int niter; bool overflow; };
+
+// 1/d to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps (5 dependent instructions instead of the ~14 of an
+// IEEE-correct division; only used for the per-iteration ray step of the contact update)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
 
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
@@ -76,7 +89,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     qs = 0.0;
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mi[C] * row_bcast<C>(tau); });
   }
-  if (c.dvalid) { sm.tau[c.d] = tau; sm.qs[c.d] = qs; }
+  if (c.dvalid) sm.qs[c.d] = qs;
   lds_sync();
   // ---- which constraints are active: limits on lanes 0..7, collision spheres on lanes 0..15 (+ sphere 16 on lane 0)
   const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
@@ -236,29 +249,39 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
   const double scale = 1.0 / (CP_MEANINERTIA * NV);
   const double AttInv = 1.0 / Apart;
   bool sweeping = go;       // uniform inside a row: this environment still iterates
+  // row kinds of MY environment packed 4 bits per row, and wave-uniform "some environment has a single row / a
+  // contact pair at step K" masks: computed once per substep, not once per step of every sweep
+  unsigned long long kinds = 0ull;
+  unsigned anyS = 0u, anyP = 0u;
+  static_for<0, MAXR>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    const int kindK = row_bcast_int<K>(kind);
+    kinds |= (unsigned long long)kindK << (4 * K);
+    if (__ballot(kindK == RK_EQ || kindK == RK_LIM) != 0) anyS |= 1u << K;
+    if (__ballot(kindK == RK_CN) != 0) anyP |= 1u << K;
+  });
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
     double improvement = 0.0;
     static_for<0, MAXR>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
-      const int kindK = row_bcast_int<K>(kind);  // kind of row K of MY environment
-      const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
-      const bool doP = sweeping && kindK == RK_CN;
-      if (__ballot(doS) != 0) {
+      const int kindK = (int)((kinds >> (4 * K)) & 15ull);
+      if ((anyS >> K) & 1u) {
+        const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
         double cand = f - res * Ainv;
         if (kind == RK_LIM) cand = cand < 0 ? 0.0 : cand;
         double d = cand - f;
         double chg = d * (0.5 * d * Adiag + res);
-        if (chg > 1e-10) { d = 0.0; chg = 0.0; }
-        if (!doS) { d = 0.0; chg = 0.0; }
+        if (chg > 1e-10 || !doS) { d = 0.0; chg = 0.0; }
         double Dd = row_bcast<K>(d);
         improvement -= row_bcast<K>(chg);
         if (l == K) f += d;
         res += Ac[K] * Dd;
       }
       if constexpr ((K & 1) == 0 && K + 1 < MAXR) {
-        if (__ballot(doP) != 0) {
+        if ((anyP >> K) & 1u) {
+          const bool doP = sweeping && kindK == RK_CN;
           double rt = swap1(res), ot = swap1(f);
           double rn = res, on = f;
           double Ann = Adiag, Att = Apart;
@@ -270,7 +293,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
           } else {
             double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
             if (denom >= MINVAL) {
-              double x = -(fn * rn + ft * rt) / denom;
+              double x = -(fn * rn + ft * rt) * fast_rcp(denom);
               x = x < -1.0 ? -1.0 : x;
               fn = fn + x * fn; ft = ft + x * ft;
             }
@@ -285,8 +308,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
           }
           double dn = fn - on, dt = ft - ot;
           double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
-          if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
-          if (!doP) { dn = 0.0; dt = 0.0; chg = 0.0; }
+          if (chg > 1e-10 || !doP) { dn = 0.0; dt = 0.0; chg = 0.0; }
           double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
           improvement -= row_bcast<K>(chg);
           if (l == K) f += dn;
@@ -345,10 +367,10 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   load_lane_const(c, l);  // roles are per 16-lane row
   c.grp = 0; c.dvalid = l < NV;
   // ---- state load (strided inside the 704-byte record; the four records of a wave are adjacent)
-  double qstate_l = 0.0;
+  double qstate_l = 0.0, kq_r = 0.0, kv_r = 0.0;  // lane l < 13 holds element l
   if (l < NV) {
     sm.q[l] = st[ES_Q + l]; sm.v[l] = st[ES_V + l]; sm.ws[l] = st[ES_WS + l];
-    sm.kq[l] = st[ES_KQ + l]; sm.kv[l] = st[ES_KV + l];
+    kq_r = st[ES_KQ + l]; kv_r = st[ES_KV + l];
     qstate_l = st[ES_QSTATE + l];
   }
   if (l < NU) sm.ctrl[l] = st[ES_CTRL + l];
@@ -361,18 +383,12 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   double ctrl = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
   for (int sub = 0; sub < p.n_sub; sub++) {
-    if (l < NV && live) { sm.kq[l] = sm.q[l]; sm.kv[l] = sm.v[l]; }  // DynamicModel::setState
-    double cnew;
-    if (MODE == 0) {
-      int dd = c.d < NV ? c.d : 0;
-      cnew = 10.0 * (act_l - sm.q[dd]) + 5.0 * (0.0 - sm.v[dd]);
-    } else {
-      cnew = act_l;
-    }
-    lds_sync();
+    const int dd = c.d < NV ? c.d : 0;
+    const double q_d = sm.q[dd], v_d = sm.v[dd];
+    double cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l;
     substep<true>(sm, c, l, g, cnew, live, so);
     if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
-    if (live) { ctrl = cnew; niter_sum += so.niter; time += 0.0005; }
+    if (live) { kq_r = q_d; kv_r = v_d; ctrl = cnew; niter_sum += so.niter; time += 0.0005; }  // setState of this substep
     if (__ballot(live) == 0) break;
   }
   if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = ctrl;
@@ -380,46 +396,48 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   // ---- observation, reward, termination for the environments that completed all substeps
   if (p.obs) {
     const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
-    opstate18(sm, c, l, fix_kin, sm.s18);
-    double sp = 0.0;
-    if (l < 16) {
-      // obs index l and l+16 (26 values per env)
-      double a0 = l + 1 < 18 ? sm.s18[l + 1] : 0.0;
-      if (l == 5 || l == 11) a0 -= sm.s18[0];
-      sm.obs[l] = a0;
-      if (l + 16 < 26) sm.obs[l + 16] = (l + 16 < 17) ? sm.s18[l + 17] : 0.0;
-    }
-    lds_sync();
+    auto opstate_regs = [&](double& oa, double& ob, double& bodyx) {
+      if (l < NV) { sm.kq[l] = kq_r; sm.kv[l] = kv_r; }
+      lds_sync();
+      opstate18(sm, c, l, fix_kin, sm.s18);
+      oa = sm.s18[l + 1 < 18 ? l + 1 : 17];      // obs[l] = s18[l+1]
+      bodyx = sm.s18[0];
+      if (l == 5 || l == 11) oa -= bodyx;
+      ob = l == 0 ? sm.s18[17] : 0.0;            // obs[16 + l]
+      lds_sync();
+    };
+    double obs_a, obs_b, bodyx;
+    opstate_regs(obs_a, obs_b, bodyx);
+    const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
     double reward = 0.0;
     int done = 0;
     if (p.env_kind == 0) {
       double tmax = p.traj_tmax;
       int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
       const double* rq = p.traj_qpos + (size_t)idx * NV;
-      if (l < 9) {
-        int col = l < 5 ? l : (l == 5 ? 6 : (l == 6 ? 8 : (l == 7 ? 9 : 11)));
-        sm.obs[17 + l] = rq[col];
+      if (l >= 1 && l < 10) {
+        int k = l - 1;
+        int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
+        obs_b = rq[col];
       }
-      lds_sync();
       const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
-      // qstate joint sum: lanes hold qstate[l]; gather the six values through LDS-free DPP broadcasts
       double qv = fixq ? sm.q[l < NV ? l : 0] : qstate_l;
       double j = row_bcast<3>(qv) + row_bcast<4>(qv) + row_bcast<6>(qv);
       j += row_bcast<8>(qv) + row_bcast<9>(qv) + row_bcast<11>(qv);
       double sum = 0.0;
-      for (int i = 20; i < 26; i++) sum += sm.obs[i];
+      sum += row_bcast<4>(obs_b); sum += row_bcast<5>(obs_b); sum += row_bcast<6>(obs_b);
+      sum += row_bcast<7>(obs_b); sum += row_bcast<8>(obs_b); sum += row_bcast<9>(obs_b);
       j -= sum; j = exp(-(j * j));
-      double pp = sm.s18[0] + sm.s18[1];
-      pp -= sm.obs[17] + sm.obs[18]; pp = exp(-(pp * pp));
-      double oo = sm.s18[2];
-      oo -= sm.obs[19]; oo = exp(-(oo * oo));
+      double pp = bodyx + z;
+      pp -= row_bcast<1>(obs_b) + row_bcast<2>(obs_b); pp = exp(-(pp * pp));
+      double oo = pitch;
+      oo -= row_bcast<3>(obs_b); oo = exp(-(oo * oo));
       reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
-      done = (sm.s18[1] < 0.6) || (sm.s18[1] > 1.2) || (reward < 0.6);
+      done = (z < 0.6) || (z > 1.2) || (reward < 0.6);
     } else {
       double a2 = 0.0;
       for (int i = 0; i < p.adim; i++) { double a = p.actions[e * p.adim + i]; a2 += a * a; }
-      double z = sm.s18[1];
-      double m = (sm.obs[5] + sm.obs[11]) / 2.0;
+      double m = (row_bcast<5>(obs_a) + row_bcast<11>(obs_a)) / 2.0;
       reward = 0.0;
       reward -= 2 * (0.9 - z) * (0.9 - z);
       reward -= 2 * m * m;
@@ -427,7 +445,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       reward -= 0.001 * a2;
       done = z < 0.5;
     }
-    if (live && p.terminal_obs) { if (l < 16) p.terminal_obs[e * 26 + l] = sm.obs[l]; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = sm.obs[16 + l]; }
+    if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
     const bool do_reset = live && done && p.auto_reset;
     if (__ballot(do_reset) != 0) {
       // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
@@ -435,23 +453,14 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       if (do_reset) time = 0.0;
       lds_sync();
       G16Out ro; ro.niter = 0; ro.overflow = false;
-      substep<false>(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, ro);
-      // (the reset pose has 12 active rows, it cannot overflow)
-      // reset observation from the stale kinematics -- only the resetting environments may overwrite their buffers
-      lds_sync();
-      // opstate18 recomputes for every environment of the wave; non-resetting ones get their own value back
-      opstate18(sm, c, l, fix_kin, sm.s18);
-      if (do_reset && l < 16) {
-        double a0 = l + 1 < 18 ? sm.s18[l + 1] : 0.0;
-        if (l == 5 || l == 11) a0 -= sm.s18[0];
-        sm.obs[l] = a0;
-        if (l + 16 < 26) sm.obs[l + 16] = (l + 16 < 17) ? sm.s18[l + 17] : 0.0;
-      }
-      lds_sync();
+      substep<false>(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, ro);  // 12 active rows: cannot overflow
+      double ra, rb, rx;
+      opstate_regs(ra, rb, rx);  // reset observation from the stale kinematics (quirk Q2)
+      if (do_reset) { obs_a = ra; obs_b = rb; }
     }
     if (live) {
-      if (l < 16) p.obs[e * 26 + l] = sm.obs[l];
-      if (l < 10) p.obs[e * 26 + 16 + l] = sm.obs[16 + l];
+      p.obs[e * 26 + l] = obs_a;
+      if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
       if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
     }
   }
@@ -459,7 +468,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   if (valid) {
     if (l < NV) {
       st[ES_Q + l] = sm.q[l]; st[ES_V + l] = sm.v[l]; st[ES_WS + l] = sm.ws[l];
-      st[ES_KQ + l] = sm.kq[l]; st[ES_KV + l] = sm.kv[l]; st[ES_QSTATE + l] = qstate_l;
+      st[ES_KQ + l] = kq_r; st[ES_KV + l] = kv_r; st[ES_QSTATE + l] = qstate_l;
     }
     if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
     if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
