@@ -162,6 +162,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->pending, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->pending, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
+  if (h->cfg.flags & CASSIE_WAVE_PER_ENV) h->g16 = false;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   hipLaunchKernelGGL(cassie::env_init_kernel, dim3((n_envs * cassie::ENV_STRIDE + 255) / 256), dim3(256), 0, h->stream, h->state, n_envs);

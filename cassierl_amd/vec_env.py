@@ -14,7 +14,7 @@ from . import _lib
 
 CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2, "Jacobian": 3}
 ENV_KINDS = {"walk": 0, "stand": 1}
-FIX_STALE_KIN, FIX_STALE_QSTATE = 1, 2
+FIX_STALE_KIN, FIX_STALE_QSTATE, WAVE_PER_ENV = 1, 2, 4
 STATE_STRIDE = 88
 
 

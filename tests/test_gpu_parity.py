@@ -278,3 +278,28 @@ def test_legacy_abi_batch_of_one(oracle_mod):
     L.GetOperationalSpaceState(h, ct.byref(xs))
     np.testing.assert_allclose(cv.operational_state_to_array(xs), o.opstate(0), atol=1e-10)
     L.Render(h)
+
+
+def test_g16_and_wave_per_env_kernels_agree(vec, traj):
+    """The 4-envs-per-wave fast path (+ clean-up pass) and the wave-per-environment kernel are two implementations of the same
+    step: run the same random-torque rollout through both, including falls that overflow 16 rows, and compare."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 37  # not a multiple of 4: exercises the partial last wave
+    rng = np.random.default_rng(17)
+    a = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    b = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
+    np.testing.assert_array_equal(a.reset_host(), b.reset_host())
+    saw_overflow = False
+    for t in range(150):
+        acts = rng.uniform(-1, 1, (n, 6)) * TQ * (0.2 if t < 100 else 1.0)
+        # teacher-force b from a's state so that rounding-level differences cannot grow across steps
+        b.set_full_state_host(a.get_full_state_host())
+        oa, ra, da = a.step_host(acts)
+        ob, rb, db = b.step_host(acts)
+        assert (da == db).all()
+        np.testing.assert_allclose(ra, rb, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(oa, ob, rtol=0, atol=1e-8)
+        sa, sb = a.get_full_state_host(), b.get_full_state_host()
+        np.testing.assert_allclose(sa[:, :26], sb[:, :26], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(sa[:, 84], sb[:, 84], atol=1e-12)  # env time
+    a.close(); b.close()
