@@ -1,0 +1,321 @@
+"""TRPO outer loop over the batched environment: counterpart of rllab/envs/trpo_cassie.py:12-55.
+
+The reference drives ONE environment through rllab's TRPO (Theano).  Here the rollout is N resident environments stepped by
+one kernel launch per Env.step, and the optimiser is written directly against torch tensors on the same device:
+
+  policy     GaussianMLPPolicy(hidden_sizes=(32, 32), init_std=2.0)            trpo_cassie.py:21-27
+             (tanh hidden units, state-independent learned log-std -- rllab's defaults [external])
+  baseline   LinearFeatureBaseline: ridge regression on [o, o^2, t, t^2, t^3, 1]  trpo_cassie.py:29 [external]
+  algorithm  TRPO: batch_size env-steps per iteration, max_path_length=1000, discount=0.99, step_size (mean KL) 0.005,
+             conjugate gradient (10 iterations, damping 1e-5) + backtracking line search (0.8, 15)   trpo_cassie.py:31-42
+  env        normalize(Cassie2dEnv()): actions in [-1, 1] mapped affinely to the action box and clipped  trpo_cassie.py:13
+
+Multi-GPU: one process per GPU, each with its own shard of environments; the policy gradient, every Fisher-vector
+product, the baseline's normal equations and the line-search statistics are averaged with all_reduce (RCCL on MI355X, gloo in
+the CPU tests), so all ranks take the identical step.  Episode returns are gathered once per batch (rollout.gather_returns).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+# --------------------------------------------------------------------------------------------- distributed helpers
+def _world():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def all_mean_(t):
+    """In-place mean over ranks (no-op single process)."""
+    if _world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= _world()
+    return t
+
+
+def all_sum_(t):
+    if _world() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+# --------------------------------------------------------------------------------------------- policy / baseline
+class GaussianMLPPolicy(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden_sizes=(32, 32), init_std=2.0, dtype=torch.float32):
+        super().__init__()
+        layers, d = [], obs_dim
+        for h in hidden_sizes:
+            layers += [nn.Linear(d, h), nn.Tanh()]
+            d = h
+        layers.append(nn.Linear(d, act_dim))
+        self.mean_net = nn.Sequential(*layers)
+        self.log_std = nn.Parameter(torch.full((act_dim,), math.log(init_std)))
+        for m in self.mean_net:
+            if isinstance(m, nn.Linear):  # rllab: Xavier-uniform weights, zero bias [external]
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+        self.to(dtype)
+
+    def dist_info(self, obs):
+        return self.mean_net(obs), self.log_std.expand(obs.shape[0], -1)
+
+    @torch.no_grad()
+    def get_actions(self, obs, generator=None):
+        mean, log_std = self.dist_info(obs)
+        noise = torch.randn(mean.shape, dtype=mean.dtype, device=mean.device, generator=generator)
+        return mean + noise * log_std.exp(), mean, log_std
+
+    @staticmethod
+    def log_likelihood(actions, mean, log_std):
+        z = (actions - mean) / log_std.exp()
+        return -(log_std.sum(-1) + 0.5 * (z * z).sum(-1) + 0.5 * mean.shape[-1] * math.log(2 * math.pi))
+
+    @staticmethod
+    def kl(old_mean, old_log_std, new_mean, new_log_std):
+        old_std, new_std = old_log_std.exp(), new_log_std.exp()
+        num = (old_mean - new_mean) ** 2 + old_std ** 2 - new_std ** 2
+        return (num / (2 * new_std ** 2 + 1e-8) + new_log_std - old_log_std).sum(-1)
+
+
+class LinearFeatureBaseline:
+    """Ridge regression of the discounted return on [o, o^2, t, t^2, t^3, 1], o clipped to [-10, 10], t = step/100."""
+
+    def __init__(self, reg_coeff=1e-5):
+        self.coeffs, self.reg_coeff = None, reg_coeff
+
+    @staticmethod
+    def features(obs, t):
+        o = obs.clamp(-10, 10)
+        al = (t.to(obs.dtype) / 100.0).unsqueeze(-1)
+        return torch.cat([o, o * o, al, al ** 2, al ** 3, torch.ones_like(al)], dim=-1)
+
+    def fit(self, obs, t, returns):
+        X = self.features(obs, t).double()
+        y = returns.double()
+        A = all_sum_(X.T @ X)
+        b = all_sum_(X.T @ y)
+        reg = self.reg_coeff
+        eye = torch.eye(A.shape[0], dtype=A.dtype, device=A.device)
+        for _ in range(5):
+            sol = torch.linalg.solve(A + reg * eye, b)
+            if torch.isfinite(sol).all():
+                break
+            reg *= 10
+        self.coeffs = sol
+
+    def predict(self, obs, t):
+        if self.coeffs is None:
+            return torch.zeros(obs.shape[0], dtype=torch.float64, device=obs.device)
+        return self.features(obs, t).double() @ self.coeffs
+
+
+class NormalizedActions:
+    """rllab.envs.normalized_env.normalize (actions only): [-1, 1] -> [lb, ub], then clip."""
+
+    def __init__(self, low, high, device, dtype=torch.float64):
+        self.low = torch.as_tensor(low, dtype=dtype, device=device)
+        self.high = torch.as_tensor(high, dtype=dtype, device=device)
+
+    def __call__(self, a):
+        a = a.to(self.low.dtype)
+        scaled = self.low + (a + 1.0) * 0.5 * (self.high - self.low)
+        return torch.minimum(torch.maximum(scaled, self.low), self.high).contiguous()
+
+
+# --------------------------------------------------------------------------------------------- math helpers
+def discounted_returns(rewards, dones, gamma, last_value=None):
+    """rewards, dones: [T, N].  Return-to-go that restarts after a done (path boundary)."""
+    T = rewards.shape[0]
+    out = torch.zeros_like(rewards)
+    run = torch.zeros_like(rewards[0]) if last_value is None else last_value.clone()
+    for t in range(T - 1, -1, -1):
+        run = rewards[t] + gamma * run * (~dones[t]).to(rewards.dtype)
+        out[t] = run
+    return out
+
+
+def flat_params(module):
+    return torch.cat([p.data.reshape(-1) for p in module.parameters()])
+
+
+def set_flat_params(module, flat):
+    i = 0
+    for p in module.parameters():
+        n = p.numel()
+        p.data.copy_(flat[i:i + n].view_as(p))
+        i += n
+
+
+def flat_grad(y, module, retain_graph=False, create_graph=False):
+    g = torch.autograd.grad(y, list(module.parameters()), retain_graph=retain_graph, create_graph=create_graph)
+    return torch.cat([x.reshape(-1) for x in g])
+
+
+def conjugate_gradient(Avp, b, iters=10, tol=1e-10):
+    x = torch.zeros_like(b)
+    r, p = b.clone(), b.clone()
+    rr = r @ r
+    for _ in range(iters):
+        Ap = Avp(p)
+        alpha = rr / (p @ Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        rr_new = r @ r
+        if rr_new < tol:
+            break
+        p = r + (rr_new / rr) * p
+        rr = rr_new
+    return x
+
+
+# --------------------------------------------------------------------------------------------- TRPO
+class TRPO:
+    def __init__(self, env_step, env_reset, policy, baseline, n_envs, obs_dim, act_map, batch_size=15000, max_path_length=1000,
+                 discount=0.99, step_size=0.005, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15, seed=1):
+        """env_step(actions[N, adim] float64) -> (obs[N, obs_dim], reward[N], done[N] uint8/bool), auto-resetting;
+        env_reset() -> obs.  batch_size counts env-steps over ALL ranks, as rllab's batch_size does."""
+        self.env_step, self.env_reset = env_step, env_reset
+        self.policy, self.baseline, self.act_map = policy, baseline, act_map
+        self.n_envs, self.obs_dim = n_envs, obs_dim
+        self.horizon = max(1, int(math.ceil(batch_size / (n_envs * _world()))))
+        self.max_path_length, self.discount, self.step_size = max_path_length, discount, step_size
+        self.cg_iters, self.reg_coeff = cg_iters, reg_coeff
+        self.backtrack_ratio, self.max_backtracks = backtrack_ratio, max_backtracks
+        dev = next(policy.parameters()).device
+        self.gen = torch.Generator(device=dev)
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.gen.manual_seed(seed * 1000003 + rank)
+        self.obs = None
+        self.path_t = torch.zeros(n_envs, dtype=torch.int64, device=dev)
+        self.path_ret = torch.zeros(n_envs, dtype=torch.float64, device=dev)
+        self.itr = 0
+
+    # ---- sampling: T vectorised Env.steps, everything stays on the device
+    @torch.no_grad()
+    def collect(self):
+        pol_dtype = next(self.policy.parameters()).dtype
+        if self.obs is None:
+            self.obs = self.env_reset().clone()
+        T, N = self.horizon, self.n_envs
+        dev = self.obs.device
+        obs_b = torch.empty((T, N, self.obs_dim), dtype=pol_dtype, device=dev)
+        act_b = torch.empty((T, N, self.policy.log_std.numel()), dtype=pol_dtype, device=dev)
+        mean_b, lstd_b = torch.empty_like(act_b), torch.empty_like(act_b)
+        rew_b = torch.empty((T, N), dtype=torch.float64, device=dev)
+        done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
+        t_b = torch.empty((T, N), dtype=torch.int64, device=dev)
+        finished = []
+        for t in range(T):
+            o = self.obs.to(pol_dtype)
+            a, mean, log_std = self.policy.get_actions(o, self.gen)
+            nobs, rew, done = self.env_step(self.act_map(a))
+            done = done.bool().clone()
+            obs_b[t], act_b[t], mean_b[t], lstd_b[t] = o, a, mean, log_std
+            rew_b[t], t_b[t] = rew, self.path_t
+            self.path_ret += rew
+            self.path_t += 1
+            cut = done | (self.path_t >= self.max_path_length)  # rllab truncates paths at max_path_length
+            done_b[t] = cut
+            finished.append(self.path_ret[cut].clone())
+            self.path_ret[cut] = 0.0
+            self.path_t[cut] = 0
+            self.obs = nobs.clone()
+        return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
+                    episode_returns=torch.cat(finished) if finished else torch.zeros(0, device=dev))
+
+    def process(self, batch):
+        T, N = batch["rew"].shape
+        flat = lambda x: x.reshape(T * N, *x.shape[2:])
+        obs, tt = flat(batch["obs"]), flat(batch["t"])
+        # bootstrap unfinished paths with the baseline of the next observation (0 at iteration 0)
+        last_v = self.baseline.predict(self.obs.to(obs.dtype), self.path_t)
+        returns = discounted_returns(batch["rew"], batch["done"], self.discount, last_v)
+        values = self.baseline.predict(obs, tt).view(T, N)
+        adv = flat(returns - values)                       # gae_lambda = 1
+        n = torch.tensor([adv.numel()], dtype=torch.float64, device=adv.device)
+        s1 = all_sum_(adv.sum().view(1).clone()); s2 = all_sum_((adv * adv).sum().view(1).clone()); n = all_sum_(n)
+        mean = s1 / n
+        std = (s2 / n - mean * mean).clamp_min(0).sqrt()
+        adv = ((adv - mean) / (std + 1e-8)).to(obs.dtype)  # center_adv
+        self.baseline.fit(obs, tt, flat(returns))
+        return dict(obs=obs, act=flat(batch["act"]), mean=flat(batch["mean"]), log_std=flat(batch["log_std"]), adv=adv)
+
+    # ---- constrained update
+    def optimize(self, d):
+        pol = self.policy
+        obs, act, adv, old_mean, old_lstd = d["obs"], d["act"], d["adv"], d["mean"], d["log_std"]
+        old_ll = pol.log_likelihood(act, old_mean, old_lstd)
+
+        def surrogate():
+            mean, log_std = pol.dist_info(obs)
+            lr = (pol.log_likelihood(act, mean, log_std) - old_ll).exp()
+            return -(lr * adv).mean(), pol.kl(old_mean, old_lstd, mean, log_std).mean()
+
+        loss, _ = surrogate()
+        g = all_mean_(flat_grad(loss, pol))
+
+        def Fvp(v):
+            _, kl = surrogate()
+            gk = flat_grad(kl, pol, retain_graph=True, create_graph=True)
+            hv = flat_grad(gk @ v, pol)
+            return all_mean_(hv) + self.reg_coeff * v
+
+        descent = conjugate_gradient(Fvp, g, self.cg_iters)
+        shs = 0.5 * (descent @ Fvp(descent))
+        step = torch.sqrt(self.step_size / (shs + 1e-8)) * descent
+        if not torch.isfinite(step).all():
+            return dict(loss_before=float(loss), loss_after=float(loss), kl=0.0, backtracks=-1)
+        theta = flat_params(pol)
+        loss_before = float(all_mean_(loss.detach().clone().view(1)))
+        for k in range(self.max_backtracks + 1):
+            set_flat_params(pol, theta - (self.backtrack_ratio ** k) * step)
+            with torch.no_grad():
+                l_new, kl_new = surrogate()
+            l_new = float(all_mean_(l_new.view(1).clone())); kl_new = float(all_mean_(kl_new.view(1).clone()))
+            if math.isfinite(l_new) and l_new < loss_before and kl_new <= self.step_size:
+                return dict(loss_before=loss_before, loss_after=l_new, kl=kl_new, backtracks=k)
+        set_flat_params(pol, theta)  # line search failed: keep the old policy
+        return dict(loss_before=loss_before, loss_after=loss_before, kl=0.0, backtracks=self.max_backtracks + 1)
+
+    def train_iteration(self):
+        from . import rollout as R
+        batch = self.collect()
+        stats = self.optimize(self.process(batch))
+        er = batch["episode_returns"]
+        cnt = all_sum_(torch.tensor([float(er.numel()), float(er.sum())], dtype=torch.float64, device=er.device))
+        per_env = batch["rew"].sum(0)                       # the one gather of the rollout batch (N per rank)
+        stats.update(itr=self.itr, env_steps=batch["rew"].numel() * _world(), episodes=int(cnt[0]),
+                     avg_return=float(cnt[1] / cnt[0]) if cnt[0] > 0 else float("nan"),
+                     avg_reward=float(all_mean_(batch["rew"].mean().view(1).clone())),
+                     gathered=int(R.gather_returns(per_env).numel()))
+        self.itr += 1
+        return stats
+
+    # ---- snapshot_mode="last" (trpo_cassie.py:50): policy, baseline, env-independent counters
+    def save(self, path, extra=None):
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
+        torch.save(dict(policy=self.policy.state_dict(), baseline=self.baseline.coeffs, itr=self.itr, extra=extra), path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location=next(self.policy.parameters()).device)
+        self.policy.load_state_dict(ck["policy"])
+        self.baseline.coeffs = ck["baseline"]
+        self.itr = ck["itr"]
+        return ck.get("extra")
+
+
+def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajectory=None, seed=1, **kw):
+    """trpo_cassie.py:12-42 on the batched MI355X environment."""
+    from .vec_env import CassieVecEnv
+    env = CassieVecEnv(n_envs, kind=kind, control_mode=control_mode, n_substeps=10, auto_reset=True, device=device, trajectory=trajectory)
+    env.use_torch_stream()
+    dev = "cuda:%d" % device
+    bufs = env.alloc()
+    policy = GaussianMLPPolicy(26, env.adim, (32, 32), init_std=2.0).to(dev)
+    act_map = NormalizedActions(env.action_space.low, env.action_space.high, dev)
+    algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, 26, act_map, seed=seed, **kw)
+    algo.env = env
+    return algo
