@@ -45,21 +45,22 @@ __device__ __forceinline__ double rdlane(double x, int l) {
   return __hiloint2double(hi, lo);
 }
 // broadcast lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
+// (mov_dpp: no "old" operand to materialise -- every lane of a row_newbcast / quad_perm / row_ror has a valid source)
 template <int K> __device__ __forceinline__ double row_bcast(double x) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x150 + K, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x150 + K, 0xF, 0xF, false);
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + K, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + K, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 // exchange with lane^1 (DPP quad_perm [1,0,3,2])
 __device__ __forceinline__ double swap1(double x) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 // all-reduce inside every 16-lane row (DPP row rotations)
 template <int CTRLCODE> __device__ __forceinline__ double dpp_mov(double x) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRLCODE, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRLCODE, 0xF, 0xF, false);
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRLCODE, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRLCODE, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row_sum(double x) {
@@ -290,22 +291,33 @@ __device__ __forceinline__ void mass_rows(SM& sm, const LaneConst& c, const DofC
   if (!c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mr[C] = (C == (lane & 15)) ? 1.0 : 0.0; }); }
 }
 
+// 1/d to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps: 5 dependent instructions instead of the ~14 of an
+// IEEE-correct division.  Used on latency-critical paths of the 4-envs-per-wave kernel.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
 // In-register Gauss-Jordan inverse of an N x N SPD matrix (N <= 16) held one row per lane inside every 16-lane row of the
 // wave; the four rows of the wave are independent problems executed by the same instruction stream (DPP row_newbcast).
 // Lanes with (lane&15) >= N must hold a zero row.
-template <int N>
+template <int N, bool FAST = false>
 __device__ __forceinline__ void gauss_jordan_rows(double (&Mr)[N], int lane) {
   static_for<0, N>([&](auto kk) {
     constexpr int K = decltype(kk)::value;
     double piv = row_bcast<K>(Mr[K]);
-    double inv = 1.0 / piv;
-    double t = Mr[K] * inv;
+    double inv = FAST ? fast_rcp(piv) : 1.0 / piv;
     bool isk = (lane & 15) == K;
+    double t = isk ? 1.0 - inv : Mr[K] * inv;  // pivot row: pk - (1 - inv) pk = pk * inv
     static_for<0, N>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
       if constexpr (C != K) {
         double pk = row_bcast<K>(Mr[C]);
-        Mr[C] = isk ? pk * inv : Mr[C] - t * pk;
+        Mr[C] = __builtin_fma(-t, pk, Mr[C]);
       }
     });
     Mr[K] = isk ? inv : -t;

@@ -40,7 +40,7 @@ struct EnvLds {
 };
 
 template <int K> __device__ __forceinline__ int row_bcast_int(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, 0x150 + K, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(x, 0x150 + K, 0xF, 0xF, false);
 }
 
 // position of the n-th set bit of mask (n counted from 0); -1 if there is none
@@ -54,17 +54,6 @@ __device__ __forceinline__ int nth_set_bit(unsigned mask, int n) {
 }
 
 struct G16Out { int niter; bool overflow; };
-
-// 1/d to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps (5 dependent instructions instead of the ~14 of an
-// IEEE-correct division; only used for the per-iteration ray step of the contact update)
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-d, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  return r;
-}
 
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
@@ -80,14 +69,15 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     double bias;
     mass_rows<0>(sm, c, dc, l, Mi, bias, false);
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mh[C] = Mi[C] + ((C == c.d && c.dvalid) ? H * dc.damping : 0.0); });
-    gauss_jordan_rows<NV>(Mi, l);
-    gauss_jordan_rows<NV>(Mh, l);
+    gauss_jordan_rows<NV, true>(Mi, l);
+    gauss_jordan_rows<NV, true>(Mh, l);
     if (c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mi[C]; }); }
     double v_d = sm.v[c.d < NV ? c.d : 0];
     double u = ctrl < dc.clo ? dc.clo : (ctrl > dc.chi ? dc.chi : ctrl);
     tau = -dc.damping * v_d - bias + dc.gear * u;
-    qs = 0.0;
-    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mi[C] * row_bcast<C>(tau); });
+    double qs0 = 0.0, qs1 = 0.0;  // two partial sums: halves the dependent-FMA chain
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; if constexpr (C & 1) qs1 += Mi[C] * row_bcast<C>(tau); else qs0 += Mi[C] * row_bcast<C>(tau); });
+    qs = qs0 + qs1;
   }
   if (c.dvalid) sm.qs[c.d] = qs;
   lds_sync();
@@ -239,7 +229,15 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     }
   }
   double res = 0.0;
-  static_for<0, MAXR>([&](auto kk) { constexpr int K = decltype(kk)::value; res += Ac[K] * row_bcast<K>(f); });
+  {
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    static_for<0, MAXR>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      double t = Ac[K] * row_bcast<K>(f);
+      if constexpr ((K & 3) == 0) r0 += t; else if constexpr ((K & 3) == 1) r1 += t; else if constexpr ((K & 3) == 2) r2 += t; else r3 += t;
+    });
+    res = (r0 + r1) + (r2 + r3);
+  }
   {
     double cost = row_sum(active ? f * (0.5 * res + b) : 0.0);
     if (cost > 0) { f = 0.0; res = 0.0; }
@@ -260,63 +258,81 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     if (__ballot(kindK == RK_EQ || kindK == RK_LIM) != 0) anyS |= 1u << K;
     if (__ballot(kindK == RK_CN) != 0) anyP |= 1u << K;
   });
+  double improvement = 0.0;
+  // one single-row step (connect or joint limit) at row K of every environment
+  auto single_step = [&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    const int kindK = (int)((kinds >> (4 * K)) & 15ull);
+    const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
+    double cand = f - res * Ainv;
+    cand = ((kind == RK_LIM) & (cand < 0)) ? 0.0 : cand;
+    double d = cand - f;
+    double chg = d * (0.5 * d * Adiag + res);
+    const bool keep = (chg <= 1e-10) & doS;
+    d = keep ? d : 0.0; chg = keep ? chg : 0.0;
+    double Dd = row_bcast<K>(d);
+    improvement -= row_bcast<K>(chg);
+    f += (l == K) ? d : 0.0;
+    res += Ac[K] * Dd;
+  };
+  // one elliptic contact pair at rows (K, K+1), K even; branch-free so that steps can be scheduled across each other
+  auto pair_step = [&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    const int kindK = (int)((kinds >> (4 * K)) & 15ull);
+    const bool doP = sweeping && kindK == RK_CN;
+    double rt = swap1(res), ot = swap1(f);
+    double rn = res, on = f;
+    double Ann = Adiag, Att = Apart;
+    // normal-only update (taken when the normal force is ~0)
+    double fn_n = on - rn * Ainv;
+    fn_n = fn_n < 0 ? 0.0 : fn_n;
+    // ray update
+    double denom = on * (Ann * on + Ant * ot) + ot * (Ant * on + Att * ot);
+    double x = -(on * rn + ot * rt) * fast_rcp(denom);
+    x = x < -1.0 ? -1.0 : x;
+    x = denom >= MINVAL ? x : 0.0;
+    const bool use_n = on < MINVAL;
+    double fn = use_n ? fn_n : on + x * on;
+    double ft = use_n ? 0.0 : ot + x * ot;
+    // friction on one dimension: unconstrained minimiser unless it leaves the cone
+    double bc = rt - Att * ot + Ant * (fn - on);
+    double x0 = -bc * AttInv;
+    double v1 = x0 * (1.0 / mu);
+    double val = v1 * v1 - fn * fn;
+    const bool on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
+    double ftc = on_cone ? __builtin_copysign(mu * fn, x0) : x0;
+    ft = fn >= MINVAL ? ftc : ft;
+    double dn = fn - on, dt = ft - ot;
+    double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+    const bool keep = (chg <= 1e-10) & doP;
+    dn = keep ? dn : 0.0; dt = keep ? dt : 0.0; chg = keep ? chg : 0.0;
+    double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
+    improvement -= row_bcast<K>(chg);
+    f += (l == K) ? dn : ((l == K + 1) ? Dt : 0.0);
+    res += Ac[K] * Dn + Ac[K + 1] * Dt;
+  };
+  // common configuration (robot on its feet): no active joint limit and at most 4 contacts in every environment of the
+  // wave => rows are exactly 4 connect rows + pairs at rows 4,6,8,10: straight-line sweep without per-step branches
+  const bool simple = __ballot(go && (nlim != 0 || ncon > 4)) == 0;
+  const bool pair8 = (anyP >> 8) & 1u, pair10 = (anyP >> 10) & 1u;
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
-    double improvement = 0.0;
-    static_for<0, MAXR>([&](auto kk) {
-      constexpr int K = decltype(kk)::value;
-      const int kindK = (int)((kinds >> (4 * K)) & 15ull);
-      if ((anyS >> K) & 1u) {
-        const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
-        double cand = f - res * Ainv;
-        if (kind == RK_LIM) cand = cand < 0 ? 0.0 : cand;
-        double d = cand - f;
-        double chg = d * (0.5 * d * Adiag + res);
-        if (chg > 1e-10 || !doS) { d = 0.0; chg = 0.0; }
-        double Dd = row_bcast<K>(d);
-        improvement -= row_bcast<K>(chg);
-        if (l == K) f += d;
-        res += Ac[K] * Dd;
-      }
-      if constexpr ((K & 1) == 0 && K + 1 < MAXR) {
-        if ((anyP >> K) & 1u) {
-          const bool doP = sweeping && kindK == RK_CN;
-          double rt = swap1(res), ot = swap1(f);
-          double rn = res, on = f;
-          double Ann = Adiag, Att = Apart;
-          double fn = on, ft = ot;
-          if (on < MINVAL) {
-            fn = fn - rn * Ainv;
-            fn = fn < 0 ? 0.0 : fn;
-            ft = 0.0;
-          } else {
-            double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
-            if (denom >= MINVAL) {
-              double x = -(fn * rn + ft * rt) * fast_rcp(denom);
-              x = x < -1.0 ? -1.0 : x;
-              fn = fn + x * fn; ft = ft + x * ft;
-            }
-          }
-          if (fn >= MINVAL) {
-            double bc = rt - Att * ot + Ant * (fn - on);
-            double x0 = -bc * AttInv;
-            double v1 = x0 * (1.0 / mu);
-            double val = v1 * v1 - fn * fn;
-            ft = x0;
-            if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
-          }
-          double dn = fn - on, dt = ft - ot;
-          double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
-          if (chg > 1e-10 || !doP) { dn = 0.0; dt = 0.0; chg = 0.0; }
-          double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
-          improvement -= row_bcast<K>(chg);
-          if (l == K) f += dn;
-          if (l == K + 1) f += Dt;
-          res += Ac[K] * Dn + Ac[K + 1] * Dt;
+    improvement = 0.0;
+    if (simple) {
+      single_step(IC<0>{}); single_step(IC<1>{}); single_step(IC<2>{}); single_step(IC<3>{});
+      pair_step(IC<4>{}); pair_step(IC<6>{});
+      if (pair8) pair_step(IC<8>{});
+      if (pair10) pair_step(IC<10>{});
+    } else {
+      static_for<0, MAXR>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        if ((anyS >> K) & 1u) single_step(kk);
+        if constexpr ((K & 1) == 0 && K + 1 < MAXR) {
+          if ((anyP >> K) & 1u) pair_step(kk);
         }
-      }
-    });
+      });
+    }
     if (sweeping) {
       niter = iter + 1;
       if (improvement * scale < CP_TOLERANCE) sweeping = false;
@@ -327,19 +343,26 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
   double gg = tau;
   {
     const int kL = c.kL, kR = c.kR;
+    double g0 = 0.0, g1 = 0.0;
     static_for<0, MAXR>([&](auto kk) {
       constexpr int K = decltype(kk)::value;
       const int k = sm.rowleg[K] == 0 ? kL : kR;
       double js = sm.rowJ[K][k < 0 ? 0 : k];
-      gg += (k < 0 ? 0.0 : js) * row_bcast<K>(f);
+      double t = (k < 0 ? 0.0 : js) * row_bcast<K>(f);
+      if constexpr (K & 1) g1 += t; else g0 += t;
     });
+    gg += g0 + g1;
   }
   double qacc = 0.0, qacch = 0.0;
-  static_for<0, NV>([&](auto cc) {
-    constexpr int C = decltype(cc)::value;
-    double gc = row_bcast<C>(gg);
-    qacc += Mi[C] * gc; qacch += Mh[C] * gc;
-  });
+  {
+    double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      double gc = row_bcast<C>(gg);
+      if constexpr (C & 1) { a1 += Mi[C] * gc; h1 += Mh[C] * gc; } else { a0 += Mi[C] * gc; h0 += Mh[C] * gc; }
+    });
+    qacc = a0 + a1; qacch = h0 + h1;
+  }
   lds_sync();
   if (c.dvalid && go) {
     sm.ws[c.d] = qacc;
