@@ -258,7 +258,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     if (__ballot(kindK == RK_EQ || kindK == RK_LIM) != 0) anyS |= 1u << K;
     if (__ballot(kindK == RK_CN) != 0) anyP |= 1u << K;
   });
-  double improvement = 0.0;
+  double acc = 0.0;  // cost changes of the rows owned by this lane in the current sweep (summed over the row once per sweep)
   // one single-row step (connect or joint limit) at row K of every environment
   auto single_step = [&](auto kk) {
     constexpr int K = decltype(kk)::value;
@@ -269,9 +269,9 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     double d = cand - f;
     double chg = d * (0.5 * d * Adiag + res);
     const bool keep = (chg <= 1e-10) & doS;
-    d = keep ? d : 0.0; chg = keep ? chg : 0.0;
+    d = keep ? d : 0.0;
+    acc += (keep & (l == K)) ? chg : 0.0;
     double Dd = row_bcast<K>(d);
-    improvement -= row_bcast<K>(chg);
     f += (l == K) ? d : 0.0;
     res += Ac[K] * Dd;
   };
@@ -303,11 +303,11 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
     double ftc = on_cone ? __builtin_copysign(mu * fn, x0) : x0;
     ft = fn >= MINVAL ? ftc : ft;
     double dn = fn - on, dt = ft - ot;
-    double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+    double chg = dn * (0.5 * Ann * dn + Ant * dt + rn) + dt * (0.5 * Att * dt + rt);
     const bool keep = (chg <= 1e-10) & doP;
-    dn = keep ? dn : 0.0; dt = keep ? dt : 0.0; chg = keep ? chg : 0.0;
+    dn = keep ? dn : 0.0; dt = keep ? dt : 0.0;
+    acc += (keep & (l == K)) ? chg : 0.0;
     double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
-    improvement -= row_bcast<K>(chg);
     f += (l == K) ? dn : ((l == K + 1) ? Dt : 0.0);
     res += Ac[K] * Dn + Ac[K + 1] * Dt;
   };
@@ -318,7 +318,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
-    improvement = 0.0;
+    acc = 0.0;
     if (simple) {
       single_step(IC<0>{}); single_step(IC<1>{}); single_step(IC<2>{}); single_step(IC<3>{});
       pair_step(IC<4>{}); pair_step(IC<6>{});
@@ -333,6 +333,7 @@ __device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, i
         }
       });
     }
+    const double improvement = -row_sum(acc);
     if (sweeping) {
       niter = iter + 1;
       if (improvement * scale < CP_TOLERANCE) sweeping = false;
