@@ -55,4 +55,18 @@ class Cassie2dTraj:
 
     def action(self, t):
         i = self.index(t)
-        return (self.mpos[i], self.mvel[i], self.torque[i])
+        mpos = None if self.mpos is None else self.mpos[i]
+        mvel = None if self.mvel is None else self.mvel[i]
+        return (mpos, mvel, self.torque[i])
+
+
+def pd_targets(traj, t, kp=10.0, kd=5.0):
+    """PD target angles that reproduce the reference-gait torques through Cassie2d::StepPd's law
+    (Cassie2dEnv.step_traj_export_csv, rllab/envs/cassie2d.py:234-257):
+        angle_i = (torque_i - kd * (0 - qvel_j)) / kp + qpos_j,  j in (3, 4, 6, 8, 9, 11).
+    Returns (angles[6], joint_velocities[6]) -- the two blocks of a row of the reference's trajectory.csv."""
+    qpos, qvel = traj.state(t)
+    torques = traj.action(t)[2]
+    joints = [3, 4, 6, 8, 9, 11]
+    angles = np.array([(torques[i] - kd * (0.0 - qvel[j])) / kp + qpos[j] for i, j in enumerate(joints)])
+    return angles, np.array([qvel[j] for j in joints])

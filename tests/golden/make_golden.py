@@ -30,8 +30,18 @@ def main():
     ac_t = np.array([tr.action(t)[2] for t in grid])
     tmax = tr.time[-1]
     idx = np.array([int((t % tmax) / tmax * len(tr.time)) for t in grid])
+    # PD targets of step_traj_export_csv (cassie2d.py:234-257), evaluated with the reference's own arithmetic
+    pd_t = np.arange(0, 2.0, 0.0137)
+    pd_rows = []
+    for t in pd_t:
+        qpos, qvel = tr.state(t)
+        torques = tr.action(t)[2]
+        joints, kp, kd = [3, 4, 6, 8, 9, 11], 10.0, 5.0
+        angles = [(torques[i] - kd * (0.0 - qvel[joints[i]])) / kp + qpos[joints[i]] for i in range(len(joints))]
+        pd_rows.append(angles + [qvel[j] for j in joints])
     np.savez_compressed(os.path.join(HERE, "traj2d.npz"), time=tr.time, qpos=tr.qpos, qvel=tr.qvel, torque=tr.torque,
-                        grid=grid, grid_index=idx, grid_qpos=st_q, grid_qvel=st_v, grid_torque=ac_t)
+                        grid=grid, grid_index=idx, grid_qpos=st_q, grid_qvel=st_v, grid_torque=ac_t,
+                        pd_t=pd_t, pd_rows=np.array(pd_rows))
     # ---- structs
     kat = {"sizes": {}, "offsets": {}}
     for name in ("ControllerTorque", "ControllerForce", "ControllerOsc", "ControllerPd", "StateGeneral", "StateOperationalSpace"):

@@ -67,3 +67,11 @@ def test_trajectory_conversion_from_stepdata(traj):
     assert np.array_equal(tr.time, traj["time"])
     np.testing.assert_allclose(tr.qpos, traj["qpos"], rtol=0, atol=1e-15)
     assert np.array_equal(tr.qvel, traj["qvel"]) and np.array_equal(tr.torque, traj["torque"])
+
+
+def test_pd_targets_match_step_traj_export_csv(traj):
+    from cassierl_amd.trajectory import pd_targets
+    tr = Cassie2dTraj.from_arrays(traj["time"], traj["qpos"], traj["qvel"], traj["torque"])
+    for t, row in zip(traj["pd_t"], traj["pd_rows"]):
+        ang, vel = pd_targets(tr, t)
+        np.testing.assert_allclose(np.concatenate([ang, vel]), row, rtol=0, atol=1e-14)
