@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcassie2d.so")
-SOURCES = ["cassie_cabi.hip", "cassie_kernels.hip", "cassie_vec_layout.h", "cassie2d_planar.h"]
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))  # cassie_cabi.hip includes the rest
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("cassie2d.h", "cassie_vec.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]

@@ -23,16 +23,21 @@ constexpr int NCR = 15;  // controller rows: 0..3 Jeq (Lx,Lz,Rx,Rz), 4..13 targe
 constexpr int NZ = 14;   // QP variables
 constexpr double OSC_W_COM = 5.0, OSC_W_STANCE = 10.0, OSC_W_REST = 0.1, OSC_W_F = 1e-4, OSC_MU = 0.5;  // OSC_RBDL.h:92-98, RobotInterface.h:64
 
+// The controller code below is ROW-GENERIC: `l` is the lane index inside a 16-lane DPP row and `rowok` says whether the row
+// hosts a problem.  The wave-per-environment kernel runs it with one live row (rowok = lane < 16); the 4-envs-per-wave
+// kernel runs it with four.  Every cross-lane step is a DPP row operation and every loop is controlled by wave-wide
+// "any row still busy" ballots, so rows never diverge around a DPP instruction.
 struct CtrlSmem {
   double Jd[NCR][NV];  // dense controller rows
   double acc[16];      // JdotQdot of each row (velocity-product acceleration, no gravity)
   double JH[4][NV];    // Jeq Hinv
   double S4[16];       // Jeq Hinv Jeq' (4x4)
-  double T[NZ][12];    // T[var][target row]
-  double t0[12];
+  union {
+    struct { double T[NZ][12]; double t0[12]; };  // OSC: T[var][target row], t0
+    struct { double U[6][NV]; };                  // Jacobian controller: Nc Bt columns
+  };
   double bias[16];     // NonlinearEffects + damping*qvel (DynamicState.cpp:47-52)
   double y[16];
-  double U[6][NV];     // Nc Bt columns (Jacobian controller)
   double act[8];       // controller input (7 accelerations or 6 forces)
   double u[8];         // controller output
   double s18[18];
@@ -78,15 +83,17 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
 // ---------------------------------------------------------------- DynamicState + constraint projector (both controllers)
 // Leaves in LDS: sm.minv = Hinv (RBDL semantics), cs.Jd, cs.acc, cs.JH, cs.bias; returns the wave-uniform P4 = (Jeq Hinv Jeq')^+
 // and g4 = P4 * JeqdotQdot.
-__device__ __forceinline__ void ctrl_dyn(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, double (&P4)[16], double (&g4)[4]) {
+template <class SM>
+__device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, double (&P4)[16], double (&g4)[4]) {
+  const int lane = rowok ? l : 63;  // role tests below are written against `lane`; dead rows take no role
   planar_fk<1>(sm, sm.q, sm.v, c, lane);
   {
     DofConst dc;
     load_dof_const(dc, c);
     double Mr[NV], bias;
-    mass_rows<1>(sm, c, dc, lane, Mr, bias, false);
-    gauss_jordan_rows<NV>(Mr, lane);
-    if (c.dvalid && c.grp == 0) {
+    mass_rows<1>(sm, c, dc, l, Mr, bias, false);
+    gauss_jordan_rows<NV>(Mr, l);
+    if (c.dvalid && c.grp == 0 && rowok) {
       static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
       cs.bias[c.d] = bias + dc.damping * sm.v[c.d];
     }
@@ -181,9 +188,11 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 }
 
 // ---------------------------------------------------------------- Cassie2d::StepOsc controller: cs.act[7] -> cs.u[6]
-__device__ __forceinline__ void ctrl_osc(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane) {
+template <class SM>
+__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid) {
+  const int lane = rowok ? l : 63;
   double P4[16], g4[4];
-  ctrl_dyn(sm, cs, c, lane, P4, g4);
+  ctrl_dyn(sm, cs, c, l, rowok, P4, g4);
   // ---- column lanes: 0..5 motors, 6..13 friction-cone generators of contact sites 2..5, 14 the bias column
   {
     double w[NV];
@@ -249,63 +258,72 @@ __device__ __forceinline__ void ctrl_osc(Smem& sm, CtrlSmem& cs, const LaneConst
       G[Jv] = s;
     });
   }
-  const bool isvar = (lane & 15) < NZ && lane < 16;
+  const bool isvar = rowok && l < NZ;
   const double lo = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][0] : 0.0;
   const double hi = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][1] : 1.7976931348623157e308;
-  // ---- primal active-set iterations
+  // ---- primal active-set iterations; each row runs its own problem, the loop ends when no row is busy
   double z = 0.0;
-  bool bound = lane >= 6, atlo = true;
+  bool bound = l >= 6, atlo = true;
+  bool busy = rowok;  // uniform inside a row
   for (int it = 0; it < 60; it++) {
+    if (__ballot(busy) == 0) break;
     double g = cq;
     static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g += G[Jv] * row_bcast<Jv>(z); });
-    const unsigned bm = (unsigned)(__ballot(bound && isvar) & 0xFFFFu);
+    const unsigned bm = (unsigned)(__ballot(bound && isvar) >> (16 * rowid)) & 0xFFFFu;
     double Mr[NZ];
     static_for<0, NZ>([&](auto jj) {
       constexpr int Jv = decltype(jj)::value;
       double val = G[Jv];
       if (bound || ((bm >> Jv) & 1)) val = 0.0;
-      if (Jv == (lane & 15) && (bound || !isvar)) val = 1.0;
-      if (!isvar) val = (Jv == (lane & 15)) ? 1.0 : 0.0;
+      if (Jv == (l & 15) && (bound || !isvar)) val = 1.0;
+      if (!isvar) val = (Jv == (l & 15)) ? 1.0 : 0.0;
       Mr[Jv] = val;
     });
-    gauss_jordan_rows<NZ>(Mr, lane);
+    gauss_jordan_rows<NZ>(Mr, l);
     const double rhs = (bound || !isvar) ? 0.0 : -g;
     double d = 0.0;
     static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; d += Mr[Jv] * row_bcast<Jv>(rhs); });
     // ratio test
     double t = 2.0;
     if (isvar && !bound) {
-      if (d > 0 && lane < 6) t = (hi - z) / d;
+      if (d > 0 && l < 6) t = (hi - z) / d;
       else if (d < 0) t = (lo - z) / d;
       if (t < 0) t = 0;
     }
-    double tmin = rdlane(row_min(t), 0);  // wave-uniform decision taken from the row that holds the QP
-    double alpha = tmin < 1.0 ? tmin : 1.0;
-    z += alpha * d;
-    if (tmin < 1.0) {
-      unsigned hit = (unsigned)(__ballot(isvar && !bound && t == tmin) & 0xFFFFu);
-      int blk = __ffs(hit) - 1;
-      if (lane == blk) { bound = true; atlo = d < 0; z = atlo ? lo : hi; }
-      continue;
+    const double tmin = row_min(t);
+    const bool blocked = tmin < 1.0;
+    const double alpha = blocked ? tmin : 1.0;
+    if (busy) z += alpha * d;
+    {
+      const unsigned hit = (unsigned)(__ballot(busy && blocked && isvar && !bound && t == tmin) >> (16 * rowid)) & 0xFFFFu;
+      const int blk = __ffs(hit) - 1;
+      if (busy && blocked && l == blk) { bound = true; atlo = d < 0; z = atlo ? lo : hi; }
     }
-    // full step: multipliers of the working set at the new point
-    g = cq;
-    static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g += G[Jv] * row_bcast<Jv>(z); });
-    double viol = (bound && isvar) ? (atlo ? -g : g) : -1.0e300;
-    double vmax = rdlane(row_max(viol), 0);
-    if (vmax <= 1e-9) break;
-    unsigned hit = (unsigned)(__ballot(isvar && bound && viol == vmax) & 0xFFFFu);
-    int rel = __ffs(hit) - 1;
-    if (lane == rel) bound = false;
+    // full step: multipliers of the working set at the new point (evaluated for every row, used by the unblocked ones)
+    double g2 = cq;
+    static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g2 += G[Jv] * row_bcast<Jv>(z); });
+    const double viol = (bound && isvar) ? (atlo ? -g2 : g2) : -1.0e300;
+    const double vmax = row_max(viol);
+    const bool full = busy && !blocked;
+    const bool conv = full && vmax <= 1e-9;
+    {
+      const unsigned hit = (unsigned)(__ballot(full && !conv && isvar && bound && viol == vmax) >> (16 * rowid)) & 0xFFFFu;
+      const int rel = __ffs(hit) - 1;
+      if (full && !conv && l == rel) bound = false;
+    }
+    if (conv) busy = false;
   }
   if (lane < 6) cs.u[lane] = z;
   lds_sync();
 }
 
 // ---------------------------------------------------------------- Cassie2d::StepJacobian controller: cs.act[6] -> cs.u[6]
-__device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, double* dbg = nullptr) {
+template <class SM>
+__device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, double* dbg = nullptr) {
+  const int lane = rowok ? l : 63;
+  (void)rowid;
   double P4[16], g4[4];
-  ctrl_dyn(sm, cs, c, lane, P4, g4);
+  ctrl_dyn(sm, cs, c, l, rowok, P4, g4);
   if (dbg && lane == 0) {
     for (int i = 0; i < 13; i++) dbg[97 + i] = cs.bias[i];
     for (int i = 0; i < 4; i++) dbg[110 + i] = g4[i];
@@ -313,7 +331,7 @@ __device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const Lane
     for (int i = 0; i < NCR * NV; i++) dbg[130 + i] = cs.Jd[i / NV][i % NV];
   }
   // Jc6' f on the dof lanes: per foot the mean of the two 6-D site Jacobians; f = (My, Fx, Fz) (Cassie2d.cpp:139-163)
-  if (c.dvalid && c.grp == 0) {
+  if (c.dvalid && c.grp == 0 && rowok) {
     double jtf = 0.0;
 #pragma unroll
     for (int foot = 0; foot < 2; foot++) {
@@ -352,33 +370,37 @@ __device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const Lane
   double Ur[6], Vr[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) { Ur[k] = rowU ? cs.U[k][lane < NV ? lane : 0] : 0.0; Vr[k] = (rowV && lane == k) ? 1.0 : 0.0; }
+  bool busy = rowok;
   for (int sweep = 0; sweep < 30; sweep++) {
-    double off = 0.0;  // wave-uniform: rotation parameters are taken from the 16-lane row that holds the matrix
+    if (__ballot(busy) == 0) break;
+    double off = 0.0;  // uniform inside a row
     static_for<0, 5>([&](auto pp) {
       constexpr int Pp = decltype(pp)::value;
       static_for<Pp + 1, 6>([&](auto qq) {
         constexpr int Q = decltype(qq)::value;
-        double a = rdlane(row_sum(Ur[Pp] * Ur[Pp]), 0), b = rdlane(row_sum(Ur[Q] * Ur[Q]), 0), cc = rdlane(row_sum(Ur[Pp] * Ur[Q]), 0);
-        if (fabs(cc) > 1e-300 && fabs(cc) > 1e-17 * sqrt(a * b)) {
-          off += fabs(cc) / sqrt(a * b);
-          double zeta = (b - a) / (2.0 * cc);
-          double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          double cs_ = 1.0 / sqrt(1.0 + t * t), sn = cs_ * t;
-          double up = Ur[Pp], uq = Ur[Q];
-          Ur[Pp] = cs_ * up - sn * uq; Ur[Q] = sn * up + cs_ * uq;
-          double vp = Vr[Pp], vq = Vr[Q];
-          Vr[Pp] = cs_ * vp - sn * vq; Vr[Q] = sn * vp + cs_ * vq;
-        }
+        double a = row_sum(Ur[Pp] * Ur[Pp]), b = row_sum(Ur[Q] * Ur[Q]), cc = row_sum(Ur[Pp] * Ur[Q]);
+        const bool rot = busy && fabs(cc) > 1e-300 && fabs(cc) > 1e-17 * sqrt(a * b);
+        // rotation parameters (computed on every lane, applied where `rot`): no DPP below this point of the pair
+        double ab = sqrt(a * b);
+        double zeta = (b - a) / (2.0 * (rot ? cc : 1.0));
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double cs_ = 1.0 / sqrt(1.0 + t * t), sn = cs_ * t;
+        cs_ = rot ? cs_ : 1.0; sn = rot ? sn : 0.0;
+        off += rot ? fabs(cc) / ab : 0.0;
+        double up = Ur[Pp], uq = Ur[Q];
+        Ur[Pp] = cs_ * up - sn * uq; Ur[Q] = sn * up + cs_ * uq;
+        double vp = Vr[Pp], vq = Vr[Q];
+        Vr[Pp] = cs_ * vp - sn * vq; Vr[Q] = sn * vp + cs_ * vq;
       });
     });
-    if (off < 1e-15) break;
+    if (off < 1e-15) busy = false;
   }
   double rhs = rowU ? cs.y[lane < NV ? lane : 0] : 0.0;
   double u = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    double s2 = rdlane(row_sum(Ur[k] * Ur[k]), 0);
-    double pr = rdlane(row_sum(Ur[k] * rhs), 0);
+    double s2 = row_sum(Ur[k] * Ur[k]);
+    double pr = row_sum(Ur[k] * rhs);
     double coef = sqrt(s2) > 1e-4 ? pr / s2 : 0.0;
     u += Vr[k] * coef;
   }
@@ -393,10 +415,10 @@ __device__ __forceinline__ void ctrl_jacobian(Smem& sm, CtrlSmem& cs, const Lane
 
 // ---------------------------------------------------------------- scripted standing controllers (cassie2d.py:263-331)
 // Reads the operational-space state exactly as the Python does (GetOperationalSpaceState before the step: stale kinematics).
-template <int CTRL>
-__device__ __forceinline__ void scripted_targets(Smem& sm, CtrlSmem& cs, const LaneConst& c, int lane, bool fix_kin, double zpos, double zvel) {
-  opstate18(sm, c, lane, fix_kin, cs.s18);
-  if (lane == 0) {
+template <int CTRL, class SM>
+__device__ __forceinline__ void scripted_targets(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, bool fix_kin, double zpos, double zvel) {
+  opstate18(sm, c, rowok ? l : 63, fix_kin, cs.s18);
+  if (rowok && l == 0) {
     const double* s = cs.s18;  // body_x 0..2, body_xd 3..5, left_x 6..8, left_xd 9..11, right_x 12..14, right_xd 15..17
     if (CTRL == 2) {
       const double stance_kp = 100.0, com_kp = 100.0, com_kd = 20.0, pitch_kp = 20.0, pitch_kd = 10.0;
@@ -446,11 +468,11 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   int niter_sum = 0;
   double ctrl = 0.0;
   for (int sub = 0; sub < p.n_sub; sub++) {
-    if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, fix_kin, zp, zv);
+    if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zp, zv);
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
     lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, lane);
-    else ctrl_jacobian(sm, cs, c, lane, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
+    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4);
+    else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
     ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
     substep<true, 32>(sm, c, lane, ctrl, so, nullptr, ovf);
     niter_sum += so.niter;

@@ -63,7 +63,11 @@ template <int CTRLCODE> __device__ __forceinline__ double dpp_mov(double x) {
   int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRLCODE, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// The adds must not be contracted with a multiply in the caller: fma(a_i, b_i, x_j) on lane i and fma(a_j, b_j, x_i) on lane j
+// round differently, and then the lanes of a row disagree in the last bit -- fatal for per-row decisions taken from the sum
+// (Jacobi rotation signs, active-set picks).  With contraction off every lane of the row gets the bit-identical value.
 __device__ __forceinline__ double row_sum(double x) {
+#pragma clang fp contract(off)
   x += dpp_mov<0x128>(x); x += dpp_mov<0x124>(x); x += dpp_mov<0x122>(x); x += dpp_mov<0x121>(x);
   return x;
 }
