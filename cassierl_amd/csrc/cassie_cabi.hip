@@ -16,6 +16,7 @@
 #include "cassie_kernels.hip"
 #include "cassie_kernels_g16.hip"
 #include "cassie_ctrl.hip"
+#include "cassie_ctrl_g16.hip"
 
 static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
 static_assert(sizeof(StateGeneral) == 208 && sizeof(StateOperationalSpace) == 144 && sizeof(ControllerOsc) == 56 &&
@@ -82,6 +83,30 @@ cassie::VecParams make_params(CassieVec* h) {
   return p;
 }
 
+// controller-in-the-loop modes; zpos/zvel != null selects the scripted standing controllers
+template <int CTRL, bool SCRIPTED>
+void launch_ctrl_kernels(CassieVec* h, const cassie::VecParams& p, const double* zpos, const double* zvel) {
+  dim3 grid(h->n), block(64);
+  if (h->g16 && !p.debug) {
+    // 4 environments per wavefront, then the wave-per-environment kernel for the (rare) environments left pending
+    hipLaunchKernelGGL((cassie::g16::env_ctrl_step_g16_kernel<CTRL, SCRIPTED>), dim3((h->n + 3) / 4), block, 0, h->stream, p, zpos, zvel, h->pending);
+    cassie::VecParams pc = p;
+    pc.pending = h->pending;
+    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<CTRL, SCRIPTED>), grid, block, 0, h->stream, pc, zpos, zvel);
+  } else {
+    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<CTRL, SCRIPTED>), grid, block, 0, h->stream, p, zpos, zvel);
+  }
+}
+
+int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const double* zpos, const double* zvel) {
+  const bool scripted = zpos != nullptr;
+  if (mode == CASSIE_CTRL_OSC) { if (scripted) launch_ctrl_kernels<2, true>(h, p, zpos, zvel); else launch_ctrl_kernels<2, false>(h, p, zpos, zvel); }
+  else if (mode == CASSIE_CTRL_JACOBIAN) { if (scripted) launch_ctrl_kernels<3, true>(h, p, zpos, zvel); else launch_ctrl_kernels<3, false>(h, p, zpos, zvel); }
+  else return fail(h, CASSIE_EINVAL, "controller-in-the-loop stepping exists for OSC and Jacobian modes only");
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   dim3 grid(h->n), block(64);
   const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
@@ -106,10 +131,8 @@ int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
     if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4, MAXACT>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3, MAXACT>), grid, block, 0, h->stream, p);
   }
-  else if (mode == CASSIE_CTRL_OSC) {
-    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<2, false>), grid, block, 0, h->stream, p, (const double*)nullptr, (const double*)nullptr);
-  } else if (mode == CASSIE_CTRL_JACOBIAN) {
-    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<3, false>), grid, block, 0, h->stream, p, (const double*)nullptr, (const double*)nullptr);
+  else if (mode == CASSIE_CTRL_OSC || mode == CASSIE_CTRL_JACOBIAN) {
+    return launch_ctrl_step(h, mode, p, nullptr, nullptr);
   } else return fail(h, CASSIE_EINVAL, "unknown control mode %d", mode);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
@@ -234,12 +257,7 @@ int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev
   HIPCHK(h, hipSetDevice(h->device));
   cassie::VecParams p = make_params(h);
   p.actions = nullptr; p.n_sub = n_sub; p.obs = nullptr;
-  dim3 grid(h->n), block(64);
-  if (control_mode == CASSIE_CTRL_OSC) hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<2, true>), grid, block, 0, h->stream, p, zpos_dev, zvel_dev);
-  else if (control_mode == CASSIE_CTRL_JACOBIAN) hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<3, true>), grid, block, 0, h->stream, p, zpos_dev, zvel_dev);
-  else return fail(h, CASSIE_EINVAL, "standing controllers exist for OSC and Jacobian modes only");
-  HIPCHK(h, hipGetLastError());
-  return CASSIE_OK;
+  return launch_ctrl_step(h, control_mode, p, zpos_dev, zvel_dev);
 }
 
 int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev) {

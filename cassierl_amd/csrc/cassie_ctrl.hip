@@ -452,6 +452,9 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   if (env >= p.n_envs) return;
+  // clean-up pass of the 4-envs-per-wave kernel: only the envs it could not finish, only their remaining substeps
+  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
+  if (n_sub == 0) return;
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
   double ctrl = 0.0;
-  for (int sub = 0; sub < p.n_sub; sub++) {
+  for (int sub = 0; sub < n_sub; sub++) {
     if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zp, zv);
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
     lds_sync();

@@ -57,8 +57,8 @@ struct G16Out { int niter; bool overflow; };
 
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
-template <bool INTEGRATE>
-__device__ __forceinline__ void substep(EnvLds& sm, const LaneConst& c, int l, int g, double ctrl, bool live, G16Out& out) {
+template <bool INTEGRATE, class SM>
+__device__ __forceinline__ void substep(SM& sm, const LaneConst& c, int l, int g, double ctrl, bool live, G16Out& out) {
   // ---- kinematics, mass matrix, both inverses
   planar_fk<0>(sm, sm.q, sm.v, c, l);
   double Mi[NV], Mh[NV];  // rows of M^-1 and (M + h B)^-1 on the dof lanes

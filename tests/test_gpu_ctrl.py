@@ -158,3 +158,61 @@ def test_legacy_abi_osc_and_jacobian(oracle_mod):
     q1, v1 = o.state()
     np.testing.assert_allclose(qg, q1, atol=1e-7)
     np.testing.assert_allclose(vg, v1, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_g16_and_wave_per_env_controller_kernels_agree(vec, mode):
+    """Env.step with the controller in the loop: the 4-envs-per-wave kernel (+ clean-up pass for environments that need more
+    than 16 constraint rows) against the wave-per-environment kernel, teacher-forced, including falls and auto-resets."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 41
+    rng = np.random.default_rng(5)
+    a = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True)
+    b = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
+    np.testing.assert_array_equal(a.reset_host(), b.reset_host())
+    ndone = 0
+    for t in range(160):
+        if mode == "OSC":
+            acts = np.stack([osc_action(rng) for e in range(n)])
+            if t >= 30:
+                acts[::3, 0], acts[::3, 1], acts[::3, 6] = 15.0, -20.0, 10.0  # drive every third robot into the ground
+        else:
+            acts = np.stack([jac_action(rng) * (1.0 if (t < 30 or e % 3) else 0.2) for e in range(n)])
+        b.set_full_state_host(a.get_full_state_host())
+        oa, ra, da = a.step_host(acts)
+        ob, rb, db = b.step_host(acts)
+        assert (da == db).all()
+        ndone += int(da.sum())
+        np.testing.assert_allclose(ra, rb, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(oa, ob, rtol=0, atol=1e-7)
+        sa, sb = a.get_full_state_host(), b.get_full_state_host()
+        np.testing.assert_allclose(sa[:, :26], sb[:, :26], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sa[:, 39:65], sb[:, 39:65], rtol=0, atol=1e-7)  # kinematics of the last setState (Q1/Q2)
+        np.testing.assert_allclose(sa[:, 78:84], sb[:, 78:84], rtol=0, atol=1e-5)  # mj_data->ctrl
+        np.testing.assert_allclose(sa[:, 84], sb[:, 84], atol=1e-12)               # env time
+    assert ndone > 0  # some environments fell: the overflow / clean-up / auto-reset branches ran
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_g16_scripted_standing_controller_agrees(vec, mode):
+    """standing_controller_* in the loop on perturbed initial poses (config 3's workload), both kernels."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 23
+    rng = np.random.default_rng(9)
+    a = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    b = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False, flags=WAVE_PER_ENV)
+    a.reset_host(); b.reset_host()
+    s = a.get_full_state_host()
+    s[:, :13] += rng.uniform(-0.01, 0.01, (n, 13))
+    a.set_full_state_host(s)
+    zp = rng.uniform(0.7, 0.95, n)
+    for blk in range(40):
+        b.set_full_state_host(a.get_full_state_host())
+        a.standing_step_host(mode, zp, 0.0, 10)
+        b.standing_step_host(mode, zp, 0.0, 10)
+        sa, sb = a.get_full_state_host(), b.get_full_state_host()
+        np.testing.assert_allclose(sa[:, :26], sb[:, :26], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sa[:, 39:65], sb[:, 39:65], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sa[:, 84], sb[:, 84], atol=1e-12)
+    a.close(); b.close()
