@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
     else ctrl_jacobian(sm, cs, c, l, live, g);
     const double cnew = c.act >= 0 ? cs.u[c.act] : 0.0;
     lds_sync();
-    substep<true>(sm, c, l, g, cnew, live, so);
+    substep(sm, c, l, g, cnew, live, true, so);
     if (live && so.overflow) {
       // not done here: undo setState so that the clean-up pass sees the environment exactly as before this substep
       live = false; pend = p.n_sub - sub;
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
       if (do_reset) time = 0.0;
       lds_sync();
       G16Out ro; ro.niter = 0; ro.overflow = false;
-      substep<false>(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, ro);  // reset pose: 12 rows, cannot overflow
+      substep(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, false, ro);  // reset pose: 12 rows, cannot overflow
       double ra, rb;
       opstate_regs(ra, rb);
       if (do_reset) { obs_a = ra; obs_b = rb; }

@@ -57,13 +57,24 @@ struct G16Out { int niter; bool overflow; };
 
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
-template <bool INTEGRATE, class SM>
-__device__ __forceinline__ void substep(SM& sm, const LaneConst& c, int l, int g, double ctrl, bool live, G16Out& out) {
+// `integrate` (wave-uniform) = false gives mj_forward only (Cassie2d::Reset); it is a run-time flag so that a kernel carries ONE
+// copy of this code (two copies doubled the code size and the register spills around the second one).
+template <class SM>
+__device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, int g, double ctrl, bool live, bool integrate, G16Out& out) {
+  // Per-lane model constants are re-read from constant memory in every substep (K$/L1 hits).  Without these barriers the
+  // compiler hoists ~50 loop-invariant table loads out of the substep loop and then spills them to scratch, which costs
+  // HBM write traffic at every kernel boundary (profiles/r01_c_pmc: 32 MB per launch against 3.7 MB algorithmic).
+  l = opaque(l);
+  LaneConst c = c_in;
+  c.ancmask = opaque(c.ancmask); c.d = opaque(c.d); c.dlink = opaque(c.dlink); c.submask = opaque(c.submask);
+  c.rel = opaque(c.rel); c.act = opaque(c.act); c.kL = opaque(c.kL); c.kR = opaque(c.kR);
   // ---- kinematics, mass matrix, both inverses
   planar_fk<0>(sm, sm.q, sm.v, c, l);
-  double Mi[NV], Mh[NV];  // rows of M^-1 and (M + h B)^-1 on the dof lanes
+  double Mh[NV];  // row of (M + h B)^-1 on the dof lanes (the row of M^-1 is re-read from LDS at the end: 26 VGPRs less
+                  // live across the PGS loop)
   double tau, qs;
   {
+    double Mi[NV];
     DofConst dc;
     load_dof_const(dc, c);
     double bias;
@@ -360,14 +371,15 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c, int l, int g
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
       double gc = row_bcast<C>(gg);
-      if constexpr (C & 1) { a1 += Mi[C] * gc; h1 += Mh[C] * gc; } else { a0 += Mi[C] * gc; h0 += Mh[C] * gc; }
+      const double mi = sm.minv[(c.dvalid ? c.d : 0) * NV + C];
+      if constexpr (C & 1) { a1 += mi * gc; h1 += Mh[C] * gc; } else { a0 += mi * gc; h0 += Mh[C] * gc; }
     });
     qacc = a0 + a1; qacch = h0 + h1;
   }
   lds_sync();
   if (c.dvalid && go) {
     sm.ws[c.d] = qacc;
-    if (INTEGRATE) {
+    if (integrate) {
       double vn = sm.v[c.d] + H * qacch;
       sm.v[c.d] = vn;
       sm.q[c.d] = sm.q[c.d] + H * vn;
@@ -406,35 +418,45 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   int pend = 0, niter_sum = 0;
   double ctrl = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
-  for (int sub = 0; sub < p.n_sub; sub++) {
+  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+  // One loop, one copy of the substep code: passes 0..n_sub-1 are the physics substeps; the end-of-step section computes
+  // observation / reward / termination; if any environment of the wave terminated, one more pass (mj_forward only, on the
+  // reset pose, for those environments) produces the reset observation.
+  double obs_a = 0.0, obs_b = 0.0, reward = 0.0;
+  int done = 0;
+  bool do_reset = false, reset_pass = false;
+  int sub = 0;
+  while (true) {
     const int dd = c.d < NV ? c.d : 0;
     const double q_d = sm.q[dd], v_d = sm.v[dd];
-    double cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l;
-    substep<true>(sm, c, l, g, cnew, live, so);
-    if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
-    if (live) { kq_r = q_d; kv_r = v_d; ctrl = cnew; niter_sum += so.niter; time += 0.0005; }  // setState of this substep
-    if (__ballot(live) == 0) break;
-  }
-  if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = ctrl;
-  lds_sync();
-  // ---- observation, reward, termination for the environments that completed all substeps
-  if (p.obs) {
-    const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
-    auto opstate_regs = [&](double& oa, double& ob, double& bodyx) {
-      if (l < NV) { sm.kq[l] = kq_r; sm.kv[l] = kv_r; }
+    double cnew;
+    if (reset_pass) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
+    else cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l;
+    substep(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so);  // reset pose: 12 active rows, cannot overflow
+    if (!reset_pass) {
+      if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
+      if (live) { kq_r = q_d; kv_r = v_d; ctrl = cnew; niter_sum += so.niter; time += 0.0005; }  // setState of this substep
+      sub++;
+      if (sub < p.n_sub && __ballot(live) != 0) continue;
+      if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = ctrl;
       lds_sync();
-      opstate18(sm, c, l, fix_kin, sm.s18);
-      oa = sm.s18[l + 1 < 18 ? l + 1 : 17];      // obs[l] = s18[l+1]
-      bodyx = sm.s18[0];
-      if (l == 5 || l == 11) oa -= bodyx;
-      ob = l == 0 ? sm.s18[17] : 0.0;            // obs[16 + l]
-      lds_sync();
-    };
-    double obs_a, obs_b, bodyx;
-    opstate_regs(obs_a, obs_b, bodyx);
+    }
+    if (!p.obs) break;
+    // ---- end-of-step section: operational-space state from the kinematics of the last setState (quirks Q1/Q2)
+    if (l < NV) { sm.kq[l] = kq_r; sm.kv[l] = kv_r; }
+    lds_sync();
+    opstate18(sm, c, l, fix_kin, sm.s18);
+    double oa = sm.s18[l + 1 < 18 ? l + 1 : 17];      // obs[l] = s18[l+1]
+    const double bodyx = sm.s18[0];
+    if (l == 5 || l == 11) oa -= bodyx;
+    double ob = l == 0 ? sm.s18[17] : 0.0;            // obs[16 + l]
+    lds_sync();
+    if (reset_pass) {
+      if (do_reset) { obs_a = oa; obs_b = ob; }       // Cassie2dEnv.reset returns the 17 op-space values only
+      break;
+    }
+    obs_a = oa; obs_b = ob;
     const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
-    double reward = 0.0;
-    int done = 0;
     if (p.env_kind == 0) {
       double tmax = p.traj_tmax;
       int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
@@ -470,23 +492,18 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       done = z < 0.5;
     }
     if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
-    const bool do_reset = live && done && p.auto_reset;
-    if (__ballot(do_reset) != 0) {
-      // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
-      if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; qstate_l = cp_env_qinit[l]; }
-      if (do_reset) time = 0.0;
-      lds_sync();
-      G16Out ro; ro.niter = 0; ro.overflow = false;
-      substep<false>(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, ro);  // 12 active rows: cannot overflow
-      double ra, rb, rx;
-      opstate_regs(ra, rb, rx);  // reset observation from the stale kinematics (quirk Q2)
-      if (do_reset) { obs_a = ra; obs_b = rb; }
-    }
-    if (live) {
-      p.obs[e * 26 + l] = obs_a;
-      if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
-      if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
-    }
+    do_reset = live && done && p.auto_reset;
+    if (__ballot(do_reset) == 0) break;
+    // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
+    if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; qstate_l = cp_env_qinit[l]; }
+    if (do_reset) time = 0.0;
+    lds_sync();
+    reset_pass = true;
+  }
+  if (p.obs && live) {
+    p.obs[e * 26 + l] = obs_a;
+    if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
+    if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
   }
   // ---- state write-back
   if (valid) {
