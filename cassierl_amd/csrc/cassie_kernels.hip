@@ -678,6 +678,10 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   if (env >= p.n_envs) return;
+  // clean-up pass of the 4-envs-per-wave kernel: only envs it could not finish, only their remaining substeps.  Checked before
+  // anything else so that the (usual) no-op wave touches neither the state nor its scratch.
+  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
+  if (n_sub == 0) return;
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);
@@ -692,9 +696,6 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   double* ovf = p.ovf + (size_t)env * p.ovf_stride;
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
-  // clean-up pass of the 4-envs-per-wave kernel: only envs it could not finish, only their remaining substeps
-  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
-  if (n_sub == 0) return;
   for (int sub = 0; sub < n_sub; sub++) {
     // DynamicModel::setState: remember the pre-step state (kinematics used by GetOperationalSpaceState)
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }

@@ -24,11 +24,15 @@ namespace g16 {
 constexpr int MAXR = 16;
 enum { RK_SKIP = 0, RK_EQ = 1, RK_LIM = 2, RK_CN = 3, RK_CT = 4 };
 
-// LDS of one environment (3.9 KB; 4 per wavefront).  Buffers whose lifetimes do not overlap inside a substep share storage.
+// LDS of one environment (4.5 KB; 4 per wavefront, 8 wavefronts per CU).  Buffers whose lifetimes do not overlap inside a
+// substep share storage.  kq2..tim are per-lane values that live across all substeps of an Env.step; they sit in LDS rather
+// than in VGPRs because the register allocator would otherwise spill exactly those (long-lived, rarely used) to scratch.
 struct EnvLds {
   double q[16], v[16], ws[16], ctrl[8];
   double lc[12], ls[12], lw[12], lox[12], loz[12], lcx[12], lcz[12], lfx[12], lfz[12];
   double qs[16];
+  double kq2[16], kv2[16];  // qpos/qvel at the last DynamicModel::setState (ES_KQ/ES_KV)
+  double qst[16], actl[16], ctl[16], tim[2];  // self.qstate, this step's action per dof lane, last ctrl per dof lane, env time
   union {
     struct { double s1x[16], s1z[16], s2[16]; };          // mass_rows exchange (dead once the M rows are built)
     struct { double rowJ[MAXR][8]; int rowleg[MAXR]; };   // constraint rows (from the row build to the end of the substep)
@@ -70,8 +74,6 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   c.rel = opaque(c.rel); c.act = opaque(c.act); c.kL = opaque(c.kL); c.kR = opaque(c.kR);
   // ---- kinematics, mass matrix, both inverses
   planar_fk<0>(sm, sm.q, sm.v, c, l);
-  double Mh[NV];  // row of (M + h B)^-1 on the dof lanes (the row of M^-1 is re-read from LDS at the end: 26 VGPRs less
-                  // live across the PGS loop)
   double tau, qs;
   {
     double Mi[NV];
@@ -79,9 +81,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     load_dof_const(dc, c);
     double bias;
     mass_rows<0>(sm, c, dc, l, Mi, bias, false);
-    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; Mh[C] = Mi[C] + ((C == c.d && c.dvalid) ? H * dc.damping : 0.0); });
     gauss_jordan_rows<NV, true>(Mi, l);
-    gauss_jordan_rows<NV, true>(Mh, l);
     if (c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mi[C]; }); }
     double v_d = sm.v[c.d < NV ? c.d : 0];
     double u = ctrl < dc.clo ? dc.clo : (ctrl > dc.chi ? dc.chi : ctrl);
@@ -366,6 +366,18 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     gg += g0 + g1;
   }
   double qacc = 0.0, qacch = 0.0;
+  // (M + h B)^-1 for the implicit-damping Euler step is built HERE, from a second pass over the (still valid) link sums, rather
+  // than next to M^-1 at the top: its 13 doubles per lane would otherwise be live across the whole constraint solve and push
+  // the kernel over 256 VGPRs (r01_c: 356 B/lane of scratch = 32 MB of HBM writes per launch).  The row of M^-1 is re-read
+  // from LDS.  rowJ (overlaid by mass_rows' exchange buffers) is dead from here on.
+  double Mh[NV];
+  {
+    DofConst dc;
+    load_dof_const(dc, c);
+    double bias_unused;
+    mass_rows<0>(sm, c, dc, l, Mh, bias_unused, true);
+    gauss_jordan_rows<NV, true>(Mh, l);
+  }
   {
     double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
     static_for<0, NV>([&](auto cc) {
@@ -403,27 +415,23 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   load_lane_const(c, l);  // roles are per 16-lane row
   c.grp = 0; c.dvalid = l < NV;
   // ---- state load (strided inside the 704-byte record; the four records of a wave are adjacent)
-  double qstate_l = 0.0, kq_r = 0.0, kv_r = 0.0;  // lane l < 13 holds element l
   if (l < NV) {
     sm.q[l] = st[ES_Q + l]; sm.v[l] = st[ES_V + l]; sm.ws[l] = st[ES_WS + l];
-    kq_r = st[ES_KQ + l]; kv_r = st[ES_KV + l];
-    qstate_l = st[ES_QSTATE + l];
+    sm.kq2[l] = st[ES_KQ + l]; sm.kv2[l] = st[ES_KV + l];
+    sm.qst[l] = st[ES_QSTATE + l];
   }
   if (l < NU) sm.ctrl[l] = st[ES_CTRL + l];
-  double time = st[ES_TIME];
-  double act_l = 0.0;
-  if (p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[e * p.adim + c.act];
+  if (l == 0) sm.tim[0] = st[ES_TIME];
+  sm.actl[l] = (p.actions && c.act >= 0 && c.dvalid) ? p.actions[e * p.adim + c.act] : 0.0;
   lds_sync();
   bool live = valid;
   int pend = 0, niter_sum = 0;
-  double ctrl = 0.0;
+  sm.ctl[l] = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
   const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
   // One loop, one copy of the substep code: passes 0..n_sub-1 are the physics substeps; the end-of-step section computes
   // observation / reward / termination; if any environment of the wave terminated, one more pass (mj_forward only, on the
   // reset pose, for those environments) produces the reset observation.
-  double obs_a = 0.0, obs_b = 0.0, reward = 0.0;
-  int done = 0;
   bool do_reset = false, reset_pass = false;
   int sub = 0;
   while (true) {
@@ -431,19 +439,19 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     const double q_d = sm.q[dd], v_d = sm.v[dd];
     double cnew;
     if (reset_pass) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
-    else cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l;
+    else { const double act_l = sm.actl[l]; cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l; }
     substep(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so);  // reset pose: 12 active rows, cannot overflow
     if (!reset_pass) {
       if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
-      if (live) { kq_r = q_d; kv_r = v_d; ctrl = cnew; niter_sum += so.niter; time += 0.0005; }  // setState of this substep
+      if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; }  // setState of this substep
       sub++;
       if (sub < p.n_sub && __ballot(live) != 0) continue;
-      if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = ctrl;
+      if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = sm.ctl[l];
       lds_sync();
     }
     if (!p.obs) break;
     // ---- end-of-step section: operational-space state from the kinematics of the last setState (quirks Q1/Q2)
-    if (l < NV) { sm.kq[l] = kq_r; sm.kv[l] = kv_r; }
+    if (l < NV) { sm.kq[l] = sm.kq2[l]; sm.kv[l] = sm.kv2[l]; }
     lds_sync();
     opstate18(sm, c, l, fix_kin, sm.s18);
     double oa = sm.s18[l + 1 < 18 ? l + 1 : 17];      // obs[l] = s18[l+1]
@@ -452,13 +460,15 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     double ob = l == 0 ? sm.s18[17] : 0.0;            // obs[16 + l]
     lds_sync();
     if (reset_pass) {
-      if (do_reset) { obs_a = oa; obs_b = ob; }       // Cassie2dEnv.reset returns the 17 op-space values only
+      if (do_reset) { p.obs[e * 26 + l] = oa; if (l < 10) p.obs[e * 26 + 16 + l] = ob; }  // Cassie2dEnv.reset: 17 op-space values
       break;
     }
-    obs_a = oa; obs_b = ob;
+    double obs_a = oa, obs_b = ob, reward = 0.0;
+    int done = 0;
     const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
     if (p.env_kind == 0) {
       double tmax = p.traj_tmax;
+      const double time = sm.tim[0];
       int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
       const double* rq = p.traj_qpos + (size_t)idx * NV;
       if (l >= 1 && l < 10) {
@@ -467,7 +477,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
         obs_b = rq[col];
       }
       const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
-      double qv = fixq ? sm.q[l < NV ? l : 0] : qstate_l;
+      double qv = fixq ? sm.q[l < NV ? l : 0] : sm.qst[l];
       double j = row_bcast<3>(qv) + row_bcast<4>(qv) + row_bcast<6>(qv);
       j += row_bcast<8>(qv) + row_bcast<9>(qv) + row_bcast<11>(qv);
       double sum = 0.0;
@@ -492,27 +502,27 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       done = z < 0.5;
     }
     if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
+    if (live) {
+      p.obs[e * 26 + l] = obs_a;
+      if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
+      if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
+    }
     do_reset = live && done && p.auto_reset;
     if (__ballot(do_reset) == 0) break;
     // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
-    if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; qstate_l = cp_env_qinit[l]; }
-    if (do_reset) time = 0.0;
+    if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; sm.qst[l] = cp_env_qinit[l]; }
+    if (do_reset && l == 0) sm.tim[0] = 0.0;
     lds_sync();
     reset_pass = true;
-  }
-  if (p.obs && live) {
-    p.obs[e * 26 + l] = obs_a;
-    if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
-    if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
   }
   // ---- state write-back
   if (valid) {
     if (l < NV) {
       st[ES_Q + l] = sm.q[l]; st[ES_V + l] = sm.v[l]; st[ES_WS + l] = sm.ws[l];
-      st[ES_KQ + l] = kq_r; st[ES_KV + l] = kv_r; st[ES_QSTATE + l] = qstate_l;
+      st[ES_KQ + l] = sm.kq2[l]; st[ES_KV + l] = sm.kv2[l]; st[ES_QSTATE + l] = sm.qst[l];
     }
     if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
-    if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
+    if (l == 0) { st[ES_TIME] = sm.tim[0]; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
   }
 }
 
