@@ -17,7 +17,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* -DORC_CASSIE3D builds the same Part 1/2 pipeline for model/cassie3d_stiff.xml (floating base: 3 world-frame
+ * translations + unit quaternion with body-frame angular velocity, 14 hinges).  Parts 3-5
+ * (DynamicState, controllers, environments) exist for Cassie2d only, as in the reference. */
+#ifdef ORC_CASSIE3D
+#include "cassie3d_model.h"
+#define NQ CM_NQ
+#define QADR(j) (cm_jnt_qadr[j])
+#define QPOS0 cm_qpos0
+#else
 #include "cassie2d_model.h"
+#define NQ CM_NV
+#define QADR(j) (j)
+#define QPOS0 cm_jnt_ref
+#endif
 
 #define NV CM_NV
 #define NB CM_NBODY
@@ -128,7 +141,7 @@ struct Oracle {
   double dof_invweight0[NV], body_invweight0[NB], meaninertia;
   unsigned char affects[NB][NV]; /* dof k moves body b */
   /* mjData */
-  double qpos[NV], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NU];
+  double qpos[NQ], qvel[NV], qacc[NV], qacc_ws[NV], ctrl[NU];
   Kin kin;
   double M[NV * NV], L[NV * NV], bias[NV], passive[NV], actuator[NV], qfrc_smooth[NV], qacc_smooth[NV];
   int ncon;
@@ -141,7 +154,7 @@ struct Oracle {
   double AR[ORC_MAXEFC * ORC_MAXEFC];
   int solver_niter;
   /* DynamicModel state_ (last setState) and DynamicState */
-  double kin_qpos[NV], kin_qvel[NV];
+  double kin_qpos[NQ], kin_qvel[NV];
   DynState ds;
   /* last OSC QP */
   double qp_x[39], qp_kkt[4];
@@ -167,7 +180,26 @@ static void kinematics(const Oracle* o, int sem, const double* q, const double* 
     v3add(ao, k->ao[p], t); v3add(ao, ao, t2);
     for (int j = 0; j < NV; j++) {
       if (cm_jnt_body[j] != b) continue;
-      double ax[3], qd = v ? v[j] : 0.0, d = q[j] - cm_jnt_ref[j];
+      if (cm_jnt_type[j] == 2) { /* rotational half of a free joint: quaternion at q[QADR], body-frame angular velocity */
+        if (cm_jnt_axis[j][0] != 1.0) continue; /* the y and z dofs are handled together with the x dof */
+        const double* qq = q + QADR(j);
+        double n = sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+        double qw = qq[0] / n, qx = qq[1] / n, qy = qq[2] / n, qz = qq[3] / n;
+        double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                       2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx),
+                       2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)};
+        double m2[9], wl[3] = {v ? v[j] : 0.0, v ? v[j + 1] : 0.0, v ? v[j + 2] : 0.0}, ww[3];
+        m3mul(m2, mat, R); memcpy(mat, m2, sizeof m2);
+        for (int c = 0; c < 3; c++) {
+          v3set(k->axis[j + c], mat[c], mat[3 + c], mat[6 + c]);
+          v3cpy(k->anchor[j + c], pos);
+        }
+        m3mulv(ww, mat, wl);                 /* the three dofs act together: w += R omega, and the velocity-product */
+        v3cross(t, w, ww); v3add(al, al, t); /* angular acceleration is w_parent x (R omega) (mj_comVel, ball/free) */
+        v3add(w, w, ww);
+        continue;
+      }
+      double ax[3], qd = v ? v[j] : 0.0, d = q[QADR(j)] - cm_jnt_ref[j];
       m3mulv(ax, mat, cm_jnt_axis[j]);
       v3cpy(k->axis[j], ax);
       if (cm_jnt_type[j] == 0) { /* slide */
@@ -362,7 +394,7 @@ static void make_constraints(Oracle* o) {
   for (int j = 0; j < NV; j++) {
     if (!cm_jnt_limited[j]) continue;
     for (int side = 0; side < 2; side++) {
-      double dist = side == 0 ? o->qpos[j] - cm_jnt_range[j][0] : cm_jnt_range[j][1] - o->qpos[j];
+      double dist = side == 0 ? o->qpos[QADR(j)] - cm_jnt_range[j][0] : cm_jnt_range[j][1] - o->qpos[QADR(j)];
       if (dist < 0) {
         double J[NV] = {0};
         J[j] = side == 0 ? 1.0 : -1.0;
@@ -629,7 +661,22 @@ static void euler(Oracle* o) { /* mj_Euler: joint damping integrated implicitly,
     memcpy(qacc, o->qacc, sizeof qacc);
   }
   for (int j = 0; j < NV; j++) o->qvel[j] += h * qacc[j];
-  for (int j = 0; j < NV; j++) o->qpos[j] += h * o->qvel[j];
+  for (int j = 0; j < NV; j++) {
+    if (cm_jnt_type[j] != 2) { o->qpos[QADR(j)] += h * o->qvel[j]; continue; }
+    if (cm_jnt_axis[j][0] != 1.0) continue;
+    /* mju_quatIntegrate: quat <- normalize(quat) * axisangle(omega_body, h |omega|) */
+    double* qq = o->qpos + QADR(j);
+    double wx = o->qvel[j], wy = o->qvel[j + 1], wz = o->qvel[j + 2], wn = sqrt(wx * wx + wy * wy + wz * wz);
+    double ax[3] = {1, 0, 0}, ang = 0;
+    if (wn >= MINVAL) { ax[0] = wx / wn; ax[1] = wy / wn; ax[2] = wz / wn; ang = h * wn; }
+    double sh = sin(0.5 * ang), r[4] = {cos(0.5 * ang), ax[0] * sh, ax[1] * sh, ax[2] * sh};
+    double n = sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    double a[4] = {qq[0] / n, qq[1] / n, qq[2] / n, qq[3] / n};
+    qq[0] = a[0] * r[0] - a[1] * r[1] - a[2] * r[2] - a[3] * r[3];
+    qq[1] = a[0] * r[1] + a[1] * r[0] + a[2] * r[3] - a[3] * r[2];
+    qq[2] = a[0] * r[2] - a[1] * r[3] + a[2] * r[0] + a[3] * r[1];
+    qq[3] = a[0] * r[3] + a[1] * r[2] - a[2] * r[1] + a[3] * r[0];
+  }
 }
 
 static void mj_step(Oracle* o) { orc_forward(o); euler(o); }
@@ -640,6 +687,7 @@ static void set_state(Oracle* o) { /* DynamicModel::setState (DynamicModel.cpp:2
   memcpy(o->kin_qvel, o->qvel, sizeof o->qvel);
 }
 
+#ifndef ORC_CASSIE3D
 static const int contact_site_ids[4] = {2, 3, 4, 5}; /* Cassie2d.cpp:34 */
 static const int target_site_ids[5] = {1, 2, 3, 4, 5}; /* Cassie2d.cpp:35-36 */
 
@@ -669,12 +717,15 @@ static void update_dynamic_state(Oracle* o, Kin* k) { /* DynamicState::UpdateDyn
   }
 }
 
+#endif /* !ORC_CASSIE3D */
+
 void orc_step_torque(Oracle* o, const double* torques) {
   set_state(o); /* UpdateDynamicState result is unused in this mode */
   memcpy(o->ctrl, torques, sizeof o->ctrl);
   mj_step(o);
 }
 
+#ifndef ORC_CASSIE3D
 void orc_step_pd(Oracle* o, const double* angles) {
   static const int joints[NU] = {3, 4, 6, 8, 9, 11};
   set_state(o);
@@ -684,12 +735,14 @@ void orc_step_pd(Oracle* o, const double* angles) {
 }
 
 #include "cassie_oracle_ctrl.inc"
+#endif /* !ORC_CASSIE3D */
 
 void orc_get_state(const Oracle* o, double* qpos, double* qvel) {
   memcpy(qpos, o->qpos, sizeof o->qpos);
   memcpy(qvel, o->qvel, sizeof o->qvel);
 }
 
+#ifndef ORC_CASSIE3D
 void orc_get_opstate(const Oracle* o, int flags, double* s) {
   /* GetOperationalSpaceState (Cassie2d.cpp:218-237): kinematics of the LAST setState (quirk Q1/Q2),
    * pitch and pitch rate from the current mj_data (Q1), element [2] of the foot vectors never written (Q4). */
@@ -716,6 +769,8 @@ void orc_get_opstate(const Oracle* o, int flags, double* s) {
   s[5] = o->qvel[2];
 }
 
+#endif /* !ORC_CASSIE3D */
+
 /* ------------------------------------------------------------------ lifecycle */
 static void derive_constants(Oracle* o) {
   /* what MuJoCo's compiler (set0) and DynamicModel::LoadModel derive at load time */
@@ -727,7 +782,7 @@ static void derive_constants(Oracle* o) {
     }
   for (int sem = 0; sem < 2; sem++) {
     Kin k;
-    kinematics(o, sem, cm_jnt_ref, NULL, &k);
+    kinematics(o, sem, QPOS0, NULL, &k);
     for (int e = 0; e < NEQ; e++) {
       double r[3], pw[3];
       m3mulv(r, k.xmat[cm_eq_body1[e]], cm_eq_anchor1[e]);
@@ -746,6 +801,12 @@ static void derive_constants(Oracle* o) {
         chol_solve(NV, L0, e, col);
         o->dof_invweight0[j] = col[j];
       }
+      for (int j = 0; j + 2 < NV; j++) /* free joint: translational and rotational triples are averaged (mj_setConst) */
+        if (cm_jnt_type[j] == 2 && cm_jnt_axis[j][0] == 1.0) {
+          double tr3 = (o->dof_invweight0[j - 3] + o->dof_invweight0[j - 2] + o->dof_invweight0[j - 1]) / 3.0;
+          double ro3 = (o->dof_invweight0[j] + o->dof_invweight0[j + 1] + o->dof_invweight0[j + 2]) / 3.0;
+          for (int c = 0; c < 3; c++) { o->dof_invweight0[j - 3 + c] = tr3; o->dof_invweight0[j + c] = ro3; }
+        }
       o->body_invweight0[0] = 0;
       for (int b = 1; b < NB; b++) {
         double Jv[3 * NV], x[NV], s = 0;
@@ -760,8 +821,12 @@ static void derive_constants(Oracle* o) {
   }
 }
 
+#ifdef ORC_CASSIE3D
+#define qpos_init cm_qpos_init /* standing pose: the sagittal angles of Cassie2d.cpp:56-58 on an upright floating base */
+#else
 static const double qpos_init[NV] = {0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407,
                                      0.68111815, -1.40730353, 1.62972043, -1.77611107, -0.61968402}; /* Cassie2d.cpp:56-58 */
+#endif
 
 Oracle* orc_create(void) {
   Oracle* o = (Oracle*)calloc(1, sizeof *o);
@@ -830,6 +895,7 @@ void orc_get_model_consts(const Oracle* o, int sem, double* a2, double* dw, doub
   if (bw) memcpy(bw, o->body_invweight0, sizeof o->body_invweight0);
   if (mi) *mi = o->meaninertia;
 }
+#ifndef ORC_CASSIE3D
 void orc_get_dynamic_state(Oracle* o, double* M, double* bias, double* Bt, double* Jc, double* Jeq, double* Jd) {
   Kin k; update_dynamic_state(o, &k);
   if (M) memcpy(M, o->ds.M, sizeof o->ds.M);
@@ -845,3 +911,6 @@ void orc_get_osc_qp(const Oracle* o, double* x39, double* kkt4) {
 }
 
 #include "cassie_oracle_env.inc"
+#else
+int orc_dims(int* nq, int* nv, int* nu) { *nq = NQ; *nv = NV; *nu = NU; return NB; }
+#endif /* !ORC_CASSIE3D */

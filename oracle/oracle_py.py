@@ -223,3 +223,121 @@ def envs_step(envs, actions, n_sub=10, auto_reset=True, nthreads=0):
     L.orc_envs_step(arr, ct.c_int(n), _p(actions), ct.c_int(actions.shape[1]), ct.c_int(n_sub), ct.c_int(int(auto_reset)),
                     _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)), ct.c_int(nthreads))
     return obs, rew, done
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cassie3d (oracle/liboracle3d.so = the same Part 1/2 pipeline compiled with -DORC_CASSIE3D)
+NQ3, NV3, NU3 = 21, 20, 10
+_LIB3 = None
+
+
+def build3d(force=False):
+    so = os.path.join(HERE, "liboracle3d.so")
+    srcs = [os.path.join(HERE, f) for f in ("cassie_oracle.c", "cassie_oracle.h", "cassie3d_model.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle3d.so"])
+    return so
+
+
+def lib3d():
+    global _LIB3
+    if _LIB3 is None:
+        L = ct.CDLL(build3d())
+        L.orc_create.restype = ct.c_void_p
+        L.orc_energy.restype = ct.c_double
+        _LIB3 = L
+    return _LIB3
+
+
+class Oracle3D:
+    """One Cassie3d mechanism: mj_forward / mj_step of model/cassie3d_stiff.xml in torque mode."""
+
+    def __init__(self):
+        self.L = lib3d()
+        self.h = ct.c_void_p(self.L.orc_create())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_free(self.h)
+            self.h = None
+
+    def reset(self, qpos, qvel):
+        self.L.orc_reset(self.h, _p(_vec(qpos, NQ3)), _p(_vec(qvel, NV3)))
+
+    def step_torque(self, u):
+        self.L.orc_step_torque(self.h, _p(_vec(u, NU3)))
+
+    def forward(self):
+        self.L.orc_forward(self.h)
+
+    def state(self):
+        q, v = np.zeros(NQ3), np.zeros(NV3)
+        self.L.orc_get_state(self.h, _p(q), _p(v))
+        return q, v
+
+    def set_state_raw(self, qpos, qvel, ws=None):
+        w = _vec(ws, NV3) if ws is not None else None
+        self.L.orc_set_state_raw(self.h, _p(_vec(qpos, NQ3)), _p(_vec(qvel, NV3)), _p(w) if w is not None else None)
+
+    def set_gravity(self, gz):
+        self.L.orc_set_gravity(self.h, ct.c_double(gz))
+
+    def set_damping_scale(self, s):
+        self.L.orc_set_damping_scale(self.h, ct.c_double(s))
+
+    def set_contact_enabled(self, e):
+        self.L.orc_set_contact_enabled(self.h, ct.c_int(int(e)))
+
+    @property
+    def nefc(self):
+        return self.L.orc_nefc(self.h)
+
+    @property
+    def ncon(self):
+        return self.L.orc_ncon(self.h)
+
+    @property
+    def solver_niter(self):
+        return self.L.orc_solver_niter(self.h)
+
+    def mass_matrix(self, qpos):
+        M = np.zeros((NV3, NV3))
+        self.L.orc_get_mass_matrix(self.h, ct.c_int(0), _p(_vec(qpos, NQ3)), _p(M))
+        return M
+
+    def bias(self, qpos, qvel):
+        b = np.zeros(NV3)
+        self.L.orc_get_bias(self.h, ct.c_int(0), _p(_vec(qpos, NQ3)), _p(_vec(qvel, NV3)), _p(b))
+        return b
+
+    def qacc(self):
+        a = np.zeros(NV3)
+        self.L.orc_get_qacc(self.h, _p(a))
+        return a
+
+    def warmstart(self):
+        a = np.zeros(NV3)
+        self.L.orc_get_warmstart(self.h, _p(a))
+        return a
+
+    def efc(self):
+        n = self.nefc
+        J, f, pos, aref = np.zeros((n, NV3)), np.zeros(n), np.zeros(n), np.zeros(n)
+        typ = np.zeros(n, dtype=np.int32)
+        self.L.orc_get_efc(self.h, _p(J), _p(f), _p(pos), _p(aref), typ.ctypes.data_as(ct.POINTER(ct.c_int)))
+        return J, f, pos, aref, typ
+
+    def energy(self):
+        ke, pe = ct.c_double(), ct.c_double()
+        e = self.L.orc_energy(self.h, ct.byref(ke), ct.byref(pe))
+        return e, ke.value, pe.value
+
+    def site_pos(self, qpos, site):
+        p = np.zeros(3)
+        self.L.orc_site_pos(self.h, ct.c_int(0), _p(_vec(qpos, NQ3)), ct.c_int(site), _p(p))
+        return p
+
+    def model_consts(self):
+        a2, dw, bw, mi = np.zeros((2, 3)), np.zeros(NV3), np.zeros(22), ct.c_double()
+        self.L.orc_get_model_consts(self.h, ct.c_int(0), _p(a2), _p(dw), _p(bw), ct.byref(mi))
+        return a2, dw, bw, mi.value

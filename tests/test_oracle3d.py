@@ -1,0 +1,169 @@
+"""Cassie3d oracle (oracle/liboracle3d.so) against the numpy evaluation of the same MJCF (tests/golden/model3d_kat.json,
+made by cassierl_amd/model/compile_model3d.py) and against physics invariants.  CPU only.
+
+There is no reference implementation of a Cassie3d step (the reference ships only the MJCF), so -- like the 2-D oracle --
+this one is 'parity unpinned'; what pins it is the model file itself and mechanics."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(ROOT, "tests", "golden", "model3d_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture()
+def o3():
+    import oracle_py
+    return oracle_py.Oracle3D()
+
+
+def quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def integrate_pos(q, v, h):
+    """q (+) h v on the configuration manifold (world translation, body-frame rotation, hinges)"""
+    q2 = q.copy()
+    q2[:3] += h * v[:3]
+    w = v[3:6]
+    n = np.linalg.norm(w)
+    if n > 0:
+        r = np.concatenate([[np.cos(0.5 * h * n)], np.sin(0.5 * h * n) * w / n])
+        q2[3:7] = quat_mul(q[3:7], r)
+    q2[7:] += h * v[6:]
+    return q2
+
+
+def test_model_constants_match_numpy_tree(o3, kat):
+    a2, dw, bw, mi = o3.model_consts()
+    assert kat["nq"] == 21 and kat["nv"] == 20
+    np.testing.assert_allclose(mi, kat["meaninertia"], rtol=1e-12)
+    np.testing.assert_allclose(dw, kat["dof_invweight0"], rtol=1e-9)
+    np.testing.assert_allclose(bw, kat["body_invweight0"], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(a2, kat["eq_anchor2"], atol=1e-12)
+    assert abs(kat["total_mass"] - 32.822) < 1e-9   # sum of the <inertial mass=...> entries of cassie3d_stiff.xml
+    # the free joint's translational and rotational triples share one inverse weight each (mj_setConst)
+    assert np.ptp(dw[:3]) == 0 and np.ptp(dw[3:6]) == 0
+
+
+def test_mass_matrix_and_sites_match_numpy_tree(o3, kat):
+    for s in kat["samples"]:
+        q = np.array(s["qpos"])
+        M = o3.mass_matrix(q)
+        np.testing.assert_allclose(M, np.array(s["M"]), rtol=0, atol=1e-11)
+        assert np.allclose(M, M.T) and np.linalg.eigvalsh(M).min() > 0
+        for i, name in enumerate(["imu", "body_center", "left_contact_front", "left_contact_rear", "right_contact_front", "right_contact_rear"]):
+            np.testing.assert_allclose(o3.site_pos(q, i), s["site_world"][name], atol=1e-12)
+    # floating base: the translational block is total mass * I whatever the pose
+    M = o3.mass_matrix(np.array(kat["samples"][2]["qpos"]))
+    np.testing.assert_allclose(M[:3, :3], kat["total_mass"] * np.eye(3), atol=1e-10)
+
+
+def test_bias_is_the_lagrangian_one(o3, kat):
+    """bias = C(q,v) + g(q): check  d/dt (M v) - dT/dq - (-dV/dq)  numerically on the manifold (no constraints, no damping)."""
+    rng = np.random.default_rng(1)
+    q = np.array(kat["samples"][1]["qpos"])
+    v = rng.uniform(-1, 1, 20)
+    eps = 1e-6
+
+    def T(q, v):
+        return 0.5 * v @ o3.mass_matrix(q) @ v
+
+    def V(q):
+        o3.set_state_raw(q, np.zeros(20))
+        return o3.energy()[2]
+
+    # dM/dt v along the motion, and the generalised gradient of L = T - V with respect to a configuration perturbation e_k
+    Mdot_v = (o3.mass_matrix(integrate_pos(q, v, eps)) - o3.mass_matrix(integrate_pos(q, v, -eps))) @ v / (2 * eps)
+    dL = np.zeros(20)
+    for k in range(20):
+        e = np.zeros(20); e[k] = 1.0
+        qp, qm = integrate_pos(q, e, eps), integrate_pos(q, e, -eps)
+        dL[k] = ((T(qp, v) - V(qp)) - (T(qm, v) - V(qm))) / (2 * eps)
+    bias = o3.bias(q, v)
+    # hinge and translation coordinates are holonomic: Euler-Lagrange holds component-wise; the body-frame angular velocity is a
+    # quasi-velocity, whose equation carries the extra  omega x (dT/d omega)  term (Euler-Poincare)
+    expect = Mdot_v - dL
+    p = o3.mass_matrix(q) @ v
+    expect[3:6] += np.cross(v[3:6], p[3:6])
+    np.testing.assert_allclose(bias, expect, rtol=0, atol=2e-5)
+
+
+def test_free_flight_conserves_momentum_and_energy(o3, kat):
+    o3.set_contact_enabled(False); o3.set_damping_scale(0.0); o3.set_gravity(0.0)
+    rng = np.random.default_rng(2)
+    q = np.array(kat["qpos_init"]); q[2] = 3.0
+    v = rng.uniform(-1, 1, 20)
+    o3.reset(q, v)
+    # closed loops stay closed only through the connect constraints: start from a consistent velocity by letting them act
+    for _ in range(20):
+        o3.step_torque(np.zeros(10))
+    q0, v0 = o3.state()
+    M0 = o3.mass_matrix(q0)
+    p_lin0 = (M0 @ v0)[:3]
+    e0 = o3.energy()[0]
+    for _ in range(400):
+        o3.step_torque(np.zeros(10))
+    q1, v1 = o3.state()
+    p_lin1 = (o3.mass_matrix(q1) @ v1)[:3]
+    np.testing.assert_allclose(p_lin1, p_lin0, atol=2e-3)   # O(h) integrator + soft constraints
+    assert abs(o3.energy()[0] - e0) < 0.02 * abs(e0) + 1e-3
+    assert abs(np.linalg.norm(q1[3:7]) - 1.0) < 1e-12
+
+
+def test_free_fall_acceleration(o3, kat):
+    o3.set_contact_enabled(False)
+    q = np.array(kat["qpos_init"]); q[2] = 3.0
+    o3.reset(q, np.zeros(20))
+    a = o3.qacc()
+    # at rest the rate of change of linear momentum is (M qacc)[:3] = total external force = m g (internal joint motion and the
+    # loop-closure forces cancel); the sagittal-symmetric pose has no lateral acceleration
+    F = (o3.mass_matrix(q) @ a)[:3]
+    np.testing.assert_allclose(F, [0.0, 0.0, -9.806 * kat["total_mass"]], atol=1e-8)
+    assert abs(a[1]) < 1e-4   # the XML is mirror-symmetric only to ~1e-4 (e.g. inertial pos y = +-0.0001)
+
+
+def test_standing_pose_contacts_and_symmetry(o3, kat):
+    q = np.array(kat["qpos_init"])
+    o3.reset(q, np.zeros(20))
+    assert o3.ncon == 4 and o3.nefc == 6 + 3 * 4   # both toe capsules on the floor with both ends
+    J, f, pos, aref, typ = o3.efc()
+    assert (typ[:6] == 0).all() and (typ[6:] == 2).all()
+    assert (f[6::3] >= 0).all()                      # normal forces push
+    assert o3.solver_niter == 50
+    a = o3.qacc()
+    # left/right mirror symmetry of the model and the pose: mirrored dofs accelerate the same (abduction/yaw axes are mirrored in the XML)
+    np.testing.assert_allclose(a[8:13], a[15:20], atol=5e-3 * (1 + np.abs(a[8:13]).max()))
+    assert abs(a[1]) < 5e-3 * (1 + np.abs(a).max())
+    for _ in range(200):
+        o3.step_torque(np.zeros(10))
+    q1, _ = o3.state()
+    assert abs(np.linalg.norm(q1[3:7]) - 1.0) < 1e-12 and np.isfinite(q1).all()
+    assert abs(q1[1]) < 1e-3                        # does not drift sideways in 0.1 s
+
+
+def test_quaternion_integration_matches_rotation(o3):
+    """Spin the floating base about a body axis in free flight: after t the orientation is the axis-angle rotation |w| t."""
+    o3.set_contact_enabled(False); o3.set_gravity(0.0); o3.set_damping_scale(0.0)
+    import oracle_py
+    q = np.zeros(21); q[3] = 1.0; q[2] = 5.0
+    q[7:] = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "model3d_kat.json")))["qpos_init"])[7:]
+    # lock the shape by spinning about the principal-ish z axis slowly: check only the kinematic relation qdot = 1/2 q * w
+    v = np.zeros(20); v[5] = 0.7
+    o3.reset(q, v)
+    o3.step_torque(np.zeros(10))
+    q1, v1 = o3.state()
+    w = v1[3:6]
+    ang = 0.0005 * np.linalg.norm(w)
+    expect = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * w / np.linalg.norm(w)])
+    np.testing.assert_allclose(q1[3:7], expect, atol=1e-14)
