@@ -23,6 +23,10 @@ EXPORTS = [
     "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
+    # batched Cassie3d physics (include/cassie3d_vec.h)
+    "Cassie3dVecCreate", "Cassie3dVecFree", "Cassie3dVecLastError", "Cassie3dVecSetStream", "Cassie3dVecSynchronize",
+    "Cassie3dVecReset", "Cassie3dVecStep", "Cassie3dVecStatePtr", "Cassie3dVecStepHost", "Cassie3dVecGetStateHost",
+    "Cassie3dVecSetStateHost", "Cassie3dVecDebugForwardHost", "Cassie3dVecTimeSteps",
 ]
 
 
@@ -74,6 +78,22 @@ def load():
     L.CassieVecGetFullStateHost.argtypes = [vp, dp]
     L.CassieVecDebugSubstepHost.argtypes = [vp, ct.c_int, dp, dp]
     L.CassieVecTimeSteps.argtypes = [vp, dp, ct.c_int, dp, dp, u8p, ct.POINTER(ct.c_float)]
+    L.Cassie3dVecCreate.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, ct.c_int]
+    L.Cassie3dVecFree.argtypes = [vp]
+    L.Cassie3dVecFree.restype = None
+    L.Cassie3dVecLastError.argtypes = [vp]
+    L.Cassie3dVecLastError.restype = ct.c_char_p
+    L.Cassie3dVecSetStream.argtypes = [vp, vp]
+    L.Cassie3dVecSynchronize.argtypes = [vp]
+    L.Cassie3dVecReset.argtypes = [vp, dp, dp]
+    L.Cassie3dVecStep.argtypes = [vp, dp, ct.c_int]
+    L.Cassie3dVecStatePtr.argtypes = [vp]
+    L.Cassie3dVecStatePtr.restype = ct.c_void_p
+    L.Cassie3dVecStepHost.argtypes = [vp, dp, ct.c_int]
+    L.Cassie3dVecGetStateHost.argtypes = [vp, dp]
+    L.Cassie3dVecSetStateHost.argtypes = [vp, dp]
+    L.Cassie3dVecDebugForwardHost.argtypes = [vp, dp, dp]
+    L.Cassie3dVecTimeSteps.argtypes = [vp, dp, ct.c_int, ct.c_int, ct.POINTER(ct.c_float)]
     L.Cassie2dInit.restype = ct.c_void_p
     _LIB = L
     return L

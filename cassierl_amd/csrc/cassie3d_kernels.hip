@@ -1,0 +1,647 @@
+// cassie3d_kernels.hip -- batched Cassie3d physics (model/cassie3d_stiff.xml) on MI355X: BASELINE.json configs[4],
+// SURVEY.md section 8 row N3.  Included by cassie_cabi.hip after cassie_kernels.hip (shares its small helpers).
+//
+// The reference has no Cassie3d class (only the MJCF and vestigial hooks: xml_parser.h:321-323, RobotInterface.h:54,
+// DynamicModel.cpp:250-265); what runs here is the same MuJoCo step the 2-D path restates -- mj_forward (kinematics, CRB mass
+// matrix, RNE bias, plane-sphere/capsule collision, connect / joint-limit / elliptic-contact rows, PGS with warm start) and the
+// implicit-damping Euler step (options of cassie3d_stiff.xml:5) -- for a floating base (3 world translations + unit
+// quaternion, body-frame angular velocity) and 14 hinges: nq 21, nv 20, nu 10.  Checked against oracle/liboracle3d.so.
+//
+// One wavefront per environment, one wavefront per workgroup, everything between the state load and the state store in LDS
+// and VGPRs.  Lane roles change by phase:
+//   link lanes 0..14   kinematics level by level down the tree, then per-link inertial force/torque
+//   dof  lanes 0..19   row of M (composite-inertia form), bias, Gauss-Jordan inverses of M and M + h B (v_readlane broadcasts)
+//   row  lanes 0..63   ACTIVE constraint rows compacted in MuJoCo order (6 connect rows, active limits, 3 rows per active
+//                      contact); lane i owns force / residual i and fills column i of A = J M^-1 J' + R in LDS
+// PGS walks the rows with a wave-uniform loop: the owner's (f, residual) come by v_readlane, the update is computed
+// redundantly on every lane, and each lane applies A[i][K] * delta to its own residual.  More than 64 active rows (possible
+// only with >= 13 simultaneous contacts plus joint limits) is not handled: the environment is frozen and flagged (E3_OVF).
+#ifndef CASSIE3D_KERNELS_HIP_
+#define CASSIE3D_KERNELS_HIP_
+
+#include "cassie3d_tables.h"
+
+namespace cassie3d {
+
+using cassie::lds_sync;
+using cassie::rdlane;
+using cassie::static_for;
+using cassie::wave_sum;
+
+constexpr int MAXR = 64;
+constexpr double MINVAL = 1e-15;
+// HBM record of one environment (doubles)
+constexpr int ENV3_STRIDE = 80;
+enum { E3_Q = 0, E3_V = 21, E3_WS = 41, E3_CTRL = 61, E3_TIME = 71, E3_NITER = 72, E3_NEFC = 73, E3_OVF = 74 };
+enum { K_NONE = 0, K_EQ = 1, K_LIM = 2, K_CN = 3, K_CT = 4 };
+// debug record (tests only)
+enum { D3_M = 0, D3_BIAS = 400, D3_QS = 420, D3_NEFC = 440, D3_QACC = 441, D3_F = 461, D3_AREF = 525, D3_J = 589, D3_STRIDE = 589 + 64 * 20 };
+
+struct Params3 {
+  double* state;          // [n][ENV3_STRIDE]
+  const double* actions;  // [n][10] motor commands (pre-clamp), device
+  double* debug;          // [n][D3_STRIDE] or null
+  int n_envs, n_sub;
+};
+
+struct Smem3 {
+  double q[24], v[NV], ws[NV], tau[NV], qs[NV], gtot[NV];
+  double xpos[NL][3], xmat[NL][9];
+  double anchor[NV][3], axis[NV][3];
+  double minv[NV][NV];
+  double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
+  double rowJ[MAXR][NV];  // constraint Jacobian rows
+  union {
+    struct {  // kinematics by-products, dead once M and bias exist
+      double w[NL][3], vo[NL][3], al[NL][3], ao[NL][3];
+      double com[NL][3], F[NL][3], N[NL][3], Iw[NL][6];
+      double comp[NV][10];
+    };
+    double A[MAXR][MAXR];  // A[c][i] read by lane i (A is symmetric)
+  };
+};
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* r) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void matvec3(const double* m, const double* v, double* r) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void matmul3(const double* a, const double* b, double* r) {
+  double t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) r[i] = t[i];
+}
+__device__ __forceinline__ double impedance3(const double* si, double pos) {
+  if (si[0] == si[1] || si[2] <= MINVAL) return 0.5 * (si[0] + si[1]);
+  double x = fabs(pos / si[2]);
+  if (x >= 1) return si[1];
+  if (x <= 0) return si[0];
+  double y = x <= 0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
+  return si[0] + y * (si[1] - si[0]);
+}
+__device__ __forceinline__ int nth_set(unsigned mask, int n) {
+  int found = -1, cnt = 0;
+  for (int i = 0; i < 20; i++)
+    if ((mask >> i) & 1u) { if (cnt == n) found = i; cnt++; }
+  return found;
+}
+__device__ __forceinline__ double rdlane_dyn(double x, int l) {  // l wave-uniform, not a compile-time constant
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
+// In-register Gauss-Jordan inverse of the SPD matrix whose row d lives on lane d < NV (other lanes: zero rows).
+__device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
+  static_for<0, NV>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    double piv = rdlane(Mr[K], K);
+    double inv = 1.0 / piv;
+    bool isk = lane == K;
+    double t = isk ? 1.0 - inv : Mr[K] * inv;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      if constexpr (C != K) {
+        double pk = rdlane(Mr[C], K);
+        Mr[C] = __builtin_fma(-t, pk, Mr[C]);
+      }
+    });
+    Mr[K] = isk ? inv : -t;
+  });
+}
+
+// mju_QCQP2 (values are wave-uniform, so is the control flow)
+__device__ __forceinline__ bool qcqp2(double* res, double A11, double A12, double A22, double b1, double b2, double d, double r) {
+  b1 *= d; b2 *= d; A11 *= d * d; A22 *= d * d; A12 *= d * d;
+  double la = 0, v1 = 0, v2 = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    double det = (A11 + la) * (A22 + la) - A12 * A12;
+    if (det < 1e-10) { res[0] = 0; res[1] = 0; return false; }
+    double detinv = 1 / det, P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+    double val = v1 * v1 + v2 * v2 - r * r;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d; res[1] = v2 * d;
+  return la != 0;
+}
+
+struct Out3 { int niter, nefc; bool overflow; };
+
+// ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
+template <bool INTEGRATE>
+__device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, Out3& out, double* dbg) {
+  // ================= kinematics: links 0..14 on lanes 0..14, one tree level at a time
+  const int lk = lane < NL ? lane : 0;
+  const int depth = lane < NL ? c3_link_depth[lk] : 99, par = c3_link_parent[lk];
+  // the hinge of link lk >= 1 is dof lk + 5 (links and hinges are numbered in the same depth-first order)
+  for (int lvl = 0; lvl < 7; lvl++) {
+    if (depth == lvl) {
+      double pos[3], mat[9], w[3], vo[3], al[3], ao[3];
+      if (lk == 0) {
+        double qw = sm.q[3], qx = sm.q[4], qy = sm.q[5], qz = sm.q[6];
+        double n = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw /= n; qx /= n; qy /= n; qz /= n;
+        mat[0] = 1 - 2 * (qy * qy + qz * qz); mat[1] = 2 * (qx * qy - qw * qz); mat[2] = 2 * (qx * qz + qw * qy);
+        mat[3] = 2 * (qx * qy + qw * qz); mat[4] = 1 - 2 * (qx * qx + qz * qz); mat[5] = 2 * (qy * qz - qw * qx);
+        mat[6] = 2 * (qx * qz - qw * qy); mat[7] = 2 * (qy * qz + qw * qx); mat[8] = 1 - 2 * (qx * qx + qy * qy);
+        pos[0] = sm.q[0]; pos[1] = sm.q[1]; pos[2] = sm.q[2];
+        double wl[3] = {sm.v[3], sm.v[4], sm.v[5]};
+        matvec3(mat, wl, w);
+        vo[0] = sm.v[0]; vo[1] = sm.v[1]; vo[2] = sm.v[2];
+        al[0] = al[1] = al[2] = 0.0; ao[0] = ao[1] = ao[2] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          sm.anchor[k][0] = pos[0]; sm.anchor[k][1] = pos[1]; sm.anchor[k][2] = pos[2];  // (unused for slides)
+          sm.axis[k][0] = k == 0; sm.axis[k][1] = k == 1; sm.axis[k][2] = k == 2;
+          sm.anchor[3 + k][0] = pos[0]; sm.anchor[3 + k][1] = pos[1]; sm.anchor[3 + k][2] = pos[2];
+          sm.axis[3 + k][0] = mat[k]; sm.axis[3 + k][1] = mat[3 + k]; sm.axis[3 + k][2] = mat[6 + k];
+        }
+      } else {
+        const int dof = lk + 5;
+        const double* pm = sm.xmat[par];
+        double r[3], m0[9];
+        matvec3(pm, c3_link_pos[lk], r);
+        pos[0] = sm.xpos[par][0] + r[0]; pos[1] = sm.xpos[par][1] + r[1]; pos[2] = sm.xpos[par][2] + r[2];
+        matmul3(pm, &c3_link_rot[lk][0][0], m0);
+        double ax[3];
+        matvec3(m0, c3_dof_axis[dof], ax);
+        // Rodrigues rotation about the world axis, applied on the left (mj_kinematics)
+        double ang = sm.q[c3_dof_qadr[dof]] - c3_dof_ref[dof], s = sin(ang), c = cos(ang), t1 = 1 - c;
+        double R[9] = {c + ax[0] * ax[0] * t1, ax[0] * ax[1] * t1 - ax[2] * s, ax[0] * ax[2] * t1 + ax[1] * s,
+                       ax[1] * ax[0] * t1 + ax[2] * s, c + ax[1] * ax[1] * t1, ax[1] * ax[2] * t1 - ax[0] * s,
+                       ax[2] * ax[0] * t1 - ax[1] * s, ax[2] * ax[1] * t1 + ax[0] * s, c + ax[2] * ax[2] * t1};
+        matmul3(R, m0, mat);
+        const double qd = sm.v[dof];
+        double wp[3] = {sm.w[par][0], sm.w[par][1], sm.w[par][2]}, alp[3] = {sm.al[par][0], sm.al[par][1], sm.al[par][2]};
+        double t[3], t2[3], axqd[3] = {ax[0] * qd, ax[1] * qd, ax[2] * qd};
+        cross3(wp, r, t);
+        vo[0] = sm.vo[par][0] + t[0]; vo[1] = sm.vo[par][1] + t[1]; vo[2] = sm.vo[par][2] + t[2];
+        cross3(wp, t, t2); cross3(alp, r, t);
+        ao[0] = sm.ao[par][0] + t[0] + t2[0]; ao[1] = sm.ao[par][1] + t[1] + t2[1]; ao[2] = sm.ao[par][2] + t[2] + t2[2];
+        cross3(wp, axqd, t);
+        al[0] = alp[0] + t[0]; al[1] = alp[1] + t[1]; al[2] = alp[2] + t[2];
+        w[0] = wp[0] + axqd[0]; w[1] = wp[1] + axqd[1]; w[2] = wp[2] + axqd[2];
+        sm.anchor[dof][0] = pos[0]; sm.anchor[dof][1] = pos[1]; sm.anchor[dof][2] = pos[2];
+        sm.axis[dof][0] = ax[0]; sm.axis[dof][1] = ax[1]; sm.axis[dof][2] = ax[2];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) { sm.xpos[lk][i] = pos[i]; sm.w[lk][i] = w[i]; sm.vo[lk][i] = vo[i]; sm.al[lk][i] = al[i]; sm.ao[lk][i] = ao[i]; }
+#pragma unroll
+      for (int i = 0; i < 9; i++) sm.xmat[lk][i] = mat[i];
+      // inertial quantities of this link in world axes, positions relative to the pelvis origin
+      double rc[3], c0[3], Iw[9], tmp[9], Rt[9];
+      matvec3(mat, c3_link_ipos[lk], rc);
+      const double m = c3_link_mass[lk];
+#pragma unroll
+      for (int i = 0; i < 3; i++) c0[i] = pos[i] + rc[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rt[3 * i + j] = mat[3 * j + i];
+      matmul3(mat, &c3_link_inertia[lk][0][0], tmp);
+      matmul3(tmp, Rt, Iw);
+      double t[3], t2[3], ac[3];
+      cross3(w, rc, t); cross3(w, t, t2); cross3(al, rc, t);
+      ac[0] = ao[0] + t[0] + t2[0]; ac[1] = ao[1] + t[1] + t2[1]; ac[2] = ao[2] + t[2] + t2[2] - GRAVITY_Z;
+      double Iwv[3], Nn[3];
+      matvec3(Iw, al, Nn); matvec3(Iw, w, Iwv); cross3(w, Iwv, t);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { sm.com[lk][i] = c0[i]; sm.F[lk][i] = m * ac[i]; sm.N[lk][i] = Nn[i] + t[i]; }
+      sm.Iw[lk][0] = Iw[0]; sm.Iw[lk][1] = Iw[4]; sm.Iw[lk][2] = Iw[8]; sm.Iw[lk][3] = Iw[1]; sm.Iw[lk][4] = Iw[2]; sm.Iw[lk][5] = Iw[5];
+    }
+    lds_sync();
+  }
+  // ================= dof lanes: composite of the moved subtree, bias, row of M
+  const int d = lane < NV ? lane : 0;
+  const bool dvalid = lane < NV;
+  const int dtype = c3_dof_type[d], dlink = c3_dof_link[d], dsub = c3_dof_submask[d];
+  const double O[3] = {sm.xpos[0][0], sm.xpos[0][1], sm.xpos[0][2]};
+  double om[3], vv[3];  // spatial velocity of this dof about the pelvis origin
+  {
+    const double ax[3] = {sm.axis[d][0], sm.axis[d][1], sm.axis[d][2]};
+    if (dtype == 0) { om[0] = om[1] = om[2] = 0.0; vv[0] = ax[0]; vv[1] = ax[1]; vv[2] = ax[2]; }
+    else {
+      double pr[3] = {sm.anchor[d][0] - O[0], sm.anchor[d][1] - O[1], sm.anchor[d][2] - O[2]};
+      om[0] = ax[0]; om[1] = ax[1]; om[2] = ax[2];
+      cross3(pr, ax, vv);
+    }
+  }
+  double cm = 0, ch[3] = {0, 0, 0}, cJ[6] = {0, 0, 0, 0, 0, 0};  // composite: mass, first moment, inertia (xx yy zz xy xz yz) about O
+  double bias = 0.0;
+  {
+    double Fs[3] = {0, 0, 0}, Ts[3] = {0, 0, 0};  // resultant force and moment about this dof's anchor
+    const double p[3] = {sm.anchor[d][0], sm.anchor[d][1], sm.anchor[d][2]};
+    for (int l = 0; l < NL; l++) {
+      if (!((dsub >> l) & 1)) continue;
+      const double m = c3_link_mass[l];
+      const double c0[3] = {sm.com[l][0], sm.com[l][1], sm.com[l][2]};
+      const double r[3] = {c0[0] - O[0], c0[1] - O[1], c0[2] - O[2]};
+      const double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      cm += m; ch[0] += m * r[0]; ch[1] += m * r[1]; ch[2] += m * r[2];
+      cJ[0] += sm.Iw[l][0] + m * (r2 - r[0] * r[0]); cJ[1] += sm.Iw[l][1] + m * (r2 - r[1] * r[1]); cJ[2] += sm.Iw[l][2] + m * (r2 - r[2] * r[2]);
+      cJ[3] += sm.Iw[l][3] - m * r[0] * r[1]; cJ[4] += sm.Iw[l][4] - m * r[0] * r[2]; cJ[5] += sm.Iw[l][5] - m * r[1] * r[2];
+      const double F[3] = {sm.F[l][0], sm.F[l][1], sm.F[l][2]};
+      const double rp[3] = {c0[0] - p[0], c0[1] - p[1], c0[2] - p[2]};
+      double t[3];
+      cross3(rp, F, t);
+      Fs[0] += F[0]; Fs[1] += F[1]; Fs[2] += F[2];
+      Ts[0] += t[0] + sm.N[l][0]; Ts[1] += t[1] + sm.N[l][1]; Ts[2] += t[2] + sm.N[l][2];
+    }
+    const double ax[3] = {sm.axis[d][0], sm.axis[d][1], sm.axis[d][2]};
+    bias = dtype == 0 ? ax[0] * Fs[0] + ax[1] * Fs[1] + ax[2] * Fs[2] : ax[0] * Ts[0] + ax[1] * Ts[1] + ax[2] * Ts[2];
+  }
+  if (dvalid) {
+    sm.comp[d][0] = cm; sm.comp[d][1] = ch[0]; sm.comp[d][2] = ch[1]; sm.comp[d][3] = ch[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) sm.comp[d][4 + i] = cJ[i];
+  }
+  lds_sync();
+  double Mr[NV], Mh[NV];
+  static_for<0, NV>([&](auto jj) {
+    constexpr int J = decltype(jj)::value;
+    const int jl = c3_dof_link[J], jsub = c3_dof_submask[J], jt = c3_dof_type[J];
+    const bool j_below = (dsub >> jl) & 1, i_below = (jsub >> dlink) & 1;  // J's link moves with me / my link moves with J
+    double val = 0.0;
+    if (j_below || i_below) {
+      // composite of the deeper dof's subtree (same subtree when the two dofs sit on the same link)
+      double m, h[3], Jc[6];
+      if (j_below) {
+        m = sm.comp[J][0]; h[0] = sm.comp[J][1]; h[1] = sm.comp[J][2]; h[2] = sm.comp[J][3];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Jc[i] = sm.comp[J][4 + i];
+      } else {
+        m = cm; h[0] = ch[0]; h[1] = ch[1]; h[2] = ch[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) Jc[i] = cJ[i];
+      }
+      double oj[3], vj[3];
+      const double ax[3] = {sm.axis[J][0], sm.axis[J][1], sm.axis[J][2]};
+      if (jt == 0) { oj[0] = oj[1] = oj[2] = 0.0; vj[0] = ax[0]; vj[1] = ax[1]; vj[2] = ax[2]; }
+      else {
+        double pr[3] = {sm.anchor[J][0] - O[0], sm.anchor[J][1] - O[1], sm.anchor[J][2] - O[2]};
+        oj[0] = ax[0]; oj[1] = ax[1]; oj[2] = ax[2];
+        cross3(pr, ax, vj);
+      }
+      double Jo[3] = {Jc[0] * oj[0] + Jc[3] * oj[1] + Jc[4] * oj[2], Jc[3] * oj[0] + Jc[1] * oj[1] + Jc[5] * oj[2], Jc[4] * oj[0] + Jc[5] * oj[1] + Jc[2] * oj[2]};
+      double t1[3], t2[3];
+      cross3(oj, h, t1); cross3(om, h, t2);
+      val = om[0] * Jo[0] + om[1] * Jo[1] + om[2] * Jo[2] + m * (vv[0] * vj[0] + vv[1] * vj[1] + vv[2] * vj[2]) +
+            vv[0] * t1[0] + vv[1] * t1[1] + vv[2] * t1[2] + vj[0] * t2[0] + vj[1] * t2[1] + vj[2] * t2[2];
+    }
+    if (J == d) val += c3_dof_armature[d];
+    Mr[J] = dvalid ? val : 0.0;
+  });
+  const double damping = c3_dof_damping[d];
+  static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mh[J] = Mr[J] + ((J == d && dvalid) ? H * damping : 0.0); });
+  if (dbg && dvalid) { static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; dbg[D3_M + d * NV + J] = Mr[J]; }); dbg[D3_BIAS + d] = bias; }
+  gauss_jordan20(Mr, lane);
+  gauss_jordan20(Mh, lane);
+  // ================= smooth acceleration
+  double tau;
+  {
+    const int a = c3_dof_act[d];
+    double u = 0.0;
+    if (a >= 0) { u = ctrl_l; const double lo = c3_act_ctrlrange[a][0], hi = c3_act_ctrlrange[a][1]; u = u < lo ? lo : (u > hi ? hi : u); u *= c3_act_gear[a]; }
+    tau = dvalid ? -damping * sm.v[d] - bias + u : 0.0;
+  }
+  double qs = 0.0;
+  static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mr[C] * rdlane(tau, C); });
+  lds_sync();  // comp / com / F ... are dead from here on: sm.A may be written
+  if (dvalid) {
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[d][C] = Mr[C]; });
+    sm.qs[d] = qs; sm.tau[d] = tau;
+  }
+  if (dbg && dvalid) dbg[D3_QS + d] = qs;
+  // ================= collision: sphere s on lane s (capsule ends are spheres for a plane, mjc_PlaneCapsule)
+  bool con_act = false;
+  if (lane < NSPH) {
+    const int l = c3_sph_link[lane];
+    double r[3], hw[3];
+    matvec3(sm.xmat[l], c3_sph_pos[lane], r);
+    const double cx = sm.xpos[l][0] + r[0], cy = sm.xpos[l][1] + r[1], cz = sm.xpos[l][2] + r[2];
+    const double dist = cz - c3_sph_radius[lane];
+    con_act = dist < 0;
+    sm.sphc[lane][0] = cx; sm.sphc[lane][1] = cy; sm.sphc[lane][2] = cz - c3_sph_radius[lane] - 0.5 * dist;  // contact point
+    sm.sphdist[lane] = dist;
+    // mju_makeFrame with normal +z: first tangent = hint minus its normal part (spheres: world y), second = n x t1
+    matvec3(sm.xmat[l], c3_sph_hint[lane], hw);
+    const bool has_hint = c3_sph_hint[lane][0] != 0.0 || c3_sph_hint[lane][1] != 0.0 || c3_sph_hint[lane][2] != 0.0;
+    double tx = has_hint ? hw[0] : 0.0, ty = has_hint ? hw[1] : 1.0;
+    const double n = sqrt(tx * tx + ty * ty);
+    if (n < MINVAL) { tx = 1.0; ty = 0.0; } else { tx /= n; ty /= n; }
+    sm.spht1[lane][0] = tx; sm.spht1[lane][1] = ty;
+  }
+  bool lim_act = false;
+  double lim_dist = 0.0, lim_sgn = 0.0;
+  if (lane < NLIM) {
+    const int dof = c3_lim_dof[lane];
+    const double qd = sm.q[c3_dof_qadr[dof]];
+    const double dlo = qd - c3_lim_range[lane][0], dhi = c3_lim_range[lane][1] - qd;
+    if (dlo < 0) { lim_act = true; lim_dist = dlo; lim_sgn = 1.0; }
+    else if (dhi < 0) { lim_act = true; lim_dist = dhi; lim_sgn = -1.0; }
+  }
+  const unsigned con_mask = (unsigned)__ballot(con_act), lim_mask = (unsigned)__ballot(lim_act);
+  const int ncon = __popc(con_mask), nlim = __popc(lim_mask);
+  const int nrows = 3 * NEQ + nlim + 3 * ncon;
+  out.nefc = nrows;
+  out.overflow = nrows > MAXR;
+  if (out.overflow) { out.niter = 0; return; }  // wave-uniform
+  lds_sync();
+  // ================= the row owned by this lane
+  int kind = K_NONE, cbase = lane;
+  double J[NV];
+  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; J[Jx] = 0.0; });
+  double pos = 0.0, invw = 0.0;
+  const double* solref = c3_contact_solref;
+  const double* solimp = c3_contact_solimp;
+  auto add_point_row = [&](int link, const double* p, const double* dir, double sgn) {
+    // J += sgn * dir . d(point p of `link`)/dq
+    const int mask = c3_link_dofmask[link];
+    static_for<0, NV>([&](auto jj) {
+      constexpr int Jx = decltype(jj)::value;
+      if ((mask >> Jx) & 1) {
+        const double ax[3] = {sm.axis[Jx][0], sm.axis[Jx][1], sm.axis[Jx][2]};
+        double val;
+        if (c3_dof_type[Jx] == 0) val = dir[0] * ax[0] + dir[1] * ax[1] + dir[2] * ax[2];
+        else {
+          double r[3] = {p[0] - sm.anchor[Jx][0], p[1] - sm.anchor[Jx][1], p[2] - sm.anchor[Jx][2]}, c[3];
+          cross3(ax, r, c);
+          val = dir[0] * c[0] + dir[1] * c[1] + dir[2] * c[2];
+        }
+        J[Jx] += sgn * val;
+      }
+    });
+  };
+  if (lane < 3 * NEQ) {
+    kind = K_EQ;
+    const int e = lane / 3, comp = lane % 3;
+    const int l1 = c3_eq_link1[e], l2 = c3_eq_link2[e];
+    double r[3], p1[3], p2[3];
+    matvec3(sm.xmat[l1], c3_eq_p1[e], r);
+    p1[0] = sm.xpos[l1][0] + r[0]; p1[1] = sm.xpos[l1][1] + r[1]; p1[2] = sm.xpos[l1][2] + r[2];
+    matvec3(sm.xmat[l2], c3_eq_p2[e], r);
+    p2[0] = sm.xpos[l2][0] + r[0]; p2[1] = sm.xpos[l2][1] + r[1]; p2[2] = sm.xpos[l2][2] + r[2];
+    const double dir[3] = {comp == 0 ? 1.0 : 0.0, comp == 1 ? 1.0 : 0.0, comp == 2 ? 1.0 : 0.0};
+    add_point_row(l1, p1, dir, 1.0);
+    add_point_row(l2, p2, dir, -1.0);
+    pos = p1[comp] - p2[comp];
+    invw = c3_eq_invweight[e];
+    solref = c3_eq_solref[e]; solimp = c3_eq_solimp[e];
+  } else if (lane < 3 * NEQ + nlim) {
+    kind = K_LIM;
+    const int li = nth_set(lim_mask, lane - 3 * NEQ);
+    const int dof = c3_lim_dof[li];
+    invw = c3_dof_invweight[dof];
+    solref = c3_limit_solref; solimp = c3_limit_solimp;
+    cbase = li;  // remembered for the shuffle below
+  } else if (lane < nrows) {
+    const int k = (lane - 3 * NEQ - nlim) / 3, comp = (lane - 3 * NEQ - nlim) % 3;
+    kind = comp == 0 ? K_CN : K_CT;
+    cbase = lane - comp;
+    const int s = nth_set(con_mask, k);
+    const double tx = sm.spht1[s][0], ty = sm.spht1[s][1];
+    const double dir[3] = {comp == 0 ? 0.0 : (comp == 1 ? tx : -ty), comp == 0 ? 0.0 : (comp == 1 ? ty : tx), comp == 0 ? 1.0 : 0.0};
+    const double p[3] = {sm.sphc[s][0], sm.sphc[s][1], sm.sphc[s][2]};
+    add_point_row(c3_sph_link[s], p, dir, 1.0);
+    pos = comp == 0 ? sm.sphdist[s] : 0.0;
+    invw = c3_sph_invweight[s];
+  }
+  {
+    // joint-limit rows take (distance, side) from the lane that tested the limit
+    const int src = kind == K_LIM ? cbase : 0;
+    const double ld = __shfl(lim_dist, src), ls = __shfl(lim_sgn, src);
+    if (kind == K_LIM) {
+      const int dof = c3_lim_dof[cbase];
+      static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; J[Jx] = (dof == Jx) ? ls : 0.0; });
+      pos = ld;
+      cbase = lane;
+    }
+  }
+  const bool active = kind != K_NONE;
+  double vel = 0.0, bq = 0.0, jw = 0.0;
+  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; vel += J[Jx] * sm.v[Jx]; bq += J[Jx] * sm.qs[Jx]; jw += J[Jx] * sm.ws[Jx]; });
+  double R, aref;
+  {
+    double tc = solref[0] < 2.0 * H ? 2.0 * H : solref[0];
+    const double dr = solref[1], dmax = solimp[1];
+    const double kk = 1.0 / (dmax * dmax * tc * tc * dr * dr), bb = 2.0 / (dmax * tc);
+    const double imp = impedance3(solimp, pos);
+    R = (1.0 - imp) / imp * invw;
+    R = R > MINVAL ? R : MINVAL;
+    aref = -bb * vel - kk * imp * pos;
+  }
+  R = __shfl(R, cbase);  // friction rows share the normal row's regulariser (impratio 1, isotropic friction)
+  const double b = active ? bq - aref : 0.0;
+  const double jar = jw - aref;
+  // rows to LDS, X = J M^-1, A columns
+  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; sm.rowJ[lane][Jx] = active ? J[Jx] : 0.0; });
+  double X[NV];
+  static_for<0, NV>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    double s = 0.0;
+    static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; s += sm.minv[C][Jx] * J[Jx]; });
+    X[C] = s;
+  });
+  if (dbg && active) { static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; dbg[D3_J + lane * NV + Jx] = J[Jx]; }); dbg[D3_AREF + lane] = aref; }
+  lds_sync();
+  double Adiag = 1.0;
+  for (int c = 0; c < nrows; c++) {
+    double a = 0.0;
+    static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; a += X[Jx] * sm.rowJ[c][Jx]; });
+    if (c == lane) { a += R; Adiag = a; }
+    sm.A[c][lane] = active ? a : 0.0;
+  }
+  lds_sync();
+  // ================= warm start (mj_constraintUpdate on qacc_warmstart), kept only if its dual cost beats zero force
+  const double mu = MU;
+  double f = 0.0;
+  {
+    const double D = 1.0 / R;
+    const double jn = __shfl(jar, cbase), j1 = __shfl(jar, cbase + 1 < 64 ? cbase + 1 : 63), j2 = __shfl(jar, cbase + 2 < 64 ? cbase + 2 : 63);
+    if (kind == K_EQ) f = -D * jar;
+    else if (kind == K_LIM) f = jar < 0 ? -D * jar : 0.0;
+    else if (kind == K_CN || kind == K_CT) {
+      const int comp = lane - cbase;
+      const double N = jn * mu, U1 = j1 * mu, U2 = j2 * mu, T = sqrt(U1 * U1 + U2 * U2);
+      double fn, ft;
+      const double jown = comp == 0 ? jn : (comp == 1 ? j1 : j2), Uown = comp == 1 ? U1 : U2;
+      if (N >= mu * T || (T <= 0 && N >= 0)) { fn = 0; ft = 0; }
+      else if (mu * N + T <= 0 || (T <= 0 && N < 0)) { fn = -D * jn; ft = -D * jown; }
+      else {
+        const double Dm = D / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+        fn = -Dm * NmT * mu;
+        ft = -fn / T * Uown * mu;
+      }
+      f = comp == 0 ? fn : ft;
+    }
+  }
+  double res = 0.0;
+  for (int c = 0; c < nrows; c++) res += sm.A[c][lane] * rdlane_dyn(f, c);
+  {
+    const double cost = wave_sum(active ? f * (0.5 * res + b) : 0.0);
+    if (cost > 0) { f = 0.0; res = 0.0; }
+  }
+  res += b;
+  // ================= PGS (mj_solPGS, elliptic cones)
+  const double scale = 1.0 / (MEANINERTIA * NV);
+  int niter = 0;
+  for (int iter = 0; iter < ITERATIONS; iter++) {
+    double improvement = 0.0;
+    for (int K = 0; K < nrows; K++) {
+      const int kindK = __builtin_amdgcn_readlane(kind, K);
+      if (kindK == K_EQ || kindK == K_LIM) {
+        const double fK = rdlane_dyn(f, K), rK = rdlane_dyn(res, K), AKK = rdlane_dyn(Adiag, K);
+        double nf = fK - rK / AKK;
+        if (kindK == K_LIM && nf < 0) nf = 0.0;
+        double dK = nf - fK;
+        const double chg = 0.5 * dK * AKK * dK + dK * rK;
+        if (chg > 1e-10) dK = 0.0; else improvement -= chg;
+        res += sm.A[K][lane] * dK;
+        if (lane == K) f += dK;
+      } else {  // contact: rows K (normal), K+1, K+2 (tangents)
+        const double o0 = rdlane_dyn(f, K), o1 = rdlane_dyn(f, K + 1), o2 = rdlane_dyn(f, K + 2);
+        const double r0 = rdlane_dyn(res, K), r1 = rdlane_dyn(res, K + 1), r2 = rdlane_dyn(res, K + 2);
+        const double A00 = sm.A[K][K], A01 = sm.A[K][K + 1], A02 = sm.A[K][K + 2];
+        const double A10 = sm.A[K + 1][K], A11 = sm.A[K + 1][K + 1], A12 = sm.A[K + 1][K + 2];
+        const double A20 = sm.A[K + 2][K], A21 = sm.A[K + 2][K + 1], A22 = sm.A[K + 2][K + 2];
+        double f0 = o0, f1 = o1, f2 = o2;
+        if (f0 < MINVAL) {  // normal update
+          f0 -= r0 / A00;
+          if (f0 < 0) f0 = 0.0;
+          f1 = 0.0; f2 = 0.0;
+        } else {  // ray update
+          const double v1_0 = A00 * f0 + A01 * f1 + A02 * f2, v1_1 = A10 * f0 + A11 * f1 + A12 * f2, v1_2 = A20 * f0 + A21 * f1 + A22 * f2;
+          const double denom = f0 * v1_0 + f1 * v1_1 + f2 * v1_2;
+          if (denom >= MINVAL) {
+            double x = -(f0 * r0 + f1 * r1 + f2 * r2) / denom;
+            if (f0 + x * f0 < 0) x = -1.0;  // -f/v[0] with v[0] = f
+            const double g0 = f0, g1 = f1, g2 = f2;
+            f0 += x * g0; f1 += x * g1; f2 += x * g2;
+          }
+        }
+        if (f0 >= MINVAL) {  // friction: QCQP on the cone given the normal force
+          double bc1 = r1 - (A11 * o1 + A12 * o2) + A10 * (f0 - o0);
+          double bc2 = r2 - (A21 * o1 + A22 * o2) + A20 * (f0 - o0);
+          double vq[2];
+          const bool act = qcqp2(vq, A11, A12, A22, bc1, bc2, mu, f0);
+          if (act) {
+            double s = vq[0] * vq[0] / (mu * mu) + vq[1] * vq[1] / (mu * mu);
+            s = sqrt(f0 * f0 / (s > MINVAL ? s : MINVAL));
+            vq[0] *= s; vq[1] *= s;
+          }
+          f1 = vq[0]; f2 = vq[1];
+        }
+        double d0 = f0 - o0, d1 = f1 - o1, d2 = f2 - o2;
+        const double chg = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A10 * d0 + A11 * d1 + A12 * d2) + d2 * (A20 * d0 + A21 * d1 + A22 * d2)) +
+                           d0 * r0 + d1 * r1 + d2 * r2;
+        if (chg > 1e-10) { d0 = 0.0; d1 = 0.0; d2 = 0.0; } else improvement -= chg;
+        res += sm.A[K][lane] * d0 + sm.A[K + 1][lane] * d1 + sm.A[K + 2][lane] * d2;
+        if (lane == K) f += d0;
+        if (lane == K + 1) f += d1;
+        if (lane == K + 2) f += d2;
+        K += 2;
+      }
+    }
+    niter = iter + 1;
+    if (improvement * scale < TOLERANCE) break;
+  }
+  out.niter = nrows > 0 ? niter : 0;
+  if (dbg && active) dbg[D3_F + lane] = f;
+  // ================= total force g = tau + J' f;  qacc = M^-1 g;  Euler with implicit joint damping: (M + h B)^-1 g
+  double g = dvalid ? tau : 0.0;
+  for (int r = 0; r < nrows; r++) {
+    const double fr = rdlane_dyn(f, r);
+    g += dvalid ? sm.rowJ[r][d] * fr : 0.0;
+  }
+  double qacc = 0.0, qacch = 0.0;
+  static_for<0, NV>([&](auto cc) {
+    constexpr int C = decltype(cc)::value;
+    const double gc = rdlane(g, C);
+    qacc += sm.minv[d][C] * gc;
+    qacch += Mh[C] * gc;
+  });
+  if (dbg && dvalid) { dbg[D3_QACC + d] = qacc; if (d == 0) dbg[D3_NEFC] = nrows; }
+  lds_sync();
+  if (dvalid) {
+    sm.ws[d] = qacc;
+    if (INTEGRATE) sm.v[d] = sm.v[d] + H * qacch;
+  }
+  lds_sync();
+  if (INTEGRATE) {
+    if (lane < 3) sm.q[lane] += H * sm.v[lane];
+    if (lane >= 6 && lane < NV) sm.q[lane + 1] += H * sm.v[lane];
+    if (lane == 3) {
+      // mju_quatIntegrate: quat <- normalize(quat) * axisangle(omega_body, h |omega|)
+      const double wx = sm.v[3], wy = sm.v[4], wz = sm.v[5], wn = sqrt(wx * wx + wy * wy + wz * wz);
+      double ax = 1.0, ay = 0.0, az = 0.0, ang = 0.0;
+      if (wn >= MINVAL) { ax = wx / wn; ay = wy / wn; az = wz / wn; ang = H * wn; }
+      const double sh = sin(0.5 * ang), r0 = cos(0.5 * ang), r1 = ax * sh, r2 = ay * sh, r3 = az * sh;
+      const double n = sqrt(sm.q[3] * sm.q[3] + sm.q[4] * sm.q[4] + sm.q[5] * sm.q[5] + sm.q[6] * sm.q[6]);
+      const double a0 = sm.q[3] / n, a1 = sm.q[4] / n, a2 = sm.q[5] / n, a3 = sm.q[6] / n;
+      sm.q[3] = a0 * r0 - a1 * r1 - a2 * r2 - a3 * r3;
+      sm.q[4] = a0 * r1 + a1 * r0 + a2 * r3 - a3 * r2;
+      sm.q[5] = a0 * r2 - a1 * r3 + a2 * r0 + a3 * r1;
+      sm.q[6] = a0 * r3 + a1 * r2 - a2 * r1 + a3 * r0;
+    }
+    lds_sync();
+  }
+}
+
+// ---------------------------------------------------------------- n_sub torque-mode substeps of every environment
+template <bool INTEGRATE>
+__global__ void __launch_bounds__(64, 1) env_step3d_kernel(Params3 p) {
+  __shared__ Smem3 sm;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= p.n_envs) return;
+  double* st = p.state + (size_t)env * ENV3_STRIDE;
+  if (st[E3_OVF] != 0.0) return;  // frozen earlier (more than MAXR constraint rows)
+  if (lane < NQ) sm.q[lane] = st[E3_Q + lane];
+  if (lane < NV) { sm.v[lane] = st[E3_V + lane]; sm.ws[lane] = st[E3_WS + lane]; }
+  double time = st[E3_TIME];
+  const int a = lane < NV ? c3_dof_act[lane] : -1;
+  double ctrl_l = 0.0;
+  if (a >= 0) ctrl_l = p.actions ? p.actions[(size_t)env * NU + a] : st[E3_CTRL + a];
+  lds_sync();
+  Out3 out; out.niter = 0; out.nefc = 0; out.overflow = false;
+  int niter_sum = 0;
+  double* dbg = p.debug ? p.debug + (size_t)env * D3_STRIDE : nullptr;
+  bool ovf = false;
+  for (int sub = 0; sub < p.n_sub; sub++) {
+    substep3<INTEGRATE>(sm, lane, ctrl_l, out, dbg);
+    if (out.overflow) { ovf = true; break; }
+    niter_sum += out.niter;
+    if (INTEGRATE) time += H;
+  }
+  if (ovf) { if (lane == 0) st[E3_OVF] = 1.0; return; }  // state left exactly as before the launch
+  if (lane < NQ) st[E3_Q + lane] = sm.q[lane];
+  if (lane < NV) { st[E3_V + lane] = sm.v[lane]; st[E3_WS + lane] = sm.ws[lane]; }
+  if (a >= 0) st[E3_CTRL + a] = ctrl_l;
+  if (lane == 0) { st[E3_TIME] = time; st[E3_NITER] = (double)niter_sum; st[E3_NEFC] = (double)out.nefc; }
+}
+
+__global__ void env_init3d_kernel(double* state, int n, const double* qpos, const double* qvel) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= n) return;
+  double* st = state + (size_t)env * ENV3_STRIDE;
+  for (int i = lane; i < ENV3_STRIDE; i += blockDim.x) {
+    double v = 0.0;
+    if (i < NQ) v = qpos ? qpos[(size_t)env * NQ + i] : c3_qpos_init[i];
+    else if (i >= E3_V && i < E3_V + NV) v = qvel ? qvel[(size_t)env * NV + (i - E3_V)] : 0.0;
+    st[i] = v;
+  }
+}
+
+}  // namespace cassie3d
+#endif

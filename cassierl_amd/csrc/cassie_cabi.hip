@@ -13,10 +13,12 @@
 
 #include "../../include/cassie2d.h"
 #include "../../include/cassie_vec.h"
+#include "../../include/cassie3d_vec.h"
 #include "cassie_kernels.hip"
 #include "cassie_kernels_g16.hip"
 #include "cassie_ctrl.hip"
 #include "cassie_ctrl_g16.hip"
+#include "cassie3d_kernels.hip"
 
 static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
 static_assert(sizeof(StateGeneral) == 208 && sizeof(StateOperationalSpace) == 144 && sizeof(ControllerOsc) == 56 &&
@@ -421,5 +423,161 @@ void GetOperationalSpaceState(Cassie2d* c, StateOperationalSpace* s) {
 
 void Display(Cassie2d* c, bool display) { c->display = display; }
 void Render(Cassie2d*) {}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// include/cassie3d_vec.h: batched Cassie3d physics
+static_assert(CASSIE3D_STATE_STRIDE == cassie3d::ENV3_STRIDE && CASSIE3D_NQ == cassie3d::NQ && CASSIE3D_NV == cassie3d::NV &&
+                  CASSIE3D_NU == cassie3d::NU && CASSIE3D_DEBUG_STRIDE == cassie3d::D3_STRIDE && CASSIE3D_OFF_QVEL == cassie3d::E3_V &&
+                  CASSIE3D_OFF_WARMSTART == cassie3d::E3_WS && CASSIE3D_OFF_CTRL == cassie3d::E3_CTRL && CASSIE3D_OFF_TIME == cassie3d::E3_TIME &&
+                  CASSIE3D_OFF_OVERFLOW == cassie3d::E3_OVF,
+              "public Cassie3d layout must match the kernel layout");
+
+struct Cassie3dVec {
+  int n = 0, device = 0;
+  hipStream_t stream = nullptr;
+  double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+};
+
+namespace {
+int fail3(Cassie3dVec* h, int code, const char* msg) { if (h) h->err = msg; return code; }
+#define HIPCHK3(h, call)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) { if (h) (h)->err = std::string(#call " failed: ") + hipGetErrorString(e_); return CASSIE_EHIP; } \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
+  if (!out || n_envs <= 0) return CASSIE_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "libcassie2d: no HIP device available; this library has no CPU path\n");
+    return CASSIE_ENODEVICE;
+  }
+  if (device < 0 || device >= ndev) return CASSIE_EINVAL;
+  Cassie3dVec* h = new Cassie3dVec();
+  h->n = n_envs; h->device = device;
+  HIPCHK3(h, hipSetDevice(device));
+  HIPCHK3(h, hipStreamCreate(&h->stream));
+  HIPCHK3(h, hipEventCreate(&h->ev0));
+  HIPCHK3(h, hipEventCreate(&h->ev1));
+  HIPCHK3(h, hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)));
+  HIPCHK3(h, hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)));
+  *out = h;
+  return Cassie3dVecReset(h, nullptr, nullptr);
+}
+
+void Cassie3dVecFree(Cassie3dVec* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg);
+  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+  hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* Cassie3dVecLastError(const Cassie3dVec* h) { return h ? h->err.c_str() : "null handle"; }
+
+int Cassie3dVecSetStream(Cassie3dVec* h, void* s) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->stream;
+  return CASSIE_OK;
+}
+
+int Cassie3dVecSynchronize(Cassie3dVec* h) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int Cassie3dVecReset(Cassie3dVec* h, const double* qpos_dev, const double* qvel_dev) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(cassie3d::env_init3d_kernel, dim3(h->n), dim3(64), 0, h->stream, h->state, h->n, qpos_dev, qvel_dev);
+  cassie3d::Params3 p{};
+  p.state = h->state; p.actions = nullptr; p.debug = nullptr; p.n_envs = h->n; p.n_sub = 1;
+  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<false>), dim3(h->n), dim3(64), 0, h->stream, p);  // mj_forward
+  HIPCHK3(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+int Cassie3dVecStep(Cassie3dVec* h, const double* torques_dev, int n_sub) {
+  if (!h || !torques_dev || n_sub <= 0) return fail3(h, CASSIE_EINVAL, "bad argument");
+  HIPCHK3(h, hipSetDevice(h->device));
+  cassie3d::Params3 p{};
+  p.state = h->state; p.actions = torques_dev; p.debug = nullptr; p.n_envs = h->n; p.n_sub = n_sub;
+  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<true>), dim3(h->n), dim3(64), 0, h->stream, p);
+  HIPCHK3(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
+double* Cassie3dVecStatePtr(Cassie3dVec* h) { return h ? h->state : nullptr; }
+
+int Cassie3dVecStepHost(Cassie3dVec* h, const double* torques, int n_sub) {
+  if (!h || !torques) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  HIPCHK3(h, hipMemcpyAsync(h->d_act, torques, (size_t)h->n * cassie3d::NU * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = Cassie3dVecStep(h, h->d_act, n_sub);
+  if (rc) return rc;
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int Cassie3dVecGetStateHost(Cassie3dVec* h, double* state) {
+  if (!h || !state) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  HIPCHK3(h, hipMemcpyAsync(state, h->state, (size_t)h->n * cassie3d::ENV3_STRIDE * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int Cassie3dVecSetStateHost(Cassie3dVec* h, const double* state) {
+  if (!h || !state) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  HIPCHK3(h, hipMemcpyAsync(h->state, state, (size_t)h->n * cassie3d::ENV3_STRIDE * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int Cassie3dVecDebugForwardHost(Cassie3dVec* h, const double* torques, double* dbg) {
+  if (!h || !torques || !dbg) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  const size_t nb = (size_t)h->n * cassie3d::D3_STRIDE * sizeof(double);
+  if (!h->d_dbg) HIPCHK3(h, hipMalloc(&h->d_dbg, nb));
+  HIPCHK3(h, hipMemsetAsync(h->d_dbg, 0, nb, h->stream));
+  HIPCHK3(h, hipMemcpyAsync(h->d_act, torques, (size_t)h->n * cassie3d::NU * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  cassie3d::Params3 p{};
+  p.state = h->state; p.actions = h->d_act; p.debug = h->d_dbg; p.n_envs = h->n; p.n_sub = 1;
+  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<false>), dim3(h->n), dim3(64), 0, h->stream, p);
+  HIPCHK3(h, hipGetLastError());
+  HIPCHK3(h, hipMemcpyAsync(dbg, h->d_dbg, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  return CASSIE_OK;
+}
+
+int Cassie3dVecTimeSteps(Cassie3dVec* h, const double* torques_dev, int n_sub, int steps, float* avg_ms) {
+  if (!h || steps <= 0 || !avg_ms) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  HIPCHK3(h, hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < steps; i++) {
+    int rc = Cassie3dVecStep(h, torques_dev, n_sub);
+    if (rc) return rc;
+  }
+  HIPCHK3(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK3(h, hipEventSynchronize(h->ev1));
+  float ms = 0;
+  HIPCHK3(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = ms / steps;
+  return CASSIE_OK;
+}
 
 }  // extern "C"

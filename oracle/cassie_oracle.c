@@ -869,6 +869,7 @@ void orc_get_bias(const Oracle* o, int sem, const double* qpos, const double* qv
 void orc_get_qacc(const Oracle* o, double* qacc) { memcpy(qacc, o->qacc, sizeof o->qacc); }
 void orc_get_warmstart(const Oracle* o, double* w) { memcpy(w, o->qacc_ws, sizeof o->qacc_ws); }
 void orc_get_ctrl(const Oracle* o, double* c) { memcpy(c, o->ctrl, sizeof o->ctrl); }
+void orc_set_ctrl(Oracle* o, const double* c) { memcpy(o->ctrl, c, sizeof o->ctrl); } /* then orc_forward: mj_forward with these controls */
 void orc_get_efc(const Oracle* o, double* J, double* force, double* pos, double* aref, int* type) {
   if (J) memcpy(J, o->efc_J, sizeof(double) * o->nefc * NV);
   if (force) memcpy(force, o->efc_force, sizeof(double) * o->nefc);

@@ -65,6 +65,7 @@ void orc_get_qacc(const Oracle* o, double* qacc);
 void orc_get_warmstart(const Oracle* o, double* qacc_ws);
 void orc_get_efc(const Oracle* o, double* J /*[nefc*13]*/, double* force, double* pos, double* aref, int* type);
 void orc_get_ctrl(const Oracle* o, double* ctrl6);
+void orc_set_ctrl(Oracle* o, const double* ctrl);
 double orc_energy(const Oracle* o, double* kinetic, double* potential);
 void orc_site_pos(const Oracle* o, int sem, const double* qpos, int site, double* p3);
 void orc_get_model_consts(const Oracle* o, int sem, double* eq_anchor2 /*[2*3]*/, double* dof_invweight0 /*[13]*/,

@@ -1,0 +1,151 @@
+"""Cassie3d physics on the HIP path (include/cassie3d_vec.h) against oracle/liboracle3d.so.  -m gpu only.
+Tolerances: the kernel and the oracle evaluate the same equations with different factorisations (composite-inertia M and
+Gauss-Jordan vs per-body sums and Cholesky; incremental vs recomputed PGS residuals), so agreement is to rounding, not bitwise."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+pytestmark = pytest.mark.gpu
+
+D3 = dict(M=0, BIAS=400, QS=420, NEFC=440, QACC=441, F=461, AREF=525, J=589)
+CTRL = np.array([4.5, 4.5, 12.2, 12.2, 0.9] * 2)
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(ROOT, "tests", "golden", "model3d_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def V3():
+    from cassierl_amd import vec_env3d
+    return vec_env3d
+
+
+def random_state(rng, kat, spread=0.3, height=None):
+    q = np.array(kat["qpos_init"])
+    q[:2] += rng.uniform(-0.5, 0.5, 2)
+    q[2] = height if height is not None else q[2] + rng.uniform(-0.05, 0.3)
+    quat = np.array([1.0, 0, 0, 0]) + rng.uniform(-spread, spread, 4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] += rng.uniform(-spread, spread, 14)
+    v = rng.uniform(-1.0, 1.0, 20)
+    return q, v
+
+
+def test_forward_dynamics_terms_match_oracle(V3, kat):
+    """mj_forward piece by piece on random states (in the air and in contact): M, bias, smooth acceleration, constraint rows,
+    reference accelerations, forces, qacc."""
+    import oracle_py
+    rng = np.random.default_rng(0)
+    n = 6
+    env = V3.Cassie3dVec(n)
+    o = oracle_py.Oracle3D()
+    states, torques = [], rng.uniform(-1, 1, (n, 10)) * CTRL
+    for e in range(n):
+        q, v = random_state(rng, kat, height=(None if e % 2 else 0.80 + 0.03 * e))
+        if e == 0:
+            q, v = np.array(kat["qpos_init"]), np.zeros(20)
+        states.append((q, v))
+    env.set_state_host(np.stack([V3.state_record(q, v) for q, v in states]))
+    dbg = env.debug_forward_host(torques)
+    saw_contact = False
+    for e, (q, v) in enumerate(states):
+        o.set_state_raw(q, v, np.zeros(20))
+        _set_ctrl_forward(o, torques[e])
+        d = dbg[e]
+        M = d[D3["M"]:D3["M"] + 400].reshape(20, 20)
+        np.testing.assert_allclose(M, o.mass_matrix(q), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(d[D3["BIAS"]:D3["BIAS"] + 20], o.bias(q, v), rtol=0, atol=1e-9)
+        nefc = int(d[D3["NEFC"]])
+        assert nefc == o.nefc, (e, nefc, o.nefc)
+        J, f, pos, aref, typ = o.efc()
+        saw_contact |= bool((typ == 2).any())
+        Jg = d[D3["J"]:D3["J"] + 64 * 20].reshape(64, 20)[:nefc]
+        np.testing.assert_allclose(Jg, J, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(d[D3["AREF"]:D3["AREF"] + nefc], aref, rtol=1e-9, atol=1e-7)
+        scale = 1.0 + np.abs(f).max()
+        np.testing.assert_allclose(d[D3["F"]:D3["F"] + nefc], f, rtol=0, atol=1e-7 * scale)
+        a = o.qacc()
+        np.testing.assert_allclose(d[D3["QACC"]:D3["QACC"] + 20], a, rtol=0, atol=1e-7 * (1.0 + np.abs(a).max()))
+    assert saw_contact
+    env.close()
+
+
+def _set_ctrl_forward(o, u):
+    """mj_forward with ctrl = u on the oracle (orc_step_torque would also integrate)"""
+    import oracle_py
+    o.L.orc_set_ctrl(o.h, oracle_py._p(oracle_py._vec(u, 10)))
+    o.forward()
+
+
+def test_teacher_forced_steps_match_oracle(V3, kat):
+    """1000 substeps of random torques, the kernel restarted from the oracle's state (incl. warm start) at every substep."""
+    import oracle_py
+    rng = np.random.default_rng(1)
+    env = V3.Cassie3dVec(2)
+    o = oracle_py.Oracle3D()
+    worst_q, worst_v = 0.0, 0.0
+    u = np.zeros(10)
+    for i in range(1000):
+        if i % 20 == 0:
+            u = rng.uniform(-1, 1, 10) * CTRL
+        q, v = o.state()
+        ws = o.warmstart()
+        env.set_state_host(np.tile(V3.state_record(q, v, ws), (2, 1)))
+        env.step_host(np.tile(u, (2, 1)), 1)
+        o.step_torque(u)
+        s = env.get_state_host()
+        assert np.array_equal(s[0], s[1])
+        q1, v1 = o.state()
+        worst_q = max(worst_q, np.abs(s[0, :21] - q1).max())
+        worst_v = max(worst_v, np.abs(s[0, 21:41] - v1).max() / (1.0 + np.abs(v1).max()))
+        assert s[0, 74] == 0.0
+    assert worst_q < 1e-9 and worst_v < 1e-7, (worst_q, worst_v)
+    env.close()
+
+
+def test_free_running_1000_substeps_within_1e5(V3, kat):
+    """north_star tolerance: state trajectories within 1e-5 relative over 1000 steps on identical actions (free running)."""
+    import oracle_py
+    rng = np.random.default_rng(2)
+    env = V3.Cassie3dVec(1)
+    o = oracle_py.Oracle3D()
+    q0, v0 = o.state()
+    env.set_state_host(V3.state_record(q0, v0, o.warmstart())[None])
+    worst = 0.0
+    for blk in range(100):
+        u = rng.uniform(-0.3, 0.3, 10) * CTRL
+        env.step_host(u[None], 10)
+        for _ in range(10):
+            o.step_torque(u)
+        s = env.get_state_host()[0]
+        q1, v1 = o.state()
+        worst = max(worst, np.abs(s[:21] - q1).max() / (1.0 + np.abs(q1).max()), np.abs(s[21:41] - v1).max() / (1.0 + np.abs(v1).max()))
+    assert worst < 1e-5, worst
+    assert abs(np.linalg.norm(s[3:7]) - 1.0) < 1e-12
+    env.close()
+
+
+def test_reset_and_batch_independence(V3, kat):
+    """Every environment of a batch is independent and the default reset is the standing pose with a valid warm start."""
+    import torch
+    env = V3.Cassie3dVec(130)
+    s = env.get_state_host()
+    np.testing.assert_allclose(s[:, :21], np.tile(kat["qpos_init"], (130, 1)), atol=0)
+    assert (s[:, 73] == 18).all() and (s[:, 74] == 0).all()   # 6 connect rows + 4 contacts x 3
+    rng = np.random.default_rng(3)
+    u = rng.uniform(-1, 1, (130, 10)) * CTRL
+    u[65:] = u[:65]
+    env.step(torch.as_tensor(u, device="cuda"), 10)
+    env.synchronize()
+    s = env.get_state_host()
+    assert np.array_equal(s[:65], s[65:]) and np.isfinite(s).all()
+    assert not np.array_equal(s[0], s[1])
+    env.close()
