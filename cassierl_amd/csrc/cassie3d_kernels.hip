@@ -5,7 +5,7 @@
 // DynamicModel.cpp:250-265); what runs here is the same MuJoCo step the 2-D path restates -- mj_forward (kinematics, CRB mass
 // matrix, RNE bias, plane-sphere/capsule collision, connect / joint-limit / elliptic-contact rows, PGS with warm start) and the
 // implicit-damping Euler step (options of cassie3d_stiff.xml:5) -- for a floating base (3 world translations + unit
-// quaternion, body-frame angular velocity) and 14 hinges: nq 21, nv 20, nu 10.  Checked against oracle/liboracle3d.so.
+// quaternion, body-frame angular velocity) and 14 hinges: nq 21, nv 20, nu 10.  Checked in tests/test_gpu_cassie3d.py.
 //
 // One wavefront per environment, one wavefront per workgroup, everything between the state load and the state store in LDS
 // and VGPRs.  Lane roles change by phase:
@@ -23,6 +23,7 @@
 
 namespace cassie3d {
 
+using cassie::fast_rcp;
 using cassie::lds_sync;
 using cassie::rdlane;
 using cassie::static_for;
@@ -45,10 +46,10 @@ struct Params3 {
 };
 
 struct Smem3 {
-  double q[24], v[NV], ws[NV], tau[NV], qs[NV], gtot[NV];
+  double q[24], v[NV], ws[NV], tau[NV], qs[NV];
   double xpos[NL][3], xmat[NL][9];
   double anchor[NV][3], axis[NV][3];
-  double minv[NV][NV];
+  double minv[NV][NV], mhinv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion), (M + h B)^-1
   double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
   double rowJ[MAXR][NV];  // constraint Jacobian rows
   union {
@@ -117,19 +118,20 @@ __device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
   });
 }
 
-// mju_QCQP2 (values are wave-uniform, so is the control flow)
+// mju_QCQP2 (values are wave-uniform, so is the control flow).  Divisions are rcp + two Newton steps (~1 ulp): an IEEE f64
+// division is ~25 dependent instructions and the contact update sits on the serial critical path of the solver.
 __device__ __forceinline__ bool qcqp2(double* res, double A11, double A12, double A22, double b1, double b2, double d, double r) {
   b1 *= d; b2 *= d; A11 *= d * d; A22 *= d * d; A12 *= d * d;
   double la = 0, v1 = 0, v2 = 0;
   for (int iter = 0; iter < 20; iter++) {
     double det = (A11 + la) * (A22 + la) - A12 * A12;
     if (det < 1e-10) { res[0] = 0; res[1] = 0; return false; }
-    double detinv = 1 / det, P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
+    double detinv = fast_rcp(det), P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
     v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
     double val = v1 * v1 + v2 * v2 - r * r;
     if (val < 1e-10) break;
     double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
-    double delta = -val / deriv;
+    double delta = -val * fast_rcp(deriv);
     if (delta < 1e-10) break;
     la += delta;
   }
@@ -268,24 +270,21 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
     for (int i = 0; i < 6; i++) sm.comp[d][4 + i] = cJ[i];
   }
   lds_sync();
-  double Mr[NV], Mh[NV];
-  static_for<0, NV>([&](auto jj) {
-    constexpr int J = decltype(jj)::value;
+  // Row d of M goes to this lane's (still private) row of sm.minv, one column per trip of a ROLLED loop: unrolled, the
+  // twenty column bodies were scheduled on top of each other and spilled ~600 VGPRs to scratch.
+#pragma unroll 1
+  for (int J = 0; J < NV; J++) {
     const int jl = c3_dof_link[J], jsub = c3_dof_submask[J], jt = c3_dof_type[J];
     const bool j_below = (dsub >> jl) & 1, i_below = (jsub >> dlink) & 1;  // J's link moves with me / my link moves with J
     double val = 0.0;
     if (j_below || i_below) {
       // composite of the deeper dof's subtree (same subtree when the two dofs sit on the same link)
       double m, h[3], Jc[6];
-      if (j_below) {
-        m = sm.comp[J][0]; h[0] = sm.comp[J][1]; h[1] = sm.comp[J][2]; h[2] = sm.comp[J][3];
+      m = j_below ? sm.comp[J][0] : cm;
 #pragma unroll
-        for (int i = 0; i < 6; i++) Jc[i] = sm.comp[J][4 + i];
-      } else {
-        m = cm; h[0] = ch[0]; h[1] = ch[1]; h[2] = ch[2];
+      for (int i = 0; i < 3; i++) h[i] = j_below ? sm.comp[J][1 + i] : ch[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) Jc[i] = cJ[i];
-      }
+      for (int i = 0; i < 6; i++) Jc[i] = j_below ? sm.comp[J][4 + i] : cJ[i];
       double oj[3], vj[3];
       const double ax[3] = {sm.axis[J][0], sm.axis[J][1], sm.axis[J][2]};
       if (jt == 0) { oj[0] = oj[1] = oj[2] = 0.0; vj[0] = ax[0]; vj[1] = ax[1]; vj[2] = ax[2]; }
@@ -301,13 +300,19 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
             vv[0] * t1[0] + vv[1] * t1[1] + vv[2] * t1[2] + vj[0] * t2[0] + vj[1] * t2[1] + vj[2] * t2[2];
     }
     if (J == d) val += c3_dof_armature[d];
-    Mr[J] = dvalid ? val : 0.0;
-  });
+    if (dvalid) sm.minv[d][J] = val;
+  }
   const double damping = c3_dof_damping[d];
-  static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mh[J] = Mr[J] + ((J == d && dvalid) ? H * damping : 0.0); });
-  if (dbg && dvalid) { static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; dbg[D3_M + d * NV + J] = Mr[J]; }); dbg[D3_BIAS + d] = bias; }
+  if (dbg && dvalid) { for (int J = 0; J < NV; J++) dbg[D3_M + d * NV + J] = sm.minv[d][J]; dbg[D3_BIAS + d] = bias; }
+  {
+    double Mh[NV];  // (M + h B)^-1 for the implicit-damping Euler step, parked in LDS until then
+    static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mh[J] = dvalid ? sm.minv[d][J] + (J == d ? H * damping : 0.0) : 0.0; });
+    gauss_jordan20(Mh, lane);
+    if (dvalid) { static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; sm.mhinv[d][J] = Mh[J]; }); }
+  }
+  double Mr[NV];
+  static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mr[J] = dvalid ? sm.minv[d][J] : 0.0; });
   gauss_jordan20(Mr, lane);
-  gauss_jordan20(Mh, lane);
   // ================= smooth acceleration
   double tau;
   {
@@ -359,79 +364,74 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
   out.overflow = nrows > MAXR;
   if (out.overflow) { out.niter = 0; return; }  // wave-uniform
   lds_sync();
-  // ================= the row owned by this lane
+  // ================= the row owned by this lane: up to two (link, point, sign) point-Jacobian terms along `dir`
   int kind = K_NONE, cbase = lane;
-  double J[NV];
-  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; J[Jx] = 0.0; });
   double pos = 0.0, invw = 0.0;
   const double* solref = c3_contact_solref;
   const double* solimp = c3_contact_solimp;
-  auto add_point_row = [&](int link, const double* p, const double* dir, double sgn) {
-    // J += sgn * dir . d(point p of `link`)/dq
-    const int mask = c3_link_dofmask[link];
-    static_for<0, NV>([&](auto jj) {
-      constexpr int Jx = decltype(jj)::value;
-      if ((mask >> Jx) & 1) {
-        const double ax[3] = {sm.axis[Jx][0], sm.axis[Jx][1], sm.axis[Jx][2]};
-        double val;
-        if (c3_dof_type[Jx] == 0) val = dir[0] * ax[0] + dir[1] * ax[1] + dir[2] * ax[2];
-        else {
-          double r[3] = {p[0] - sm.anchor[Jx][0], p[1] - sm.anchor[Jx][1], p[2] - sm.anchor[Jx][2]}, c[3];
-          cross3(ax, r, c);
-          val = dir[0] * c[0] + dir[1] * c[1] + dir[2] * c[2];
-        }
-        J[Jx] += sgn * val;
-      }
-    });
-  };
+  int mask1 = 0, mask2 = 0, limdof = -1;
+  double p1[3] = {0, 0, 0}, p2[3] = {0, 0, 0}, dir[3] = {0, 0, 0};
   if (lane < 3 * NEQ) {
     kind = K_EQ;
     const int e = lane / 3, comp = lane % 3;
     const int l1 = c3_eq_link1[e], l2 = c3_eq_link2[e];
-    double r[3], p1[3], p2[3];
+    double r[3];
     matvec3(sm.xmat[l1], c3_eq_p1[e], r);
     p1[0] = sm.xpos[l1][0] + r[0]; p1[1] = sm.xpos[l1][1] + r[1]; p1[2] = sm.xpos[l1][2] + r[2];
     matvec3(sm.xmat[l2], c3_eq_p2[e], r);
     p2[0] = sm.xpos[l2][0] + r[0]; p2[1] = sm.xpos[l2][1] + r[1]; p2[2] = sm.xpos[l2][2] + r[2];
-    const double dir[3] = {comp == 0 ? 1.0 : 0.0, comp == 1 ? 1.0 : 0.0, comp == 2 ? 1.0 : 0.0};
-    add_point_row(l1, p1, dir, 1.0);
-    add_point_row(l2, p2, dir, -1.0);
+    dir[comp] = 1.0;
+    mask1 = c3_link_dofmask[l1]; mask2 = c3_link_dofmask[l2];
     pos = p1[comp] - p2[comp];
     invw = c3_eq_invweight[e];
     solref = c3_eq_solref[e]; solimp = c3_eq_solimp[e];
   } else if (lane < 3 * NEQ + nlim) {
     kind = K_LIM;
-    const int li = nth_set(lim_mask, lane - 3 * NEQ);
-    const int dof = c3_lim_dof[li];
-    invw = c3_dof_invweight[dof];
+    cbase = nth_set(lim_mask, lane - 3 * NEQ);  // the lane that tested this limit (shuffle source below)
+    limdof = c3_lim_dof[cbase];
+    invw = c3_dof_invweight[limdof];
     solref = c3_limit_solref; solimp = c3_limit_solimp;
-    cbase = li;  // remembered for the shuffle below
   } else if (lane < nrows) {
     const int k = (lane - 3 * NEQ - nlim) / 3, comp = (lane - 3 * NEQ - nlim) % 3;
     kind = comp == 0 ? K_CN : K_CT;
     cbase = lane - comp;
     const int s = nth_set(con_mask, k);
     const double tx = sm.spht1[s][0], ty = sm.spht1[s][1];
-    const double dir[3] = {comp == 0 ? 0.0 : (comp == 1 ? tx : -ty), comp == 0 ? 0.0 : (comp == 1 ? ty : tx), comp == 0 ? 1.0 : 0.0};
-    const double p[3] = {sm.sphc[s][0], sm.sphc[s][1], sm.sphc[s][2]};
-    add_point_row(c3_sph_link[s], p, dir, 1.0);
+    dir[0] = comp == 0 ? 0.0 : (comp == 1 ? tx : -ty); dir[1] = comp == 0 ? 0.0 : (comp == 1 ? ty : tx); dir[2] = comp == 0 ? 1.0 : 0.0;
+    p1[0] = sm.sphc[s][0]; p1[1] = sm.sphc[s][1]; p1[2] = sm.sphc[s][2];
+    mask1 = c3_link_dofmask[c3_sph_link[s]];
     pos = comp == 0 ? sm.sphdist[s] : 0.0;
     invw = c3_sph_invweight[s];
   }
+  double lim_s = 0.0;
   {
     // joint-limit rows take (distance, side) from the lane that tested the limit
     const int src = kind == K_LIM ? cbase : 0;
     const double ld = __shfl(lim_dist, src), ls = __shfl(lim_sgn, src);
-    if (kind == K_LIM) {
-      const int dof = c3_lim_dof[cbase];
-      static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; J[Jx] = (dof == Jx) ? ls : 0.0; });
-      pos = ld;
-      cbase = lane;
-    }
+    if (kind == K_LIM) { pos = ld; lim_s = ls; cbase = lane; }
   }
   const bool active = kind != K_NONE;
   double vel = 0.0, bq = 0.0, jw = 0.0;
-  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; vel += J[Jx] * sm.v[Jx]; bq += J[Jx] * sm.qs[Jx]; jw += J[Jx] * sm.ws[Jx]; });
+#pragma unroll 1
+  for (int j = 0; j < NV; j++) {  // rolled on purpose (register pressure); writes this lane's own LDS row
+    const double ax[3] = {sm.axis[j][0], sm.axis[j][1], sm.axis[j][2]};
+    const double an[3] = {sm.anchor[j][0], sm.anchor[j][1], sm.anchor[j][2]};
+    const bool slide = c3_dof_type[j] == 0;
+    double val = 0.0;
+    if ((mask1 >> j) & 1) {
+      double r[3] = {p1[0] - an[0], p1[1] - an[1], p1[2] - an[2]}, c[3];
+      cross3(ax, r, c);
+      val += slide ? dir[0] * ax[0] + dir[1] * ax[1] + dir[2] * ax[2] : dir[0] * c[0] + dir[1] * c[1] + dir[2] * c[2];
+    }
+    if ((mask2 >> j) & 1) {
+      double r[3] = {p2[0] - an[0], p2[1] - an[1], p2[2] - an[2]}, c[3];
+      cross3(ax, r, c);
+      val -= slide ? dir[0] * ax[0] + dir[1] * ax[1] + dir[2] * ax[2] : dir[0] * c[0] + dir[1] * c[1] + dir[2] * c[2];
+    }
+    if (j == limdof) val = lim_s;
+    sm.rowJ[lane][j] = val;
+    vel += val * sm.v[j]; bq += val * sm.qs[j]; jw += val * sm.ws[j];
+  }
   double R, aref;
   {
     double tc = solref[0] < 2.0 * H ? 2.0 * H : solref[0];
@@ -445,16 +445,15 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
   R = __shfl(R, cbase);  // friction rows share the normal row's regulariser (impratio 1, isotropic friction)
   const double b = active ? bq - aref : 0.0;
   const double jar = jw - aref;
-  // rows to LDS, X = J M^-1, A columns
-  static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; sm.rowJ[lane][Jx] = active ? J[Jx] : 0.0; });
+  // X = J M^-1 (M^-1 is symmetric: its row j is read as a contiguous broadcast)
   double X[NV];
-  static_for<0, NV>([&](auto cc) {
-    constexpr int C = decltype(cc)::value;
-    double s = 0.0;
-    static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; s += sm.minv[C][Jx] * J[Jx]; });
-    X[C] = s;
-  });
-  if (dbg && active) { static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; dbg[D3_J + lane * NV + Jx] = J[Jx]; }); dbg[D3_AREF + lane] = aref; }
+  static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; X[C] = 0.0; });
+#pragma unroll 1
+  for (int j = 0; j < NV; j++) {
+    const double Jj = sm.rowJ[lane][j];
+    static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; X[C] += sm.minv[j][C] * Jj; });
+  }
+  if (dbg && active) { for (int j = 0; j < NV; j++) dbg[D3_J + lane * NV + j] = sm.rowJ[lane][j]; dbg[D3_AREF + lane] = aref; }
   lds_sync();
   double Adiag = 1.0;
   for (int c = 0; c < nrows; c++) {
@@ -464,6 +463,7 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
     sm.A[c][lane] = active ? a : 0.0;
   }
   lds_sync();
+  const double Ainv = 1.0 / Adiag;
   // ================= warm start (mj_constraintUpdate on qacc_warmstart), kept only if its dual cost beats zero force
   const double mu = MU;
   double f = 0.0;
@@ -502,8 +502,8 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
     for (int K = 0; K < nrows; K++) {
       const int kindK = __builtin_amdgcn_readlane(kind, K);
       if (kindK == K_EQ || kindK == K_LIM) {
-        const double fK = rdlane_dyn(f, K), rK = rdlane_dyn(res, K), AKK = rdlane_dyn(Adiag, K);
-        double nf = fK - rK / AKK;
+        const double fK = rdlane_dyn(f, K), rK = rdlane_dyn(res, K), AKK = rdlane_dyn(Adiag, K), AKKinv = rdlane_dyn(Ainv, K);
+        double nf = fK - rK * AKKinv;
         if (kindK == K_LIM && nf < 0) nf = 0.0;
         double dK = nf - fK;
         const double chg = 0.5 * dK * AKK * dK + dK * rK;
@@ -518,14 +518,14 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
         const double A20 = sm.A[K + 2][K], A21 = sm.A[K + 2][K + 1], A22 = sm.A[K + 2][K + 2];
         double f0 = o0, f1 = o1, f2 = o2;
         if (f0 < MINVAL) {  // normal update
-          f0 -= r0 / A00;
+          f0 -= r0 * rdlane_dyn(Ainv, K);
           if (f0 < 0) f0 = 0.0;
           f1 = 0.0; f2 = 0.0;
         } else {  // ray update
           const double v1_0 = A00 * f0 + A01 * f1 + A02 * f2, v1_1 = A10 * f0 + A11 * f1 + A12 * f2, v1_2 = A20 * f0 + A21 * f1 + A22 * f2;
           const double denom = f0 * v1_0 + f1 * v1_1 + f2 * v1_2;
           if (denom >= MINVAL) {
-            double x = -(f0 * r0 + f1 * r1 + f2 * r2) / denom;
+            double x = -(f0 * r0 + f1 * r1 + f2 * r2) * fast_rcp(denom);
             if (f0 + x * f0 < 0) x = -1.0;  // -f/v[0] with v[0] = f
             const double g0 = f0, g1 = f1, g2 = f2;
             f0 += x * g0; f1 += x * g1; f2 += x * g2;
@@ -537,8 +537,8 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
           double vq[2];
           const bool act = qcqp2(vq, A11, A12, A22, bc1, bc2, mu, f0);
           if (act) {
-            double s = vq[0] * vq[0] / (mu * mu) + vq[1] * vq[1] / (mu * mu);
-            s = sqrt(f0 * f0 / (s > MINVAL ? s : MINVAL));
+            double s = (vq[0] * vq[0] + vq[1] * vq[1]) * (1.0 / (MU * MU));
+            s = sqrt(f0 * f0 * fast_rcp(s > MINVAL ? s : MINVAL));
             vq[0] *= s; vq[1] *= s;
           }
           f1 = vq[0]; f2 = vq[1];
@@ -570,7 +570,7 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
     constexpr int C = decltype(cc)::value;
     const double gc = rdlane(g, C);
     qacc += sm.minv[d][C] * gc;
-    qacch += Mh[C] * gc;
+    qacch += sm.mhinv[d][C] * gc;
   });
   if (dbg && dvalid) { dbg[D3_QACC + d] = qacc; if (d == 0) dbg[D3_NEFC] = nrows; }
   lds_sync();
