@@ -29,7 +29,8 @@ using cassie::rdlane;
 using cassie::static_for;
 using cassie::wave_sum;
 
-constexpr int MAXR = 64;
+constexpr int MAXR = 64;        // constraint rows of the general kernel
+constexpr int MAXR_FAST = 32;   // ... of the high-occupancy kernel (8 KB instead of 32 KB for A): 6 connect rows + 8 contacts, say
 constexpr double MINVAL = 1e-15;
 // HBM record of one environment (doubles)
 constexpr int ENV3_STRIDE = 80;
@@ -39,26 +40,29 @@ enum { K_NONE = 0, K_EQ = 1, K_LIM = 2, K_CN = 3, K_CT = 4 };
 enum { D3_M = 0, D3_BIAS = 400, D3_QS = 420, D3_NEFC = 440, D3_QACC = 441, D3_F = 461, D3_AREF = 525, D3_J = 589, D3_STRIDE = 589 + 64 * 20 };
 
 struct Params3 {
-  double* state;          // [n][ENV3_STRIDE]
-  const double* actions;  // [n][10] motor commands (pre-clamp), device
-  double* debug;          // [n][D3_STRIDE] or null
-  int n_envs, n_sub;
+  double* state;           // [n][ENV3_STRIDE]
+  const double* actions;   // [n][10] motor commands (pre-clamp), device
+  double* debug;           // [n][D3_STRIDE] or null
+  const int* pending_in;   // [n] substeps to do per env (second pass) or null: n_sub for everyone
+  int* pending_out;        // [n] substeps NOT done because the env needed more rows than this kernel has, or null: flag E3_OVF
+  int n_envs, n_sub, integrate;
 };
 
+template <int MR>
 struct Smem3 {
   double q[24], v[NV], ws[NV], tau[NV], qs[NV];
   double xpos[NL][3], xmat[NL][9];
   double anchor[NV][3], axis[NV][3];
   double minv[NV][NV], mhinv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion), (M + h B)^-1
   double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
-  double rowJ[MAXR][NV];  // constraint Jacobian rows
+  double rowJ[MR][NV];  // constraint Jacobian rows
   union {
     struct {  // kinematics by-products, dead once M and bias exist
       double w[NL][3], vo[NL][3], al[NL][3], ao[NL][3];
       double com[NL][3], F[NL][3], N[NL][3], Iw[NL][6];
       double comp[NV][10];
     };
-    double A[MAXR][MAXR];  // A[c][i] read by lane i (A is symmetric)
+    double A[MR][MR];  // A[c][i] read by lane i (A is symmetric)
   };
 };
 
@@ -142,8 +146,8 @@ __device__ __forceinline__ bool qcqp2(double* res, double A11, double A12, doubl
 struct Out3 { int niter, nefc; bool overflow; };
 
 // ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
-template <bool INTEGRATE>
-__device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, Out3& out, double* dbg) {
+template <int MR>
+__device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, bool integrate, Out3& out, double* dbg) {
   // ================= kinematics: links 0..14 on lanes 0..14, one tree level at a time
   const int lk = lane < NL ? lane : 0;
   const int depth = lane < NL ? c3_link_depth[lk] : 99, par = c3_link_parent[lk];
@@ -361,7 +365,7 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
   const int ncon = __popc(con_mask), nlim = __popc(lim_mask);
   const int nrows = 3 * NEQ + nlim + 3 * ncon;
   out.nefc = nrows;
-  out.overflow = nrows > MAXR;
+  out.overflow = nrows > MR;
   if (out.overflow) { out.niter = 0; return; }  // wave-uniform
   lds_sync();
   // ================= the row owned by this lane: up to two (link, point, sign) point-Jacobian terms along `dir`
@@ -576,10 +580,10 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
   lds_sync();
   if (dvalid) {
     sm.ws[d] = qacc;
-    if (INTEGRATE) sm.v[d] = sm.v[d] + H * qacch;
+    if (integrate) sm.v[d] = sm.v[d] + H * qacch;
   }
   lds_sync();
-  if (INTEGRATE) {
+  if (integrate) {
     if (lane < 3) sm.q[lane] += H * sm.v[lane];
     if (lane >= 6 && lane < NV) sm.q[lane + 1] += H * sm.v[lane];
     if (lane == 3) {
@@ -600,13 +604,21 @@ __device__ void substep3(Smem3& sm, int lane, double ctrl_l /* dof lane: command
 }
 
 // ---------------------------------------------------------------- n_sub torque-mode substeps of every environment
-template <bool INTEGRATE>
-__global__ void __launch_bounds__(64, 1) env_step3d_kernel(Params3 p) {
-  __shared__ Smem3 sm;
+// Two instantiations are launched back to back (cassie_cabi.hip): <MAXR_FAST, 2> does every environment that needs at most 32
+// constraint rows at twice the occupancy and hands the others over through `pending` (substeps left, state saved at that
+// point); <MAXR, 1> finishes those and returns at once for everyone else.
+template <int MR, int WPS>
+__global__ void __launch_bounds__(64, WPS) env_step3d_kernel(Params3 p) {
+  __shared__ Smem3<MR> sm;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= p.n_envs) return;
+  const int n_sub = p.pending_in ? p.pending_in[env] : p.n_sub;
+  if (n_sub == 0) return;
   double* st = p.state + (size_t)env * ENV3_STRIDE;
-  if (st[E3_OVF] != 0.0) return;  // frozen earlier (more than MAXR constraint rows)
+  if (st[E3_OVF] != 0.0) {  // frozen earlier (more than MAXR constraint rows)
+    if (lane == 0 && p.pending_out) p.pending_out[env] = 0;
+    return;
+  }
   if (lane < NQ) sm.q[lane] = st[E3_Q + lane];
   if (lane < NV) { sm.v[lane] = st[E3_V + lane]; sm.ws[lane] = st[E3_WS + lane]; }
   double time = st[E3_TIME];
@@ -615,20 +627,27 @@ __global__ void __launch_bounds__(64, 1) env_step3d_kernel(Params3 p) {
   if (a >= 0) ctrl_l = p.actions ? p.actions[(size_t)env * NU + a] : st[E3_CTRL + a];
   lds_sync();
   Out3 out; out.niter = 0; out.nefc = 0; out.overflow = false;
-  int niter_sum = 0;
+  int niter_sum = p.pending_in ? (int)st[E3_NITER] : 0;
   double* dbg = p.debug ? p.debug + (size_t)env * D3_STRIDE : nullptr;
-  bool ovf = false;
-  for (int sub = 0; sub < p.n_sub; sub++) {
-    substep3<INTEGRATE>(sm, lane, ctrl_l, out, dbg);
-    if (out.overflow) { ovf = true; break; }
+  int left = 0;
+  for (int sub = 0; sub < n_sub; sub++) {
+    substep3<MR>(sm, lane, ctrl_l, p.integrate != 0, out, dbg);
+    if (out.overflow) { left = n_sub - sub; break; }  // detected before anything of this substep was written
     niter_sum += out.niter;
-    if (INTEGRATE) time += H;
+    if (p.integrate) time += H;
   }
-  if (ovf) { if (lane == 0) st[E3_OVF] = 1.0; return; }  // state left exactly as before the launch
+  if (left != 0 && !p.pending_out) {  // nobody to hand over to: freeze the environment as it was before the launch
+    if (lane == 0) st[E3_OVF] = 1.0;
+    return;
+  }
   if (lane < NQ) st[E3_Q + lane] = sm.q[lane];
   if (lane < NV) { st[E3_V + lane] = sm.v[lane]; st[E3_WS + lane] = sm.ws[lane]; }
   if (a >= 0) st[E3_CTRL + a] = ctrl_l;
-  if (lane == 0) { st[E3_TIME] = time; st[E3_NITER] = (double)niter_sum; st[E3_NEFC] = (double)out.nefc; }
+  if (lane == 0) {
+    st[E3_TIME] = time; st[E3_NITER] = (double)niter_sum;
+    if (left == 0) st[E3_NEFC] = (double)out.nefc;
+    if (p.pending_out) p.pending_out[env] = left;
+  }
 }
 
 __global__ void env_init3d_kernel(double* state, int n, const double* qpos, const double* qvel) {

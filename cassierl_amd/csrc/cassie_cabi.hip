@@ -438,11 +438,24 @@ struct Cassie3dVec {
   int n = 0, device = 0;
   hipStream_t stream = nullptr;
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
+  int* pending = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 };
 
 namespace {
+// fast kernel (<= 32 rows, 2 waves per SIMD) for everyone, then the general kernel for the environments it left pending
+void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
+  dim3 grid(h->n), block(64);
+  if (p.debug) {
+    hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR, 1>), grid, block, 0, h->stream, p);
+    return;
+  }
+  p.pending_in = nullptr; p.pending_out = h->pending;
+  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR_FAST, 2>), grid, block, 0, h->stream, p);
+  p.pending_in = h->pending; p.pending_out = nullptr;
+  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR, 1>), grid, block, 0, h->stream, p);
+}
 int fail3(Cassie3dVec* h, int code, const char* msg) { if (h) h->err = msg; return code; }
 #define HIPCHK3(h, call)                                                                      \
   do {                                                                                        \
@@ -470,6 +483,7 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   HIPCHK3(h, hipEventCreate(&h->ev1));
   HIPCHK3(h, hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)));
   HIPCHK3(h, hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)));
+  HIPCHK3(h, hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)));
   *out = h;
   return Cassie3dVecReset(h, nullptr, nullptr);
 }
@@ -478,7 +492,7 @@ void Cassie3dVecFree(Cassie3dVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
-  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg);
+  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending);
   hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
   hipStreamDestroy(h->stream);
   delete h;
@@ -504,8 +518,8 @@ int Cassie3dVecReset(Cassie3dVec* h, const double* qpos_dev, const double* qvel_
   HIPCHK3(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(cassie3d::env_init3d_kernel, dim3(h->n), dim3(64), 0, h->stream, h->state, h->n, qpos_dev, qvel_dev);
   cassie3d::Params3 p{};
-  p.state = h->state; p.actions = nullptr; p.debug = nullptr; p.n_envs = h->n; p.n_sub = 1;
-  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<false>), dim3(h->n), dim3(64), 0, h->stream, p);  // mj_forward
+  p.state = h->state; p.actions = nullptr; p.debug = nullptr; p.n_envs = h->n; p.n_sub = 1; p.integrate = 0;
+  launch3d(h, p);  // mj_forward
   HIPCHK3(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -514,8 +528,8 @@ int Cassie3dVecStep(Cassie3dVec* h, const double* torques_dev, int n_sub) {
   if (!h || !torques_dev || n_sub <= 0) return fail3(h, CASSIE_EINVAL, "bad argument");
   HIPCHK3(h, hipSetDevice(h->device));
   cassie3d::Params3 p{};
-  p.state = h->state; p.actions = torques_dev; p.debug = nullptr; p.n_envs = h->n; p.n_sub = n_sub;
-  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<true>), dim3(h->n), dim3(64), 0, h->stream, p);
+  p.state = h->state; p.actions = torques_dev; p.debug = nullptr; p.n_envs = h->n; p.n_sub = n_sub; p.integrate = 1;
+  launch3d(h, p);
   HIPCHK3(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -556,8 +570,8 @@ int Cassie3dVecDebugForwardHost(Cassie3dVec* h, const double* torques, double* d
   HIPCHK3(h, hipMemsetAsync(h->d_dbg, 0, nb, h->stream));
   HIPCHK3(h, hipMemcpyAsync(h->d_act, torques, (size_t)h->n * cassie3d::NU * sizeof(double), hipMemcpyHostToDevice, h->stream));
   cassie3d::Params3 p{};
-  p.state = h->state; p.actions = h->d_act; p.debug = h->d_dbg; p.n_envs = h->n; p.n_sub = 1;
-  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<false>), dim3(h->n), dim3(64), 0, h->stream, p);
+  p.state = h->state; p.actions = h->d_act; p.debug = h->d_dbg; p.n_envs = h->n; p.n_sub = 1; p.integrate = 0;
+  launch3d(h, p);
   HIPCHK3(h, hipGetLastError());
   HIPCHK3(h, hipMemcpyAsync(dbg, h->d_dbg, nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK3(h, hipStreamSynchronize(h->stream));

@@ -149,3 +149,50 @@ def test_reset_and_batch_independence(V3, kat):
     assert np.array_equal(s[:65], s[65:]) and np.isfinite(s).all()
     assert not np.array_equal(s[0], s[1])
     env.close()
+
+
+def test_many_contacts_hand_over_to_the_general_kernel(V3, kat):
+    """A robot lying on the floor has more than 32 constraint rows: the high-occupancy kernel hands the environment over to the
+    64-row kernel (pending list).  Same checks as above on such states, through both the debug (general kernel only) and the
+    normal two-kernel path, including an Env.step that starts below 32 rows and crosses the limit part-way."""
+    import oracle_py
+    rng = np.random.default_rng(5)
+    o = oracle_py.Oracle3D()
+    q = np.array(kat["qpos_init"])
+    q[2] = 0.12
+    q[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]   # rolled 90 degrees: lying on its side, 9 contacts
+    v = rng.uniform(-0.05, 0.05, 20)
+    o.reset(q, v)
+    assert o.nefc > 32, o.nefc
+    env = V3.Cassie3dVec(3)
+    worst = 0.0
+    u = rng.uniform(-1, 1, 10) * CTRL
+    for i in range(60):
+        qo, vo = o.state()
+        env.set_state_host(np.tile(V3.state_record(qo, vo, o.warmstart()), (3, 1)))
+        env.step_host(np.tile(u, (3, 1)), 1)
+        o.step_torque(u)
+        s = env.get_state_host()
+        q1, v1 = o.state()
+        assert s[0, 74] == 0.0 and s[0, 73] == o.nefc
+        worst = max(worst, np.abs(s[0, :21] - q1).max(), np.abs(s[0, 21:41] - v1).max() / (1.0 + np.abs(v1).max()))
+    assert worst < 1e-7, worst
+    # falling onto the floor inside one Env.step: rows grow past 32 between substeps
+    q = np.array(kat["qpos_init"]); q[2] = 0.15
+    q[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]
+    v = np.zeros(20); v[2] = -1.0
+    o.reset(q, v)
+    n0 = o.nefc
+    env.set_state_host(np.tile(V3.state_record(q, v, o.warmstart()), (3, 1)))
+    env.step_host(np.zeros((3, 10)), 60)
+    crossed = False
+    for _ in range(60):
+        o.step_torque(np.zeros(10))
+        crossed |= o.nefc > 32
+    assert n0 <= 32 and crossed, (n0, o.nefc)
+    s = env.get_state_host()
+    q1, v1 = o.state()
+    assert abs(s[0, 71] - 60 * 0.0005) < 1e-12 and s[0, 74] == 0.0
+    np.testing.assert_allclose(s[0, :21], q1, atol=1e-6)
+    np.testing.assert_allclose(s[0, 21:41], v1, atol=1e-4 * (1 + np.abs(v1).max()))
+    env.close()
