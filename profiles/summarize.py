@@ -52,10 +52,12 @@ def main():
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(HERE, tag + "_kernel_stats.csv"))
     pd_rows, pd_total = traffic(src, "pmc_", ("env_step_g16_kernel", "env_step_kernel"))
     osc_rows, osc_total = traffic(src, "pmc_osc_", ("env_ctrl_step_g16_kernel", "env_ctrl_step_kernel"))
+    c3_rows, c3_total = traffic(src, "pmc_3d_", ("env_step3d_kernel",))
     summary = dict(source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, no tracing), tests/prof_step.py 4096 6 [PD|OSC]; "
                           "mean over dispatches after the first; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)",
                    n_envs=4096, pd=dict(kernels=pd_rows, hbm_bytes_per_env_step_launch=pd_total),
-                   osc=dict(kernels=osc_rows, hbm_bytes_per_env_step_launch=osc_total))
+                   osc=dict(kernels=osc_rows, hbm_bytes_per_env_step_launch=osc_total),
+                   cassie3d=dict(kernels=c3_rows, hbm_bytes_per_env_step_launch=c3_total))
     with open(os.path.join(HERE, tag + "_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
