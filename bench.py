@@ -125,7 +125,7 @@ def main():
                        "collective": "one all_gather of per-env returns per rollout batch"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "env_step_kernel<PD>", "kernel_ms": kernel_ms, "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "kernel": "cassie::g16::env_step_g16_kernel<0> (+ clean-up pass cassie::env_step_kernel<0,3,32>, ~1 % of the time)", "kernel_ms": kernel_ms, "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d); see fp64_valu"},
             "fp64_valu": {"achieved_tflops_est": FLOP_PER_SUBSTEP * 10 * n_local / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "flop_model": "60 kflop/substep estimate of SURVEY.md 8(d)"},
