@@ -48,16 +48,20 @@ struct Params3 {
   int n_envs, n_sub, integrate;
 };
 
+// LDS of one environment.  Everything the kinematics produces (link frames, joint axes, collision spheres, velocity
+// by-products, composite inertias) is dead by the time A is filled, so A overlays all of it: 20.4 KB for MR = 32, i.e.
+// 8 wavefronts per CU (2 per SIMD, matching the 256-VGPR budget); 53 KB for MR = 64.
 template <int MR>
 struct Smem3 {
-  double q[24], v[NV], ws[NV], tau[NV], qs[NV];
-  double xpos[NL][3], xmat[NL][9];
-  double anchor[NV][3], axis[NV][3];
+  double q[22], v[NV], ws[NV], qs[NV];
   double minv[NV][NV], mhinv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion), (M + h B)^-1
-  double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
-  double rowJ[MR][NV];  // constraint Jacobian rows
+  double rowJ[MR][NV];                 // constraint Jacobian rows
   union {
-    struct {  // kinematics by-products, dead once M and bias exist
+    struct {
+      double xpos[NL][3], xmat[NL][9];
+      double anchor[NV][3], axis[NV][3];
+      double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
+      // velocity / inertia by-products, dead once M and bias exist
       double w[NL][3], vo[NL][3], al[NL][3], ao[NL][3];
       double com[NL][3], F[NL][3], N[NL][3], Iw[NL][6];
       double comp[NV][10];
@@ -327,10 +331,10 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
   }
   double qs = 0.0;
   static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; qs += Mr[C] * rdlane(tau, C); });
-  lds_sync();  // comp / com / F ... are dead from here on: sm.A may be written
+  lds_sync();
   if (dvalid) {
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[d][C] = Mr[C]; });
-    sm.qs[d] = qs; sm.tau[d] = tau;
+    sm.qs[d] = qs;
   }
   if (dbg && dvalid) dbg[D3_QS + d] = qs;
   // ================= collision: sphere s on lane s (capsule ends are spheres for a plane, mjc_PlaneCapsule)
@@ -415,6 +419,8 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     if (kind == K_LIM) { pos = ld; lim_s = ls; cbase = lane; }
   }
   const bool active = kind != K_NONE;
+  const bool inrow = lane < MR;        // lanes beyond the row capacity of this instantiation own no LDS row / column
+  const int rl = inrow ? lane : 0;
   double vel = 0.0, bq = 0.0, jw = 0.0;
 #pragma unroll 1
   for (int j = 0; j < NV; j++) {  // rolled on purpose (register pressure); writes this lane's own LDS row
@@ -433,7 +439,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
       val -= slide ? dir[0] * ax[0] + dir[1] * ax[1] + dir[2] * ax[2] : dir[0] * c[0] + dir[1] * c[1] + dir[2] * c[2];
     }
     if (j == limdof) val = lim_s;
-    sm.rowJ[lane][j] = val;
+    if (inrow) sm.rowJ[lane][j] = val;
     vel += val * sm.v[j]; bq += val * sm.qs[j]; jw += val * sm.ws[j];
   }
   double R, aref;
@@ -454,17 +460,17 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
   static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; X[C] = 0.0; });
 #pragma unroll 1
   for (int j = 0; j < NV; j++) {
-    const double Jj = sm.rowJ[lane][j];
+    const double Jj = sm.rowJ[rl][j];
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; X[C] += sm.minv[j][C] * Jj; });
   }
-  if (dbg && active) { for (int j = 0; j < NV; j++) dbg[D3_J + lane * NV + j] = sm.rowJ[lane][j]; dbg[D3_AREF + lane] = aref; }
+  if (dbg && active) { for (int j = 0; j < NV; j++) dbg[D3_J + lane * NV + j] = sm.rowJ[rl][j]; dbg[D3_AREF + lane] = aref; }
   lds_sync();
   double Adiag = 1.0;
   for (int c = 0; c < nrows; c++) {
     double a = 0.0;
     static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; a += X[Jx] * sm.rowJ[c][Jx]; });
     if (c == lane) { a += R; Adiag = a; }
-    sm.A[c][lane] = active ? a : 0.0;
+    if (inrow) sm.A[c][lane] = active ? a : 0.0;
   }
   lds_sync();
   const double Ainv = 1.0 / Adiag;
@@ -492,7 +498,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     }
   }
   double res = 0.0;
-  for (int c = 0; c < nrows; c++) res += sm.A[c][lane] * rdlane_dyn(f, c);
+  for (int c = 0; c < nrows; c++) res += sm.A[c][rl] * rdlane_dyn(f, c);
   {
     const double cost = wave_sum(active ? f * (0.5 * res + b) : 0.0);
     if (cost > 0) { f = 0.0; res = 0.0; }
@@ -512,7 +518,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
         double dK = nf - fK;
         const double chg = 0.5 * dK * AKK * dK + dK * rK;
         if (chg > 1e-10) dK = 0.0; else improvement -= chg;
-        res += sm.A[K][lane] * dK;
+        res += sm.A[K][rl] * dK;
         if (lane == K) f += dK;
       } else {  // contact: rows K (normal), K+1, K+2 (tangents)
         const double o0 = rdlane_dyn(f, K), o1 = rdlane_dyn(f, K + 1), o2 = rdlane_dyn(f, K + 2);
@@ -551,7 +557,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
         const double chg = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A10 * d0 + A11 * d1 + A12 * d2) + d2 * (A20 * d0 + A21 * d1 + A22 * d2)) +
                            d0 * r0 + d1 * r1 + d2 * r2;
         if (chg > 1e-10) { d0 = 0.0; d1 = 0.0; d2 = 0.0; } else improvement -= chg;
-        res += sm.A[K][lane] * d0 + sm.A[K + 1][lane] * d1 + sm.A[K + 2][lane] * d2;
+        res += sm.A[K][rl] * d0 + sm.A[K + 1][rl] * d1 + sm.A[K + 2][rl] * d2;
         if (lane == K) f += d0;
         if (lane == K + 1) f += d1;
         if (lane == K + 2) f += d2;
