@@ -866,6 +866,12 @@ void orc_get_mass_matrix(const Oracle* o, int sem, const double* qpos, double* M
 void orc_get_bias(const Oracle* o, int sem, const double* qpos, const double* qvel, double* bias) {
   Kin k; kinematics(o, sem, qpos, qvel, &k); bias_force(o, &k, o->gravity_z, bias);
 }
+/* n independent mechanisms, n_sub torque-mode steps each, OpenMP over mechanisms (CPU baseline of the batched kernels) */
+void orc_batch_step_torque(Oracle** os, int n, const double* torques /*[n][NU]*/, int n_sub, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int i = 0; i < n; i++)
+    for (int s = 0; s < n_sub; s++) orc_step_torque(os[i], torques + (size_t)i * NU);
+}
 void orc_get_qacc(const Oracle* o, double* qacc) { memcpy(qacc, o->qacc, sizeof o->qacc); }
 void orc_get_warmstart(const Oracle* o, double* w) { memcpy(w, o->qacc_ws, sizeof o->qacc_ws); }
 void orc_get_ctrl(const Oracle* o, double* c) { memcpy(c, o->ctrl, sizeof o->ctrl); }

@@ -61,6 +61,7 @@ int orc_ncon(const Oracle* o);
 int orc_solver_niter(const Oracle* o);
 void orc_get_mass_matrix(const Oracle* o, int sem, const double* qpos, double* M);
 void orc_get_bias(const Oracle* o, int sem, const double* qpos, const double* qvel, double* bias);
+void orc_batch_step_torque(Oracle** os, int n, const double* torques, int n_sub, int nthreads);
 void orc_get_qacc(const Oracle* o, double* qacc);
 void orc_get_warmstart(const Oracle* o, double* qacc_ws);
 void orc_get_efc(const Oracle* o, double* J /*[nefc*13]*/, double* force, double* pos, double* aref, int* type);

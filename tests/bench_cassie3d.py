@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--episode", type=int, default=40)
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time oracle/liboracle3d.so on the host cores (OpenMP over envs)")
     a = ap.parse_args()
     env = Cassie3dVec(a.envs)
     ids = torch.arange(a.envs, device="cuda")
@@ -41,6 +42,25 @@ def main():
     out = dict(config="configs[4]: Cassie3d torque-mode random rollout", n_envs=a.envs, steps=a.steps, ms_per_step=tot_ms / a.steps,
                env_steps_per_s=a.envs * a.steps / (tot_ms * 1e-3), physics_substeps_per_s=10 * a.envs * a.steps / (tot_ms * 1e-3),
                overflowed_envs=int((s[:, 74] != 0).sum()), finite=bool(np.isfinite(s).all()))
+    if a.cpu_baseline:
+        import ctypes as ct
+        import time
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O
+        cores = len(os.sched_getaffinity(0))
+        n_cpu, steps_cpu = 4 * cores, 3
+        os_ = [O.Oracle3D() for _ in range(n_cpu)]
+        arr = (ct.c_void_p * n_cpu)(*[o.h for o in os_])
+        u = np.ascontiguousarray(acts[0][:n_cpu].cpu().numpy())
+        L = O.lib3d()
+        L.orc_batch_step_torque(arr, n_cpu, u.ctypes.data_as(O.dp), 10, cores)  # warm-up
+        t0 = time.perf_counter()
+        for t in range(steps_cpu):
+            u = np.ascontiguousarray(acts[(t + 1) % 8][:n_cpu].cpu().numpy())
+            L.orc_batch_step_torque(arr, n_cpu, u.ctypes.data_as(O.dp), 10, cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=n_cpu * steps_cpu / dt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="%d envs x %d env-steps (10 substeps each) in %.1f s, OpenMP over envs" % (n_cpu, steps_cpu, dt))
     print(json.dumps(out))
 
 
