@@ -47,7 +47,7 @@ def traffic(src, prefix, step_kernels):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
-    for name in ("bench_4096.json", "bench_65536.json", "other_configs.jsonl"):
+    for name in ("bench_4096.json", "bench_65536.json", "other_configs.jsonl", "trpo_65536.jsonl"):
         shutil.copy(os.path.join(src, name), os.path.join(HERE, "%s_%s" % (tag, name)))
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(HERE, tag + "_kernel_stats.csv"))
     pd_rows, pd_total = traffic(src, "pmc_", ("env_step_g16_kernel", "env_step_kernel"))
