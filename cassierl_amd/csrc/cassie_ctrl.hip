@@ -43,10 +43,52 @@ struct CtrlSmem {
   double s18[18];
 };
 
-// pseudoinverse of a symmetric 4x4 (singular values = |eigenvalues|, threshold tol): cyclic Jacobi on wave-uniform registers
+// pseudoinverse of a symmetric 4x4 (singular values = |eigenvalues|, threshold tol) on per-environment registers.
+// Fast path: S = Jeq Hinv Jeq' is positive definite with eigenvalues ~0.2 .. 11 in every pose the robot reaches, far above the
+// 1e-3 threshold of pseudoinverse(.,1e-3) (Cassie2d.cpp:134, OSC_RBDL.cpp:171).  When that holds the pseudoinverse IS the
+// inverse, which a 4-pivot Gauss-Jordan gives in ~150 instructions instead of ~5000 for the Jacobi eigen-decomposition.  It is
+// certified without eigenvalues: lambda_min(S) = 1/lambda_max(S^-1) >= 1/||S^-1||_F, so ||S^-1||_F * tol < 1 with positive
+// pivots proves that no singular value is at or below tol.  Otherwise: cyclic Jacobi, as before.
 __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double tol, double (&P)[16]) {
   double a[4][4], V[4][4];
   for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = 0.5 * (Sin[4 * i + j] + Sin[4 * j + i]); V[i][j] = i == j ? 1.0 : 0.0; }
+  {
+    double g[4][4];
+    bool posdef = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) g[i][j] = a[i][j];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // in-place Gauss-Jordan inverse of an SPD matrix (no pivoting needed)
+      const double piv = g[k][k];
+      posdef = posdef && piv > 0.0;
+      const double inv = 1.0 / piv;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (j != k) g[k][j] *= inv;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (i == k) continue;
+        const double t = g[i][k];
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (j != k) g[i][j] -= t * g[k][j];
+        g[i][k] = -t * inv;
+      }
+      g[k][k] = inv;
+    }
+    double fro2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) fro2 += g[i][j] * g[i][j];
+    if (posdef && fro2 * tol * tol < 1.0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) P[4 * i + j] = 0.5 * (g[i][j] + g[j][i]);
+      return;
+    }
+  }
   for (int sweep = 0; sweep < 10; sweep++) {
     double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[0][3]) + fabs(a[1][2]) + fabs(a[1][3]) + fabs(a[2][3]);
     double dia = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]) + fabs(a[3][3]);
@@ -69,13 +111,16 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
         }
       }
   }
+  double winv[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { double w = a[k][k]; winv[k] = fabs(w) > tol ? 1.0 / w : 0.0; }
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       double s = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { double w = a[k][k]; s += fabs(w) > tol ? V[i][k] * V[j][k] / w : 0.0; }
+      for (int k = 0; k < 4; k++) s += V[i][k] * V[j][k] * winv[k];
       P[4 * i + j] = s;
     }
 }
@@ -92,7 +137,7 @@ __device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& 
     load_dof_const(dc, c);
     double Mr[NV], bias;
     mass_rows<1>(sm, c, dc, l, Mr, bias, false);
-    gauss_jordan_rows<NV>(Mr, l);
+    gauss_jordan_rows<NV, true>(Mr, l);
     if (c.dvalid && c.grp == 0 && rowok) {
       static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
       cs.bias[c.d] = bias + dc.damping * sm.v[c.d];
@@ -188,8 +233,13 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 }
 
 // ---------------------------------------------------------------- Cassie2d::StepOsc controller: cs.act[7] -> cs.u[6]
+// `wset` (uniform inside a row) carries the QP working set from one call to the next, as qpOASES' hotstart does in the reference
+// (OSC_RBDL.cpp:276-280): bits 0..13 = variable i sits on a bound, bits 14..27 = ... on its lower bound; 0 = cold start (all
+// friction-cone generators at 0, motors free).  The QP is strictly convex, so the warm start changes the number of active-set
+// iterations (typically 8 -> 1 or 2), not the solution.
+constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
 template <class SM>
-__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid) {
+__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset) {
   const int lane = rowok ? l : 63;
   double P4[16], g4[4];
   ctrl_dyn(sm, cs, c, l, rowok, P4, g4);
@@ -262,8 +312,11 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
   const double lo = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][0] : 0.0;
   const double hi = lane < 6 ? cp_act_ctrlrange[lane < 6 ? lane : 0][1] : 1.7976931348623157e308;
   // ---- primal active-set iterations; each row runs its own problem, the loop ends when no row is busy
-  double z = 0.0;
-  bool bound = l >= 6, atlo = true;
+  const unsigned w0 = wset ? wset : QP_COLD_WSET;
+  bool bound = isvar && ((w0 >> (l & 15)) & 1u), atlo = (w0 >> (14 + (l & 15))) & 1u;
+  if (!isvar) { bound = l >= 6; atlo = true; }
+  double z = bound ? (atlo ? lo : hi) : 0.0;  // feasible start: bound variables on their bound, free ones at 0 (inside every box)
+  if (l >= 6) z = 0.0;                          // generators have no upper bound
   bool busy = rowok;  // uniform inside a row
   for (int it = 0; it < 60; it++) {
     if (__ballot(busy) == 0) break;
@@ -279,7 +332,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
       if (!isvar) val = (Jv == (l & 15)) ? 1.0 : 0.0;
       Mr[Jv] = val;
     });
-    gauss_jordan_rows<NZ>(Mr, l);
+    gauss_jordan_rows<NZ, true>(Mr, l);
     const double rhs = (bound || !isvar) ? 0.0 : -g;
     double d = 0.0;
     static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; d += Mr[Jv] * row_bcast<Jv>(rhs); });
@@ -312,6 +365,11 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
       if (full && !conv && l == rel) bound = false;
     }
     if (conv) busy = false;
+  }
+  {
+    const unsigned bm = (unsigned)(__ballot(bound && isvar) >> (16 * rowid)) & 0x3FFFu;
+    const unsigned am = (unsigned)(__ballot(bound && isvar && atlo) >> (16 * rowid)) & 0x3FFFu;
+    if (rowok) wset = bm | (am << 14);
   }
   if (lane < 6) cs.u[lane] = z;
   lds_sync();
@@ -470,11 +528,12 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   StepOut so; so.niter = 0; so.active = 0;
   int niter_sum = 0;
   double ctrl = 0.0;
+  unsigned wset = (unsigned)st[ES_QPWSET];
   for (int sub = 0; sub < n_sub; sub++) {
     if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zp, zv);
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
     lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4);
+    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset);
     else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
     ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
     substep<true, 32>(sm, c, lane, ctrl, so, nullptr, ovf);
@@ -504,6 +563,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
       if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }
       if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
       time = 0.0;
+      wset = 0u;
       lds_sync();
       substep<false, 32>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf);
       opstate18(sm, c, lane, fix_kin, s18);
@@ -515,6 +575,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
     if (lane == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
   }
   store_state(st, sm, lane, qstate_l, time, niter_sum);
+  if (CTRL == 2 && lane == 0) st[ES_QPWSET] = (double)wset;
 }
 
 }  // namespace cassie

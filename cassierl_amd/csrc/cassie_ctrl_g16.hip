@@ -62,13 +62,14 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
   int pend = 0, niter_sum = 0;
   double ctrl = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
+  unsigned wset = (unsigned)st[ES_QPWSET];  // OSC QP working set of the previous call (uniform inside a row)
   for (int sub = 0; sub < p.n_sub; sub++) {
     const double kq_old = sm.kq[l], kv_old = sm.kv[l];
     if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, l, live, fix_kin, zp, zv);
     else if (l < ADIM) cs.act[l] = act_l;  // the physics substep overlays cs: re-stage the action every substep
     if (live && l < NV) { sm.kq[l] = sm.q[l]; sm.kv[l] = sm.v[l]; }  // DynamicModel::setState
     lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, l, live, g);
+    if (CTRL == 2) ctrl_osc(sm, cs, c, l, live, g, wset);
     else ctrl_jacobian(sm, cs, c, l, live, g);
     const double cnew = c.act >= 0 ? cs.u[c.act] : 0.0;
     lds_sync();
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
     const bool do_reset = live && done && p.auto_reset;
     if (__ballot(do_reset) != 0) {
       if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; qstate_l = cp_env_qinit[l]; }
-      if (do_reset) time = 0.0;
+      if (do_reset) { time = 0.0; wset = 0u; }
       lds_sync();
       G16Out ro; ro.niter = 0; ro.overflow = false;
       substep(sm, c, l, g, c.act >= 0 ? sm.ctrl[c.act] : 0.0, do_reset, false, ro);  // reset pose: 12 rows, cannot overflow
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
       st[ES_KQ + l] = sm.kq[l]; st[ES_KV + l] = sm.kv[l]; st[ES_QSTATE + l] = qstate_l;
     }
     if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
-    if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
+    if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; if (CTRL == 2) st[ES_QPWSET] = (double)wset; pending[env] = pend; }
   }
 }
 

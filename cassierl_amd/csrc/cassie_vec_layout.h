@@ -11,9 +11,10 @@ namespace cassie {
 //   [ 0..12] qpos   [13..25] qvel   [26..38] qacc_warmstart
 //   [39..51] qpos at the last DynamicModel::setState   [52..64] qvel at the last setState   (quirk Q1/Q2)
 //   [65..77] self.qstate positions (written by reset only; quirk Q3)
-//   [78..83] last mj_data->ctrl (pre-clamp)   [84] env time   [85] PGS iterations of the last call   [86,87] pad
+//   [78..83] last mj_data->ctrl (pre-clamp)   [84] env time   [85] PGS iterations of the last call
+//   [86] OSC QP working set of the last StepOsc (hot start, 0 = cold; written by the OSC kernels only)   [87] pad
 constexpr int ENV_STRIDE = 88;
-enum { ES_Q = 0, ES_V = 13, ES_WS = 26, ES_KQ = 39, ES_KV = 52, ES_QSTATE = 65, ES_CTRL = 78, ES_TIME = 84, ES_NITER = 85 };
+enum { ES_Q = 0, ES_V = 13, ES_WS = 26, ES_KQ = 39, ES_KV = 52, ES_QSTATE = 65, ES_CTRL = 78, ES_TIME = 84, ES_NITER = 85, ES_QPWSET = 86 };
 
 // debug record (doubles) written by substep() when VecParams.debug != nullptr (tests only)
 enum {
