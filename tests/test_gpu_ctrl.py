@@ -216,3 +216,31 @@ def test_g16_scripted_standing_controller_agrees(vec, mode):
         np.testing.assert_allclose(sa[:, 39:65], sb[:, 39:65], rtol=0, atol=1e-7)
         np.testing.assert_allclose(sa[:, 84], sb[:, 84], atol=1e-12)
     a.close(); b.close()
+
+
+def test_osc_qp_hot_start_does_not_change_the_solution(vec):
+    """The OSC kernels keep the QP working set of the previous call in the state record (slot 86), like qpOASES' hotstart in
+    the reference (OSC_RBDL.cpp:276-280).  The QP is strictly convex: cold start, the carried working set and an arbitrary
+    (wrong) working set must all give the same torques."""
+    rng = np.random.default_rng(11)
+    n = 3
+    env = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    env.reset_host()
+    for blk in range(5):
+        env.standing_step_host("OSC", 0.88, 0.0, 10)
+    s = env.get_full_state_host()
+    assert s[0, 86] != 0.0                      # a working set was recorded
+    for t in range(20):
+        s = env.get_full_state_host()
+        s[1] = s[0]; s[2] = s[0]
+        s[1, 86] = 0.0                          # cold start
+        s[2, 86] = float(0x155 | (0x3FFF << 14))  # some other working set: motors 0,2,4 and generators 6,8 on their lower bound
+        env.set_full_state_host(s)
+        a = np.tile(osc_action(rng, 2.0), (n, 1))
+        env.substep_host("OSC", a, 1)
+        r = env.get_full_state_host()
+        np.testing.assert_allclose(r[1, 78:84], r[0, 78:84], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(r[2, 78:84], r[0, 78:84], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(r[1, :26], r[0, :26], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r[2, :26], r[0, :26], rtol=0, atol=1e-9)
+    env.close()
