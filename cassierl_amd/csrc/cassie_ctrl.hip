@@ -49,7 +49,7 @@ struct CtrlSmem {
 // inverse, which a 4-pivot Gauss-Jordan gives in ~150 instructions instead of ~5000 for the Jacobi eigen-decomposition.  It is
 // certified without eigenvalues: lambda_min(S) = 1/lambda_max(S^-1) >= 1/||S^-1||_F, so ||S^-1||_F * tol < 1 with positive
 // pivots proves that no singular value is at or below tol.  Otherwise: cyclic Jacobi, as before.
-__device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double tol, double (&P)[16]) {
+__device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double tol, double (&P)[16], bool noshort) {
   double a[4][4], V[4][4];
   for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = 0.5 * (Sin[4 * i + j] + Sin[4 * j + i]); V[i][j] = i == j ? 1.0 : 0.0; }
   {
@@ -81,7 +81,7 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) fro2 += g[i][j] * g[i][j];
-    if (posdef && fro2 * tol * tol < 1.0) {
+    if (!noshort && posdef && fro2 * tol * tol < 1.0) {
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -129,7 +129,7 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
 // Leaves in LDS: sm.minv = Hinv (RBDL semantics), cs.Jd, cs.acc, cs.JH, cs.bias; returns the wave-uniform P4 = (Jeq Hinv Jeq')^+
 // and g4 = P4 * JeqdotQdot.
 template <class SM>
-__device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, double (&P4)[16], double (&g4)[4]) {
+__device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, double (&P4)[16], double (&g4)[4], bool noshort) {
   const int lane = rowok ? l : 63;  // role tests below are written against `lane`; dead rows take no role
   planar_fk<1>(sm, sm.q, sm.v, c, lane);
   {
@@ -206,7 +206,7 @@ __device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& 
     }
   }
   lds_sync();
-  pinv_sym4(cs.S4, 1e-3, P4);  // pseudoinverse(Jeq*Hinv*Jeq', 1e-3)  (Cassie2d.cpp:134, OSC_RBDL.cpp:171)
+  pinv_sym4(cs.S4, 1e-3, P4, noshort);  // pseudoinverse(Jeq*Hinv*Jeq', 1e-3)  (Cassie2d.cpp:134, OSC_RBDL.cpp:171)
 #pragma unroll
   for (int r = 0; r < 4; r++) g4[r] = P4[4 * r] * cs.acc[0] + P4[4 * r + 1] * cs.acc[1] + P4[4 * r + 2] * cs.acc[2] + P4[4 * r + 3] * cs.acc[3];
 }
@@ -239,10 +239,10 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 // iterations (typically 8 -> 1 or 2), not the solution.
 constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
 template <class SM>
-__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset) {
+__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false) {
   const int lane = rowok ? l : 63;
   double P4[16], g4[4];
-  ctrl_dyn(sm, cs, c, l, rowok, P4, g4);
+  ctrl_dyn(sm, cs, c, l, rowok, P4, g4, noshort);
   // ---- column lanes: 0..5 motors, 6..13 friction-cone generators of contact sites 2..5, 14 the bias column
   {
     double w[NV];
@@ -377,11 +377,11 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
 
 // ---------------------------------------------------------------- Cassie2d::StepJacobian controller: cs.act[6] -> cs.u[6]
 template <class SM>
-__device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, double* dbg = nullptr) {
+__device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, double* dbg = nullptr, bool noshort = false) {
   const int lane = rowok ? l : 63;
   (void)rowid;
   double P4[16], g4[4];
-  ctrl_dyn(sm, cs, c, l, rowok, P4, g4);
+  ctrl_dyn(sm, cs, c, l, rowok, P4, g4, noshort);
   if (dbg && lane == 0) {
     for (int i = 0; i < 13; i++) dbg[97 + i] = cs.bias[i];
     for (int i = 0; i < 4; i++) dbg[110 + i] = g4[i];
@@ -423,44 +423,93 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
     if (lane == 6) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; cs.y[C] = w[C]; }); }
   }
   lds_sync();
-  // ---- u = pseudoinverse(Nc Bt, 1e-4) * rhs : one-sided Jacobi SVD, row r of U (13x6) and of V (6x6) on lane r
+  // ---- u = pseudoinverse(Nc Bt, 1e-4) * rhs; row r of U = Nc Bt (13x6) on lane r
+  // Fast path: U has full column rank in every reachable pose (singular values ~12 .. 100 against the 1e-4 threshold), and then
+  // U^+ = (U'U)^-1 U'.  N = U'U is 6x6 and well conditioned (cond ~ 70), so the normal equations are safe in double precision;
+  // lambda_min(N) >= 1/||N^-1||_F, hence ||N^-1||_F * tol^2 < 1 (with positive pivots) certifies sigma_min(U) > tol.  The
+  // one-sided Jacobi SVD (~10 k instructions) only runs for rows whose certificate fails.
   const bool rowU = lane < NV, rowV = lane < 6;
   double Ur[6], Vr[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) { Ur[k] = rowU ? cs.U[k][lane < NV ? lane : 0] : 0.0; Vr[k] = (rowV && lane == k) ? 1.0 : 0.0; }
-  bool busy = rowok;
-  for (int sweep = 0; sweep < 30; sweep++) {
-    if (__ballot(busy) == 0) break;
-    double off = 0.0;  // uniform inside a row
-    static_for<0, 5>([&](auto pp) {
-      constexpr int Pp = decltype(pp)::value;
-      static_for<Pp + 1, 6>([&](auto qq) {
-        constexpr int Q = decltype(qq)::value;
-        double a = row_sum(Ur[Pp] * Ur[Pp]), b = row_sum(Ur[Q] * Ur[Q]), cc = row_sum(Ur[Pp] * Ur[Q]);
-        const bool rot = busy && fabs(cc) > 1e-300 && fabs(cc) > 1e-17 * sqrt(a * b);
-        // rotation parameters (computed on every lane, applied where `rot`): no DPP below this point of the pair
-        double ab = sqrt(a * b);
-        double zeta = (b - a) / (2.0 * (rot ? cc : 1.0));
-        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        double cs_ = 1.0 / sqrt(1.0 + t * t), sn = cs_ * t;
-        cs_ = rot ? cs_ : 1.0; sn = rot ? sn : 0.0;
-        off += rot ? fabs(cc) / ab : 0.0;
-        double up = Ur[Pp], uq = Ur[Q];
-        Ur[Pp] = cs_ * up - sn * uq; Ur[Q] = sn * up + cs_ * uq;
-        double vp = Vr[Pp], vq = Vr[Q];
-        Vr[Pp] = cs_ * vp - sn * vq; Vr[Q] = sn * vp + cs_ * vq;
-      });
-    });
-    if (off < 1e-15) busy = false;
-  }
-  double rhs = rowU ? cs.y[lane < NV ? lane : 0] : 0.0;
+  const double rhs = rowU ? cs.y[lane < NV ? lane : 0] : 0.0;
   double u = 0.0;
+  bool certified = false;
+  {
+    double N[6][6], yk[6];
+    static_for<0, 6>([&](auto ii) {
+      constexpr int I = decltype(ii)::value;
+      yk[I] = row_sum(Ur[I] * rhs);
+      static_for<I, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; N[I][J] = row_sum(Ur[I] * Ur[J]); N[J][I] = N[I][J]; });
+    });
+    bool posdef = true;
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    double s2 = row_sum(Ur[k] * Ur[k]);
-    double pr = row_sum(Ur[k] * rhs);
-    double coef = sqrt(s2) > 1e-4 ? pr / s2 : 0.0;
-    u += Vr[k] * coef;
+    for (int k = 0; k < 6; k++) {  // in-place Gauss-Jordan inverse (values are uniform inside a row)
+      const double piv = N[k][k];
+      posdef = posdef && piv > 0.0;
+      const double inv = 1.0 / piv;
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (j != k) N[k][j] *= inv;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        if (i == k) continue;
+        const double t = N[i][k];
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j != k) N[i][j] -= t * N[k][j];
+        N[i][k] = -t * inv;
+      }
+      N[k][k] = inv;
+    }
+    double fro2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) fro2 += N[i][j] * N[i][j];
+    const double tol2 = 1e-4 * 1e-4;
+    certified = !noshort && posdef && fro2 * tol2 * tol2 < 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double uk = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) uk += 0.5 * (N[k][j] + N[j][k]) * yk[j];
+      if (lane == k) u = uk;
+    }
+  }
+  bool busy = rowok && !certified;
+  if (__ballot(busy) != 0) {  // fallback: one-sided Jacobi SVD with the singular-value threshold applied literally
+    for (int sweep = 0; sweep < 30; sweep++) {
+      if (__ballot(busy) == 0) break;
+      double off = 0.0;  // uniform inside a row
+      static_for<0, 5>([&](auto pp) {
+        constexpr int Pp = decltype(pp)::value;
+        static_for<Pp + 1, 6>([&](auto qq) {
+          constexpr int Q = decltype(qq)::value;
+          double a = row_sum(Ur[Pp] * Ur[Pp]), b = row_sum(Ur[Q] * Ur[Q]), cc = row_sum(Ur[Pp] * Ur[Q]);
+          const bool rot = busy && fabs(cc) > 1e-300 && fabs(cc) > 1e-17 * sqrt(a * b);
+          // rotation parameters (computed on every lane, applied where `rot`): no DPP below this point of the pair
+          double ab = sqrt(a * b);
+          double zeta = (b - a) / (2.0 * (rot ? cc : 1.0));
+          double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          double cs_ = 1.0 / sqrt(1.0 + t * t), sn = cs_ * t;
+          cs_ = rot ? cs_ : 1.0; sn = rot ? sn : 0.0;
+          off += rot ? fabs(cc) / ab : 0.0;
+          double up = Ur[Pp], uq = Ur[Q];
+          Ur[Pp] = cs_ * up - sn * uq; Ur[Q] = sn * up + cs_ * uq;
+          double vp = Vr[Pp], vq = Vr[Q];
+          Vr[Pp] = cs_ * vp - sn * vq; Vr[Q] = sn * vp + cs_ * vq;
+        });
+      });
+      if (off < 1e-15) busy = false;
+    }
+    double us = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double s2 = row_sum(Ur[k] * Ur[k]);
+      double pr = row_sum(Ur[k] * rhs);
+      double coef = sqrt(s2) > 1e-4 ? pr / s2 : 0.0;
+      us += Vr[k] * coef;
+    }
+    if (!certified) u = us;
   }
   if (lane < 6) cs.u[lane] = u;
   lds_sync();
@@ -529,12 +578,13 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   int niter_sum = 0;
   double ctrl = 0.0;
   unsigned wset = (unsigned)st[ES_QPWSET];
+  const bool noshort = (p.flags & FLAG_NO_PINV_SHORTCUT) != 0;
   for (int sub = 0; sub < n_sub; sub++) {
     if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zp, zv);
     if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
     lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset);
-    else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr);
+    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort);
+    else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr, noshort);
     ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
     substep<true, 32>(sm, c, lane, ctrl, so, nullptr, ovf);
     niter_sum += so.niter;

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
   double act_l = 0.0;
   if (!SCRIPTED && l < ADIM) act_l = p.actions[e * ADIM + l];
   const double zp = SCRIPTED ? zpos[e] : 0.0, zv = SCRIPTED ? zvel[e] : 0.0;
-  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
+  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0, noshort = (p.flags & FLAG_NO_PINV_SHORTCUT) != 0;
   lds_sync();
   bool live = valid;
   int pend = 0, niter_sum = 0;
@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
     else if (l < ADIM) cs.act[l] = act_l;  // the physics substep overlays cs: re-stage the action every substep
     if (live && l < NV) { sm.kq[l] = sm.q[l]; sm.kv[l] = sm.v[l]; }  // DynamicModel::setState
     lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, l, live, g, wset);
-    else ctrl_jacobian(sm, cs, c, l, live, g);
+    if (CTRL == 2) ctrl_osc(sm, cs, c, l, live, g, wset, noshort);
+    else ctrl_jacobian(sm, cs, c, l, live, g, nullptr, noshort);
     const double cnew = c.act >= 0 ? cs.u[c.act] : 0.0;
     lds_sync();
     substep(sm, c, l, g, cnew, live, true, so);

@@ -22,7 +22,9 @@ enum {
   DBG_F = 425, DBG_QACC = 471, DBG_QACCH = 484, DBG_STRIDE = 512
 };
 
-enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2 };
+// 4 = CASSIE_WAVE_PER_ENV (host side: skip the 4-envs-per-wave kernels); 8 = tests only: take the literal SVD / eigen-decomposition
+// route of the controllers' pseudo-inverses even where the certified shortcut applies
+enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2, FLAG_NO_PINV_SHORTCUT = 8 };
 
 struct VecParams {
   double* state;          // [n_envs][ENV_STRIDE]

@@ -38,7 +38,9 @@ extern "C" {
 /* flags: 0 reproduces the reference bit-for-bit including its stale-state quirks */
 #define CASSIE_FIX_STALE_KIN 1
 #define CASSIE_FIX_STALE_QSTATE 2
-#define CASSIE_WAVE_PER_ENV 4 /* PD/torque: use only the wave-per-environment kernel (A/B and cross-check of the 4-envs-per-wave path) */
+#define CASSIE_WAVE_PER_ENV 4 /* use only the wave-per-environment kernels (A/B and cross-check of the 4-envs-per-wave path) */
+#define CASSIE_NO_PINV_SHORTCUT 8 /* tests: controllers evaluate pseudoinverse(.,tol) by SVD / eigen-decomposition even where the
+                                    certified inverse / normal-equations shortcut applies (same result) */
 
 #define CASSIE_NQ 13
 #define CASSIE_NOBS 26

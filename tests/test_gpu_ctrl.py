@@ -244,3 +244,29 @@ def test_osc_qp_hot_start_does_not_change_the_solution(vec):
         np.testing.assert_allclose(r[1, :26], r[0, :26], rtol=0, atol=1e-9)
         np.testing.assert_allclose(r[2, :26], r[0, :26], rtol=0, atol=1e-9)
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_pseudoinverse_shortcuts_agree_with_the_literal_svd_route(vec, mode):
+    """pseudoinverse(Jeq Hinv Jeq', 1e-3) and pseudoinverse(Nc Bt, 1e-4) (Cassie2d.cpp:134-171, OSC_RBDL.cpp:171) are evaluated
+    as a certified inverse / normal-equations solve when no singular value can be under the threshold; flag 8 forces the
+    eigen-decomposition / one-sided Jacobi SVD that applies the threshold literally.  Both must give the same torques."""
+    from cassierl_amd.vec_env import NO_PINV_SHORTCUT
+    n = 9
+    rng = np.random.default_rng(13)
+    a = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False)
+    b = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=NO_PINV_SHORTCUT)
+    a.reset_host(); b.reset_host()
+    s = a.get_full_state_host()
+    s[:, :13] += rng.uniform(-0.05, 0.05, (n, 13))
+    a.set_full_state_host(s)
+    for t in range(120):
+        acts = np.stack([osc_action(rng, 2.0) if mode == "OSC" else jac_action(rng) for _ in range(n)])
+        b.set_full_state_host(a.get_full_state_host())
+        a.substep_host(mode, acts, 1)
+        b.substep_host(mode, acts, 1)
+        sa, sb = a.get_full_state_host(), b.get_full_state_host()
+        np.testing.assert_allclose(sa[:, 78:84], sb[:, 78:84], rtol=0, atol=1e-8)   # torques
+        np.testing.assert_allclose(sa[:, :13], sb[:, :13], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(sa[:, 13:26], sb[:, 13:26], rtol=0, atol=1e-8)  # velocities: h * M^-1 * (rounding-level torque difference)
+    a.close(); b.close()
