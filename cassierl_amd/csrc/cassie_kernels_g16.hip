@@ -258,28 +258,28 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   const double scale = 1.0 / (CP_MEANINERTIA * NV);
   const double AttInv = 1.0 / Apart;
   bool sweeping = go;       // uniform inside a row: this environment still iterates
-  // row kinds of MY environment packed 4 bits per row, and wave-uniform "some environment has a single row / a
-  // contact pair at step K" masks: computed once per substep, not once per step of every sweep
-  unsigned long long kinds = 0ull;
-  unsigned anyS = 0u, anyP = 0u;
-  static_for<0, MAXR>([&](auto kk) {
-    constexpr int K = decltype(kk)::value;
-    const int kindK = row_bcast_int<K>(kind);
-    kinds |= (unsigned long long)kindK << (4 * K);
-    if (__ballot(kindK == RK_EQ || kindK == RK_LIM) != 0) anyS |= 1u << K;
-    if (__ballot(kindK == RK_CN) != 0) anyP |= 1u << K;
-  });
+  // wave-uniform "some environment has a single row / a contact pair at step K" masks: lane 16 g + K owns row K of environment g,
+  // so the four 16-bit fields of one ballot are OR-ed together
+  unsigned anyS, anyP;
+  {
+    const unsigned long long ms = __ballot(kind == RK_EQ || kind == RK_LIM), mp = __ballot(kind == RK_CN);
+    anyS = (unsigned)((ms | (ms >> 16) | (ms >> 32) | (ms >> 48)) & 0xFFFFull);
+    anyP = (unsigned)((mp | (mp >> 16) | (mp >> 32) | (mp >> 48)) & 0xFFFFull);
+  }
   double acc = 0.0;  // cost changes of the rows owned by this lane in the current sweep (summed over the row once per sweep)
+  // Every lane runs the update of ITS OWN row kind on its own (f, residual); only the result of the lane that owns row K is
+  // used at step K (row_bcast<K> / l == K), so the step functions need the lane's own kind, not the kind of row K.
+  const bool isS = (kind == RK_EQ) | (kind == RK_LIM), isLim = kind == RK_LIM, isN = kind == RK_CN;
+  const double hAdiag = 0.5 * Adiag, hApart = 0.5 * Apart;
+  bool sS = false, sN = false;  // this sweep: my environment still iterates and my row is a single row / a contact normal
   // one single-row step (connect or joint limit) at row K of every environment
   auto single_step = [&](auto kk) {
     constexpr int K = decltype(kk)::value;
-    const int kindK = (int)((kinds >> (4 * K)) & 15ull);
-    const bool doS = sweeping && (kindK == RK_EQ || kindK == RK_LIM);
     double cand = f - res * Ainv;
-    cand = ((kind == RK_LIM) & (cand < 0)) ? 0.0 : cand;
+    cand = isLim ? fmax(cand, 0.0) : cand;
     double d = cand - f;
-    double chg = d * (0.5 * d * Adiag + res);
-    const bool keep = (chg <= 1e-10) & doS;
+    double chg = d * (hAdiag * d + res);
+    const bool keep = (chg <= 1e-10) & sS;
     d = keep ? d : 0.0;
     acc += (keep & (l == K)) ? chg : 0.0;
     double Dd = row_bcast<K>(d);
@@ -289,18 +289,15 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   // one elliptic contact pair at rows (K, K+1), K even; branch-free so that steps can be scheduled across each other
   auto pair_step = [&](auto kk) {
     constexpr int K = decltype(kk)::value;
-    const int kindK = (int)((kinds >> (4 * K)) & 15ull);
-    const bool doP = sweeping && kindK == RK_CN;
     double rt = swap1(res), ot = swap1(f);
     double rn = res, on = f;
     double Ann = Adiag, Att = Apart;
     // normal-only update (taken when the normal force is ~0)
-    double fn_n = on - rn * Ainv;
-    fn_n = fn_n < 0 ? 0.0 : fn_n;
+    double fn_n = fmax(on - rn * Ainv, 0.0);
     // ray update
     double denom = on * (Ann * on + Ant * ot) + ot * (Ant * on + Att * ot);
     double x = -(on * rn + ot * rt) * fast_rcp(denom);
-    x = x < -1.0 ? -1.0 : x;
+    x = fmax(x, -1.0);
     x = denom >= MINVAL ? x : 0.0;
     const bool use_n = on < MINVAL;
     double fn = use_n ? fn_n : on + x * on;
@@ -314,8 +311,8 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     double ftc = on_cone ? __builtin_copysign(mu * fn, x0) : x0;
     ft = fn >= MINVAL ? ftc : ft;
     double dn = fn - on, dt = ft - ot;
-    double chg = dn * (0.5 * Ann * dn + Ant * dt + rn) + dt * (0.5 * Att * dt + rt);
-    const bool keep = (chg <= 1e-10) & doP;
+    double chg = dn * (hAdiag * dn + Ant * dt + rn) + dt * (hApart * dt + rt);
+    const bool keep = (chg <= 1e-10) & sN;
     dn = keep ? dn : 0.0; dt = keep ? dt : 0.0;
     acc += (keep & (l == K)) ? chg : 0.0;
     double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
@@ -330,6 +327,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
     acc = 0.0;
+    sS = sweeping & isS; sN = sweeping & isN;
     if (simple) {
       single_step(IC<0>{}); single_step(IC<1>{}); single_step(IC<2>{}); single_step(IC<3>{});
       pair_step(IC<4>{}); pair_step(IC<6>{});
