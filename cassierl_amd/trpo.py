@@ -15,7 +15,6 @@ product, the baseline's normal equations and the line-search statistics are aver
 the CPU tests), so all ranks take the identical step.  Episode returns are gathered once per batch (rollout.gather_returns).
 """
 import math
-import os
 
 import torch
 import torch.distributed as dist

@@ -3,7 +3,6 @@
 with the planar spec / 3-D oracle.  Run on the GPU box: python tests/gpu_check.py"""
 import os
 import sys
-import time
 
 import numpy as np
 

@@ -7,12 +7,11 @@ Tolerances (north_star: 1e-5 relative over 1000 steps):
     (a) teacher-forced per step over 1000 substeps at 1e-9, (b) free-running over the first 100 substeps at 1e-6.
 """
 import ctypes as ct
-import os
 
 import numpy as np
 import pytest
 
-from conftest import ROOT, state_vec
+from conftest import state_vec
 
 pytestmark = pytest.mark.gpu
 

@@ -155,7 +155,6 @@ def test_standing_pose_contacts_and_symmetry(o3, kat):
 def test_quaternion_integration_matches_rotation(o3):
     """Spin the floating base about a body axis in free flight: after t the orientation is the axis-angle rotation |w| t."""
     o3.set_contact_enabled(False); o3.set_gravity(0.0); o3.set_damping_scale(0.0)
-    import oracle_py
     q = np.zeros(21); q[3] = 1.0; q[2] = 5.0
     q[7:] = np.array(json.load(open(os.path.join(ROOT, "tests", "golden", "model3d_kat.json")))["qpos_init"])[7:]
     # lock the shape by spinning about the principal-ish z axis slowly: check only the kinematic relation qdot = 1/2 q * w
