@@ -255,14 +255,18 @@ class TRPO:
         loss, _ = surrogate()
         g = all_mean_(flat_grad(loss, pol))
 
+        # Fisher-vector products by double backprop through ONE graph of grad(KL): the KL and its gradient do not depend on v,
+        # so they are built once and only the second backward pass is repeated for each of the ~11 products
+        _, kl0 = surrogate()
+        gk = flat_grad(kl0, pol, retain_graph=True, create_graph=True)
+
         def Fvp(v):
-            _, kl = surrogate()
-            gk = flat_grad(kl, pol, retain_graph=True, create_graph=True)
-            hv = flat_grad(gk @ v, pol)
+            hv = flat_grad(gk @ v, pol, retain_graph=True)
             return all_mean_(hv) + self.reg_coeff * v
 
         descent = conjugate_gradient(Fvp, g, self.cg_iters)
         shs = 0.5 * (descent @ Fvp(descent))
+        del gk, kl0
         step = torch.sqrt(self.step_size / (shs + 1e-8)) * descent
         if not torch.isfinite(step).all():
             return dict(loss_before=float(loss), loss_after=float(loss), kl=0.0, backtracks=-1)
@@ -280,8 +284,17 @@ class TRPO:
 
     def train_iteration(self):
         from . import rollout as R
+        timing = getattr(self, "timing", False)  # synchronising timers: rollout (policy forward + Env.step) vs TRPO update
+        if timing:
+            import time
+            torch.cuda.synchronize(); t0 = time.perf_counter()
         batch = self.collect()
+        if timing:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
         stats = self.optimize(self.process(batch))
+        if timing:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            stats.update(seconds_rollout=t1 - t0, seconds_update=t2 - t1)
         er = batch["episode_returns"]
         cnt = all_sum_(torch.tensor([float(er.numel()), float(er.sum())], dtype=torch.float64, device=er.device))
         per_env = batch["rew"].sum(0)                       # the one gather of the rollout batch (N per rank)

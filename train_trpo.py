@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--control-mode", default="PD", choices=["PD", "Torque", "OSC"])
     ap.add_argument("--snapshot", default="")
     ap.add_argument("--load-policy", default="")
+    ap.add_argument("--timing", action="store_true", help="report rollout / update seconds separately (adds synchronisations)")
     args = ap.parse_args()
     import torch
     from cassierl_amd import rollout as R
@@ -37,6 +38,7 @@ def main():
     traj = Cassie2dTraj.from_arrays(d["time"], d["qpos"])
     algo = make_cassie_trpo(args.envs_per_gpu, kind=args.kind, control_mode=args.control_mode, device=local_rank if world > 1 else 0,
                             trajectory=traj, seed=1, batch_size=args.envs_per_gpu * world * args.horizon)
+    algo.timing = args.timing
     if args.load_policy:
         algo.load(args.load_policy)
     for _ in range(args.n_itr):
