@@ -44,7 +44,10 @@ extern "C" {
 
 #define CASSIE_NQ 13
 #define CASSIE_NOBS 26
-#define CASSIE_STATE_STRIDE 88 /* doubles per environment in the resident state block */
+#define CASSIE_STATE_STRIDE 88 /* doubles per environment in the resident state block:
+                                 *  0..12 qpos | 13..25 qvel | 26..38 qacc_warmstart | 39..64 qpos,qvel at the last setState (what
+                                 *  GetOperationalSpaceState sees) | 65..77 self.qstate of the env | 78..83 last mj_data->ctrl | 84 env time |
+                                 *  85 PGS iterations of the last call | 86 OSC QP working set (hot start; 0 = cold) | 87 unused */
 
 typedef struct CassieVec CassieVec;
 
