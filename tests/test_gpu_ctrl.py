@@ -65,8 +65,8 @@ def test_env_step_osc_golden_stream(vec, streams, traj):
     env.close()
 
 
-def _py_standing_osc(o, zpos, zvel):
-    s = o.opstate(0)
+def _py_standing_osc(o, zpos, zvel, flags=0):
+    s = o.opstate(flags)
     act = np.zeros(7)
     act[2] = 0.0; act[3] = 100.0 * (-5e-3 - s[7])
     act[4] = 0.0; act[5] = 100.0 * (-5e-3 - s[13])
@@ -270,3 +270,25 @@ def test_pseudoinverse_shortcuts_agree_with_the_literal_svd_route(vec, mode):
         np.testing.assert_allclose(sa[:, :13], sb[:, :13], rtol=0, atol=1e-11)
         np.testing.assert_allclose(sa[:, 13:26], sb[:, 13:26], rtol=0, atol=1e-8)  # velocities: h * M^-1 * (rounding-level torque difference)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("wave_per_env", [False, True])
+def test_standing_controller_osc_with_current_kinematics_flag(vec, oracle_mod, wave_per_env):
+    """CASSIE_FIX_STALE_KIN: the scripted controller reads the operational-space state of the CURRENT state instead of the
+    one of the last setState (quirk Q1/Q2 switched off), on both kernel generations."""
+    from cassierl_amd.vec_env import FIX_STALE_KIN, WAVE_PER_ENV
+    env = vec(2, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False, flags=FIX_STALE_KIN | (WAVE_PER_ENV if wave_per_env else 0))
+    env.reset_host()
+    o = oracle_mod.Oracle()
+    q0 = np.array([0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407] + [0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407])
+    o.reset(q0, np.zeros(13))
+    worst = 0.0
+    for blk in range(30):
+        env.standing_step_host("OSC", 0.85, 0.0, 10)
+        for _ in range(10):
+            _py_standing_osc(o, 0.85, 0.0, flags=1)
+        sg = env.get_full_state_host()
+        q1, v1 = o.state()
+        worst = max(worst, np.abs(sg[0, :13] - q1).max(), np.abs(sg[0, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+    assert worst < 1e-5, worst
+    env.close()
