@@ -162,6 +162,30 @@ class CassieVecEnv:
         self._chk(self.L.CassieVecReset(self.h, None if mask is None else mask.data_ptr(), out["obs"].data_ptr()))
         return out["obs"]
 
+    def reset_to(self, qpos, qvel, out=None, mask=None):
+        """Cassie2d::Reset with caller-provided states (float64 CUDA tensors [n_envs, 13]); returns the observation tensor."""
+        out = out or self.alloc()
+        self._chk(self.L.CassieVecResetTo(self.h, None if mask is None else mask.data_ptr(), qpos.data_ptr(), qvel.data_ptr(),
+                                          out["obs"].data_ptr()))
+        return out["obs"]
+
+    def get_state(self):
+        """GetGeneralState for every env: (qpos, qvel) float64 CUDA tensors [n_envs, 13]."""
+        import torch
+        dev = "cuda:%d" % self.device
+        q = torch.empty((self.n_envs, 13), dtype=torch.float64, device=dev)
+        v = torch.empty((self.n_envs, 13), dtype=torch.float64, device=dev)
+        self._chk(self.L.CassieVecGetState(self.h, q.data_ptr(), v.data_ptr()))
+        return q, v
+
+    def get_opstate(self):
+        """GetOperationalSpaceState for every env: float64 CUDA tensor [n_envs, 18] in operational_state_to_array order
+        (cassie2d_structs.py), computed like the reference from the kinematics of the last setState."""
+        import torch
+        x = torch.empty((self.n_envs, 18), dtype=torch.float64, device="cuda:%d" % self.device)
+        self._chk(self.L.CassieVecGetOpState(self.h, x.data_ptr()))
+        return x
+
     def step(self, actions, out=None, terminal_obs=None):
         """actions: float64 CUDA tensor [n_envs, adim].  Returns (obs, reward, done) tensors (views of `out`)."""
         out = out or self.alloc()

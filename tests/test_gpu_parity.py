@@ -302,3 +302,50 @@ def test_g16_and_wave_per_env_kernels_agree(vec, traj):
         np.testing.assert_allclose(sa[:, :26], sb[:, :26], rtol=0, atol=1e-8)
         np.testing.assert_allclose(sa[:, 84], sb[:, 84], atol=1e-12)  # env time
     a.close(); b.close()
+
+
+def test_masked_reset_to_states_and_device_getters(vec, oracle_mod):
+    """CassieVecResetTo (Cassie2d::Reset with caller states, masked), CassieVecGetState and CassieVecGetOpState on device
+    tensors against the oracle: Reset = mj_forward without setState, so the op-space state is still the one of the previous
+    setState (quirk Q2) while qpos/qvel are the new ones."""
+    import torch
+    n = 11
+    rng = np.random.default_rng(23)
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False)
+    env.reset_host()
+    os_ = [oracle_mod.Oracle() for _ in range(n)]
+    q0 = np.array([0.0, 0.939, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407] + [0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407])
+    for o in os_:
+        o.reset(q0, np.zeros(13))                      # Cassie2dEnv.reset pose (the constructor pose differs in the 8th digit)
+    acts = rng.uniform(-1, 1, (n, 6)) * TQ * 0.3
+    env.step_host(acts)                                # one Env.step so that a setState has happened
+    for i, o in enumerate(os_):
+        for _ in range(10):
+            o.step_torque(acts[i])
+    qn = q0 + rng.uniform(-0.05, 0.05, (n, 13))
+    vn = rng.uniform(-0.3, 0.3, (n, 13))
+    mask = (np.arange(n) % 3 != 0)
+    obs = env.reset_to(torch.as_tensor(qn, device="cuda"), torch.as_tensor(vn, device="cuda"), mask=torch.as_tensor(mask.astype(np.uint8), device="cuda"))
+    q, v = env.get_state()
+    x = env.get_opstate()
+    env.synchronize()
+    q, v, x, obs = q.cpu().numpy(), v.cpu().numpy(), x.cpu().numpy(), obs.cpu().numpy()
+    for i, o in enumerate(os_):
+        if mask[i]:
+            o.reset(qn[i], vn[i])
+        qo, vo = o.state()
+        tol = 1e-12 if mask[i] else 1e-10   # untouched envs carry 10 free-running substeps of rounding
+        np.testing.assert_allclose(q[i], qo, atol=tol)
+        np.testing.assert_allclose(v[i], vo, atol=tol * 100)
+        np.testing.assert_allclose(x[i], o.opstate(0), atol=1e-9)
+    # one more step from the mixed states: warm start / kinematics bookkeeping of reset and non-reset envs stays consistent
+    acts = rng.uniform(-1, 1, (n, 6)) * TQ * 0.3
+    env.step_host(acts)
+    q, v = env.get_state_host()
+    for i, o in enumerate(os_):
+        for _ in range(10):
+            o.step_torque(acts[i])
+        qo, vo = o.state()
+        np.testing.assert_allclose(q[i], qo, atol=1e-9)
+        np.testing.assert_allclose(v[i], vo, atol=1e-7)
+    env.close()
