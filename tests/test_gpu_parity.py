@@ -349,3 +349,33 @@ def test_masked_reset_to_states_and_device_getters(vec, oracle_mod):
         np.testing.assert_allclose(q[i], qo, atol=1e-9)
         np.testing.assert_allclose(v[i], vo, atol=1e-7)
     env.close()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_terminal_observation_on_a_caller_stream(vec, streams, traj, flags):
+    """CassieVecStep's optional terminal_obs output (the observation the reference's Env.step returns before its caller
+    resets) through the device-tensor API on a caller-owned HIP stream (CassieVecSetStream), both kernel generations."""
+    import torch
+    n = 5
+    env = vec(n, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True, flags=flags)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        env.use_torch_stream()
+        out = env.alloc()
+        term = torch.zeros((n, 26), dtype=torch.float64, device="cuda")
+        env.reset(out)
+        acts = streams["walk_pd_actions"]
+        saw_done = False
+        for t in range(40):
+            a = torch.as_tensor(np.tile(acts[t], (n, 1)), device="cuda")
+            obs, rew, done = env.step(a, out, terminal_obs=term)
+            stream.synchronize()
+            d = bool(streams["walk_pd_done"][t])
+            saw_done |= d
+            assert (done.cpu().numpy().astype(bool) == d).all()
+            np.testing.assert_allclose(term.cpu().numpy(), np.tile(streams["walk_pd_obs"][t], (n, 1)), rtol=0, atol=2e-7)
+            exp = streams["walk_pd_reset_obs"][t] if d else streams["walk_pd_obs"][t]
+            np.testing.assert_allclose(obs.cpu().numpy(), np.tile(exp, (n, 1)), rtol=0, atol=2e-7)
+    assert saw_done
+    env.close()
