@@ -379,3 +379,28 @@ def test_terminal_observation_on_a_caller_stream(vec, streams, traj, flags):
             np.testing.assert_allclose(obs.cpu().numpy(), np.tile(exp, (n, 1)), rtol=0, atol=2e-7)
     assert saw_done
     env.close()
+
+
+def test_error_behaviour_of_the_batched_abi(vec):
+    """int error codes + CassieVecLastError instead of the reference's process exit (mju_error, Cassie2d.cpp:49-52)."""
+    import ctypes as ct2
+    import torch
+    from cassierl_amd import _lib
+    L = _lib.load()
+    h = ct2.c_void_p()
+    cfg = _lib.CassieVecConfig(0, 0, 10, 0, 1)
+    assert L.CassieVecCreate(ct2.byref(h), 0, 0, ct2.byref(cfg)) != 0          # n_envs must be positive
+    assert L.CassieVecCreate(ct2.byref(h), 4, 99, ct2.byref(cfg)) != 0         # no such device
+    with pytest.raises(AssertionError, match="Invalid Control Mode"):           # cassie2d.py:53
+        vec(2, control_mode="Velocity")
+    env = vec(4, kind="walk", control_mode="PD")
+    out = env.alloc()
+    a = torch.zeros((4, 6), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError, match="CassieVecSetTrajectory"):           # walk reward needs the gait table
+        env.step(a, out)
+    rc = L.CassieVecStep(env.h, None, out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(), None)
+    assert rc != 0 and b"null" in L.CassieVecLastError(env.h)
+    assert L.CassieVecSubstep(env.h, 0, a.data_ptr(), 0) != 0                   # n_sub must be positive
+    assert L.CassieVecStandingStep(env.h, 0, a.data_ptr(), a.data_ptr(), 1) != 0  # scripted controllers exist for OSC / Jacobian only
+    assert L.CassieVecNumEnvs(env.h) == 4 and L.CassieVecActionDim(env.h) == 6
+    env.close()
