@@ -126,27 +126,6 @@ __device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
   });
 }
 
-// mju_QCQP2 (values are wave-uniform, so is the control flow).  Divisions are rcp + two Newton steps (~1 ulp): an IEEE f64
-// division is ~25 dependent instructions and the contact update sits on the serial critical path of the solver.
-__device__ __forceinline__ bool qcqp2(double* res, double A11, double A12, double A22, double b1, double b2, double d, double r) {
-  b1 *= d; b2 *= d; A11 *= d * d; A22 *= d * d; A12 *= d * d;
-  double la = 0, v1 = 0, v2 = 0;
-  for (int iter = 0; iter < 20; iter++) {
-    double det = (A11 + la) * (A22 + la) - A12 * A12;
-    if (det < 1e-10) { res[0] = 0; res[1] = 0; return false; }
-    double detinv = fast_rcp(det), P11 = (A22 + la) * detinv, P22 = (A11 + la) * detinv, P12 = -A12 * detinv;
-    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
-    double val = v1 * v1 + v2 * v2 - r * r;
-    if (val < 1e-10) break;
-    double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
-    double delta = -val * fast_rcp(deriv);
-    if (delta < 1e-10) break;
-    la += delta;
-  }
-  res[0] = v1 * d; res[1] = v2 * d;
-  return la != 0;
-}
-
 struct Out3 { int niter, nefc; bool overflow; };
 
 // ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
@@ -514,49 +493,76 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
       if (kindK == K_EQ || kindK == K_LIM) {
         const double fK = rdlane_dyn(f, K), rK = rdlane_dyn(res, K), AKK = rdlane_dyn(Adiag, K), AKKinv = rdlane_dyn(Ainv, K);
         double nf = fK - rK * AKKinv;
-        if (kindK == K_LIM && nf < 0) nf = 0.0;
+        nf = kindK == K_LIM ? fmax(nf, 0.0) : nf;  // kindK is in an SGPR: a scalar select, no branch
         double dK = nf - fK;
         const double chg = 0.5 * dK * AKK * dK + dK * rK;
-        if (chg > 1e-10) dK = 0.0; else improvement -= chg;
+        const bool keep = chg <= 1e-10;
+        dK = keep ? dK : 0.0;
+        improvement -= keep ? chg : 0.0;
         res += sm.A[K][rl] * dK;
         if (lane == K) f += dK;
       } else {  // contact: rows K (normal), K+1, K+2 (tangents)
         const double o0 = rdlane_dyn(f, K), o1 = rdlane_dyn(f, K + 1), o2 = rdlane_dyn(f, K + 2);
         const double r0 = rdlane_dyn(res, K), r1 = rdlane_dyn(res, K + 1), r2 = rdlane_dyn(res, K + 2);
+        // symmetric 3x3 diagonal block of A (the mirrored entries agree to rounding; one of each pair is read)
         const double A00 = sm.A[K][K], A01 = sm.A[K][K + 1], A02 = sm.A[K][K + 2];
-        const double A10 = sm.A[K + 1][K], A11 = sm.A[K + 1][K + 1], A12 = sm.A[K + 1][K + 2];
-        const double A20 = sm.A[K + 2][K], A21 = sm.A[K + 2][K + 1], A22 = sm.A[K + 2][K + 2];
-        double f0 = o0, f1 = o1, f2 = o2;
-        if (f0 < MINVAL) {  // normal update
-          f0 -= r0 * rdlane_dyn(Ainv, K);
-          if (f0 < 0) f0 = 0.0;
-          f1 = 0.0; f2 = 0.0;
-        } else {  // ray update
-          const double v1_0 = A00 * f0 + A01 * f1 + A02 * f2, v1_1 = A10 * f0 + A11 * f1 + A12 * f2, v1_2 = A20 * f0 + A21 * f1 + A22 * f2;
-          const double denom = f0 * v1_0 + f1 * v1_1 + f2 * v1_2;
-          if (denom >= MINVAL) {
-            double x = -(f0 * r0 + f1 * r1 + f2 * r2) * fast_rcp(denom);
-            if (f0 + x * f0 < 0) x = -1.0;  // -f/v[0] with v[0] = f
-            const double g0 = f0, g1 = f1, g2 = f2;
-            f0 += x * g0; f1 += x * g1; f2 += x * g2;
+        const double A11 = sm.A[K + 1][K + 1], A12 = sm.A[K + 1][K + 2], A22 = sm.A[K + 2][K + 2];
+        // Straight-line selects instead of branches: every value here is wave-uniform, but the compiler cannot know that and
+        // would emit exec-mask branches (VALU compare -> SALU -> taken branch) on the critical path of the solver.
+        // normal-only update (taken when the normal force is ~0)
+        const double fn_n = fmax(o0 - r0 * rdlane_dyn(Ainv, K), 0.0);
+        // ray update: scale the force vector by (1 + x), x clamped so that the normal force stays >= 0
+        const double v1_0 = A00 * o0 + A01 * o1 + A02 * o2, v1_1 = A01 * o0 + A11 * o1 + A12 * o2, v1_2 = A02 * o0 + A12 * o1 + A22 * o2;
+        const double denom = o0 * v1_0 + o1 * v1_1 + o2 * v1_2;
+        double x = -(o0 * r0 + o1 * r1 + o2 * r2) * fast_rcp(denom);
+        x = fmax(x, -1.0);
+        x = denom >= MINVAL ? x : 0.0;
+        const bool use_n = o0 < MINVAL;
+        const double f0 = use_n ? fn_n : o0 + x * o0;
+        double f1 = use_n ? 0.0 : o1 + x * o1, f2 = use_n ? 0.0 : o2 + x * o2;
+        {  // friction: QCQP on the cone given the normal force (result used only if f0 >= MINVAL)
+          const double bc1 = r1 - (A11 * o1 + A12 * o2) + A01 * (f0 - o0);
+          const double bc2 = r2 - (A12 * o1 + A22 * o2) + A02 * (f0 - o0);
+          // mju_QCQP2, first Newton iterate (lambda = 0) inline; further iterates only for a sliding contact
+          const double b1 = bc1 * mu, b2 = bc2 * mu, Q11 = A11 * (mu * mu), Q22 = A22 * (mu * mu), Q12 = A12 * (mu * mu);
+          const double det0 = Q11 * Q22 - Q12 * Q12;
+          const double di0 = fast_rcp(det0);
+          double v1 = -(Q22 * di0) * b1 + (Q12 * di0) * b2, v2 = (Q12 * di0) * b1 - (Q11 * di0) * b2;
+          const double val0 = v1 * v1 + v2 * v2 - f0 * f0;
+          double la = 0.0;
+          bool degenerate = det0 < 1e-10;
+          if (__ballot(!degenerate && val0 >= 1e-10 && f0 >= MINVAL) != 0) {  // wave-uniform: sliding contact
+            double val = val0, P11 = Q22 * di0, P22 = Q11 * di0, P12 = -Q12 * di0;
+            for (int it = 0; it < 20; it++) {
+              const double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+              const double delta = -val * fast_rcp(deriv);
+              if (delta < 1e-10) break;
+              la += delta;
+              if (it == 19) break;  // iteration budget of mju_QCQP2: the last multiplier is kept, v is not recomputed
+              const double det = (Q11 + la) * (Q22 + la) - Q12 * Q12;
+              if (det < 1e-10) { degenerate = true; break; }
+              const double di = fast_rcp(det);
+              P11 = (Q22 + la) * di; P22 = (Q11 + la) * di; P12 = -Q12 * di;
+              v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+              val = v1 * v1 + v2 * v2 - f0 * f0;
+              if (val < 1e-10) break;
+            }
           }
-        }
-        if (f0 >= MINVAL) {  // friction: QCQP on the cone given the normal force
-          double bc1 = r1 - (A11 * o1 + A12 * o2) + A10 * (f0 - o0);
-          double bc2 = r2 - (A21 * o1 + A22 * o2) + A20 * (f0 - o0);
-          double vq[2];
-          const bool act = qcqp2(vq, A11, A12, A22, bc1, bc2, mu, f0);
-          if (act) {
-            double s = (vq[0] * vq[0] + vq[1] * vq[1]) * (1.0 / (MU * MU));
+          double q1 = degenerate ? 0.0 : v1 * mu, q2 = degenerate ? 0.0 : v2 * mu;
+          if (la != 0.0 && !degenerate) {  // active constraint: put the friction exactly on the cone
+            double s = (q1 * q1 + q2 * q2) * (1.0 / (MU * MU));
             s = sqrt(f0 * f0 * fast_rcp(s > MINVAL ? s : MINVAL));
-            vq[0] *= s; vq[1] *= s;
+            q1 *= s; q2 *= s;
           }
-          f1 = vq[0]; f2 = vq[1];
+          const bool fr = f0 >= MINVAL;
+          f1 = fr ? q1 : f1; f2 = fr ? q2 : f2;
         }
         double d0 = f0 - o0, d1 = f1 - o1, d2 = f2 - o2;
-        const double chg = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A10 * d0 + A11 * d1 + A12 * d2) + d2 * (A20 * d0 + A21 * d1 + A22 * d2)) +
+        const double chg = 0.5 * (d0 * (A00 * d0 + A01 * d1 + A02 * d2) + d1 * (A01 * d0 + A11 * d1 + A12 * d2) + d2 * (A02 * d0 + A12 * d1 + A22 * d2)) +
                            d0 * r0 + d1 * r1 + d2 * r2;
-        if (chg > 1e-10) { d0 = 0.0; d1 = 0.0; d2 = 0.0; } else improvement -= chg;
+        const bool keep = chg <= 1e-10;
+        d0 = keep ? d0 : 0.0; d1 = keep ? d1 : 0.0; d2 = keep ? d2 : 0.0;
+        improvement -= keep ? chg : 0.0;
         res += sm.A[K][rl] * d0 + sm.A[K + 1][rl] * d1 + sm.A[K + 2][rl] * d2;
         if (lane == K) f += d0;
         if (lane == K + 1) f += d1;
