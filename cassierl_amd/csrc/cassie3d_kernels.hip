@@ -486,19 +486,23 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
   // ================= PGS (mj_solPGS, elliptic cones)
   const double scale = 1.0 / (MEANINERTIA * NV);
   int niter = 0;
+  const bool isLim = kind == K_LIM;
+  const double hAdiag = 0.5 * Adiag;
   for (int iter = 0; iter < ITERATIONS; iter++) {
-    double improvement = 0.0;
+    double improvement = 0.0;  // contact rows: wave-uniform; single rows: accumulated on the owner lane, reduced once per sweep
+    double acc = 0.0;
     for (int K = 0; K < nrows; K++) {
       const int kindK = __builtin_amdgcn_readlane(kind, K);
       if (kindK == K_EQ || kindK == K_LIM) {
-        const double fK = rdlane_dyn(f, K), rK = rdlane_dyn(res, K), AKK = rdlane_dyn(Adiag, K), AKKinv = rdlane_dyn(Ainv, K);
-        double nf = fK - rK * AKKinv;
-        nf = kindK == K_LIM ? fmax(nf, 0.0) : nf;  // kindK is in an SGPR: a scalar select, no branch
-        double dK = nf - fK;
-        const double chg = 0.5 * dK * AKK * dK + dK * rK;
+        // every lane evaluates the single-row update of ITS OWN row from its own registers; only lane K's result is used
+        double nf = f - res * Ainv;
+        nf = isLim ? fmax(nf, 0.0) : nf;
+        double dOwn = nf - f;
+        const double chg = dOwn * (hAdiag * dOwn + res);
         const bool keep = chg <= 1e-10;
-        dK = keep ? dK : 0.0;
-        improvement -= keep ? chg : 0.0;
+        dOwn = keep ? dOwn : 0.0;
+        acc += (keep && lane == K) ? chg : 0.0;
+        const double dK = rdlane_dyn(dOwn, K);
         res += sm.A[K][rl] * dK;
         if (lane == K) f += dK;
       } else {  // contact: rows K (normal), K+1, K+2 (tangents)
@@ -571,6 +575,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
       }
     }
     niter = iter + 1;
+    improvement -= wave_sum(acc);
     if (improvement * scale < TOLERANCE) break;
   }
   out.niter = nrows > 0 ? niter : 0;
