@@ -17,6 +17,12 @@
  * (b) golden vectors generated from the two importable reference Python modules,
  * (c) physics invariants (tests/test_oracle_physics.py).
  *
+ * The same Part 1/2 source compiled with -DORC_CASSIE3D (liboracle3d.so, oracle/cassie3d_model.h) is the oracle of the Cassie3d
+ * kernels: floating base (3 world translations + unit quaternion, body-frame angular velocity, mju_quatIntegrate) + 14 hinges
+ * of model/cassie3d_stiff.xml.  The reference has no Cassie3d step at all (MJCF only), so that build is PARITY UNPINNED too; it is
+ * pinned by numpy known-answer values of the MJCF (tests/golden/model3d_kat.json) and mechanics invariants (tests/test_oracle3d.py).
+ * Only orc_create/free/reset/step_torque/forward/get_* and the test hooks exist in that build (qpos has 21 entries, qvel 20, ctrl 10).
+ *
  * Deliberately written as a GENERAL 3-D articulated-body pipeline (22 bodies,
  * 3 constraint rows per contact / connect) so that it shares no formulation with the
  * planar HIP kernels it checks.
