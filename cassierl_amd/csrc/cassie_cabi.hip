@@ -436,7 +436,7 @@ static_assert(CASSIE3D_STATE_STRIDE == cassie3d::ENV3_STRIDE && CASSIE3D_NQ == c
 
 struct Cassie3dVec {
   int n = 0, device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, own_stream = nullptr;  // kernels run on `stream`; `own_stream` is the one this handle created
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
   int* pending = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -477,24 +477,27 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (device < 0 || device >= ndev) return CASSIE_EINVAL;
   Cassie3dVec* h = new Cassie3dVec();
   h->n = n_envs; h->device = device;
-  HIPCHK3(h, hipSetDevice(device));
-  HIPCHK3(h, hipStreamCreate(&h->stream));
-  HIPCHK3(h, hipEventCreate(&h->ev0));
-  HIPCHK3(h, hipEventCreate(&h->ev1));
-  HIPCHK3(h, hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)));
-  HIPCHK3(h, hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)));
-  HIPCHK3(h, hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)));
+  auto bail = [&](int code) { Cassie3dVecFree(h); return code; };
+  if (hipSetDevice(device) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipStreamCreate(&h->stream) != hipSuccess) return bail(CASSIE_EHIP);
+  h->own_stream = h->stream;
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
-  return Cassie3dVecReset(h, nullptr, nullptr);
+  return CASSIE_OK;
 }
 
 void Cassie3dVecFree(Cassie3dVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending);
-  hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
-  hipStreamDestroy(h->stream);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
 }
 
@@ -503,7 +506,7 @@ const char* Cassie3dVecLastError(const Cassie3dVec* h) { return h ? h->err.c_str
 int Cassie3dVecSetStream(Cassie3dVec* h, void* s) {
   if (!h) return CASSIE_EINVAL;
   HIPCHK3(h, hipStreamSynchronize(h->stream));
-  h->stream = s ? (hipStream_t)s : h->stream;
+  h->stream = s ? (hipStream_t)s : h->own_stream;  // NULL: back to the handle's own stream
   return CASSIE_OK;
 }
 
