@@ -78,6 +78,33 @@ class GaussianMLPPolicy(nn.Module):
         return (num / (2 * new_std ** 2 + 1e-8) + new_log_std - old_log_std).sum(-1)
 
 
+def gram(X, y, chunk=2048):
+    """(X'X, X'y) for a tall-skinny X [N, F].  One GEMM with K = N is pathological in rocBLAS (56 ms for 524 288 x 58 in
+    FP64 on MI355X); a batch of K = `chunk` GEMMs summed afterwards does the same arithmetic in 0.2 ms."""
+    Z = torch.cat([X, y.unsqueeze(-1)], dim=-1)
+    n, f = Z.shape
+    m = (n // chunk) * chunk
+    G = torch.zeros((f, f), dtype=Z.dtype, device=Z.device)
+    if m:
+        Zc = Z[:m].view(n // chunk, chunk, f)
+        G += torch.bmm(Zc.transpose(1, 2), Zc).sum(0)
+    if m < n:
+        G += Z[m:].T @ Z[m:]
+    return G[:-1, :-1], G[:-1, -1]
+
+
+def tmatmul(A, B, chunk=2048):
+    """A' B for tall-skinny A [N, p], B [N, q] (a reduction over N): chunked for the same reason as gram()."""
+    n = A.shape[0]
+    m = (n // chunk) * chunk
+    out = torch.zeros((A.shape[1], B.shape[1]), dtype=A.dtype, device=A.device)
+    if m:
+        out += torch.bmm(A[:m].view(n // chunk, chunk, -1).transpose(1, 2), B[:m].view(n // chunk, chunk, -1)).sum(0)
+    if m < n:
+        out += A[m:].T @ B[m:]
+    return out
+
+
 class LinearFeatureBaseline:
     """Ridge regression of the discounted return on [o, o^2, t, t^2, t^3, 1], o clipped to [-10, 10], t = step/100."""
 
@@ -93,8 +120,8 @@ class LinearFeatureBaseline:
     def fit(self, obs, t, returns):
         X = self.features(obs, t).double()
         y = returns.double()
-        A = all_sum_(X.T @ X)
-        b = all_sum_(X.T @ y)
+        A, b = gram(X, y)
+        A, b = all_sum_(A.contiguous()), all_sum_(b.contiguous())
         reg = self.reg_coeff
         eye = torch.eye(A.shape[0], dtype=A.dtype, device=A.device)
         for _ in range(5):
@@ -167,6 +194,57 @@ def conjugate_gradient(Avp, b, iters=10, tol=1e-10):
         p = r + (rr_new / rr) * p
         rr = rr_new
     return x
+
+
+class AnalyticFisher:
+    """Fisher-vector products of the Gaussian tanh-MLP policy in closed form (what rllab's `hvp_approach` gets by double
+    backprop through mean-KL): F v = (1/N) J' S J v for the mean network (J = d mean / d theta by forward mode, S the
+    precision of the old Gaussian) plus a diagonal block for log_std.  Activations of the OLD policy are computed once per
+    TRPO update; a product is then ~8 GEMMs and a handful of element-wise kernels instead of ~100 autograd kernels."""
+
+    def __init__(self, policy, obs, eps=1e-8):
+        lin = [m for m in policy.mean_net if isinstance(m, nn.Linear)]
+        act_ok = all(isinstance(m, (nn.Linear, nn.Tanh)) for m in policy.mean_net)
+        if len(lin) != 3 or not act_ok:
+            raise ValueError("AnalyticFisher covers the two-hidden-layer tanh policy of trpo_cassie.py only")
+        self.names = [n for n, _ in policy.named_parameters()]
+        self.shapes = [tuple(p.shape) for p in policy.parameters()]
+        with torch.no_grad():
+            self.W = [l.weight.detach().clone() for l in lin]
+            self.X = obs
+            self.H1 = torch.tanh(torch.addmm(lin[0].bias, obs, self.W[0].T))
+            self.H2 = torch.tanh(torch.addmm(lin[1].bias, self.H1, self.W[1].T))
+            self.D1, self.D2 = 1 - self.H1 * self.H1, 1 - self.H2 * self.H2
+            var = (2 * policy.log_std.detach()).exp()
+            self.prec = 2.0 / (2.0 * var + eps)                                   # d2 KL / d mean^2 (with kl()'s epsilon)
+            self.h_ls = 4.0 * var * (2.0 * var - eps) / (2.0 * var + eps) ** 2     # d2 KL / d log_std^2
+            self.n = obs.shape[0]
+
+    @torch.no_grad()
+    def __call__(self, v):
+        parts, i = {}, 0
+        for n, shp in zip(self.names, self.shapes):
+            k = int(torch.tensor(shp).prod()) if len(shp) else 1
+            parts[n] = v[i:i + k].view(shp)
+            i += k
+        dW1, db1 = parts["mean_net.0.weight"], parts["mean_net.0.bias"]
+        dW2, db2 = parts["mean_net.2.weight"], parts["mean_net.2.bias"]
+        dW3, db3 = parts["mean_net.4.weight"], parts["mean_net.4.bias"]
+        X, H1, H2, D1, D2 = self.X, self.H1, self.H2, self.D1, self.D2
+        W1, W2, W3 = self.W
+        # forward mode: directional derivative of the mean
+        dH1 = D1 * torch.addmm(db1, X, dW1.T)
+        dH2 = D2 * (torch.addmm(db2, dH1, W2.T) + H1 @ dW2.T)
+        dmu = torch.addmm(db3, dH2, W3.T) + H2 @ dW3.T
+        w = dmu * (self.prec / self.n)
+        # reverse mode
+        out = {"log_std": self.h_ls * parts["log_std"]}
+        out["mean_net.4.weight"], out["mean_net.4.bias"] = tmatmul(w, H2), w.sum(0)
+        g2 = (w @ W3) * D2
+        out["mean_net.2.weight"], out["mean_net.2.bias"] = tmatmul(g2, H1), g2.sum(0)
+        g1 = (g2 @ W2) * D1
+        out["mean_net.0.weight"], out["mean_net.0.bias"] = tmatmul(g1, X), g1.sum(0)
+        return torch.cat([out[n].reshape(-1) for n in self.names])
 
 
 # --------------------------------------------------------------------------------------------- TRPO
@@ -255,18 +333,24 @@ class TRPO:
         loss, _ = surrogate()
         g = all_mean_(flat_grad(loss, pol))
 
-        # Fisher-vector products by double backprop through ONE graph of grad(KL): the KL and its gradient do not depend on v,
-        # so they are built once and only the second backward pass is repeated for each of the ~11 products
-        _, kl0 = surrogate()
-        gk = flat_grad(kl0, pol, retain_graph=True, create_graph=True)
+        # Fisher-vector products: closed form for the tanh-MLP Gaussian policy; otherwise double backprop through ONE graph of
+        # grad(KL) (the KL and its gradient do not depend on v: only the second backward pass is repeated per product)
+        gk = kl0 = None
+        try:
+            fisher = AnalyticFisher(pol, obs) if getattr(self, "analytic_fisher", True) else None
+        except ValueError:
+            fisher = None
+        if fisher is None:
+            _, kl0 = surrogate()
+            gk = flat_grad(kl0, pol, retain_graph=True, create_graph=True)
 
         def Fvp(v):
-            hv = flat_grad(gk @ v, pol, retain_graph=True)
+            hv = fisher(v) if fisher is not None else flat_grad(gk @ v, pol, retain_graph=True)
             return all_mean_(hv) + self.reg_coeff * v
 
         descent = conjugate_gradient(Fvp, g, self.cg_iters)
         shs = 0.5 * (descent @ Fvp(descent))
-        del gk, kl0
+        del gk, kl0, fisher
         step = torch.sqrt(self.step_size / (shs + 1e-8)) * descent
         if not torch.isfinite(step).all():
             return dict(loss_before=float(loss), loss_after=float(loss), kl=0.0, backtracks=-1)

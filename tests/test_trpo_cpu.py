@@ -187,3 +187,35 @@ def test_data_parallel_update_equals_single_process():
         assert p.exitcode == 0
     np.testing.assert_allclose(theta, ref.numpy(), rtol=0, atol=1e-9)
     assert st["backtracks"] == st_ref["backtracks"] and abs(st["kl"] - st_ref["kl"]) < 1e-10
+
+
+def test_analytic_fisher_matches_double_backprop():
+    """F v in closed form (AnalyticFisher) against rllab-style double backprop through mean-KL, float64."""
+    import torch
+    from cassierl_amd.trpo import AnalyticFisher, GaussianMLPPolicy, flat_grad
+    torch.manual_seed(0)
+    pol = GaussianMLPPolicy(26, 6, (32, 32), init_std=2.0, dtype=torch.float64)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    obs = torch.randn(500, 26, dtype=torch.float64)
+    old_mean, old_lstd = [t.detach() for t in pol.dist_info(obs)]
+    mean, lstd = pol.dist_info(obs)
+    kl = pol.kl(old_mean, old_lstd, mean, lstd).mean()
+    gk = flat_grad(kl, pol, retain_graph=True, create_graph=True)
+    fisher = AnalyticFisher(pol, obs)
+    for _ in range(4):
+        v = torch.randn(sum(p.numel() for p in pol.parameters()), dtype=torch.float64)
+        ref = flat_grad(gk @ v, pol, retain_graph=True)
+        got = fisher(v)
+        assert torch.allclose(got, ref, rtol=1e-9, atol=1e-12), float((got - ref).abs().max())
+
+
+def test_chunked_gram_matches_plain_products():
+    import torch
+    from cassierl_amd.trpo import gram
+    torch.manual_seed(1)
+    for n in (5, 2048, 5000, 8192):
+        X, y = torch.randn(n, 7, dtype=torch.float64), torch.randn(n, dtype=torch.float64)
+        A, b = gram(X, y, chunk=2048)
+        assert torch.allclose(A, X.T @ X, rtol=1e-12, atol=1e-10) and torch.allclose(b, X.T @ y, rtol=1e-12, atol=1e-10)
