@@ -11,7 +11,7 @@ python3 bench.py --steps 50 --warmup 10 > "$out/bench_4096.json" 2> "$out/bench_
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --envs-per-gpu 65536 > "$out/bench_65536.json" 2> "$out/bench_65536.err"
 python3 tests/bench_configs.py > "$out/other_configs.jsonl" 2> /dev/null
 python3 tests/bench_cassie3d.py --cpu-baseline >> "$out/other_configs.jsonl" 2> /dev/null
-python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 4 > "$out/trpo_65536.jsonl" 2> /dev/null
+python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --timing > "$out/trpo_65536.jsonl" 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations of the same command as the bench line (kernel trace + stats only)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 "$root/bench.py" --steps 50 --warmup 10 --no-cpu-baseline > "$out/stats_bench.log" 2>&1
