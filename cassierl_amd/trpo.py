@@ -283,7 +283,8 @@ class TRPO:
         rew_b = torch.empty((T, N), dtype=torch.float64, device=dev)
         done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
         t_b = torch.empty((T, N), dtype=torch.int64, device=dev)
-        finished = []
+        ep_n = torch.zeros((), dtype=torch.float64, device=dev)   # finished episodes / their summed returns, kept on the
+        ep_sum = torch.zeros((), dtype=torch.float64, device=dev) # device: boolean-mask indexing would synchronise every step
         for t in range(T):
             o = self.obs.to(pol_dtype)
             a, mean, log_std = self.policy.get_actions(o, self.gen)
@@ -295,12 +296,13 @@ class TRPO:
             self.path_t += 1
             cut = done | (self.path_t >= self.max_path_length)  # rllab truncates paths at max_path_length
             done_b[t] = cut
-            finished.append(self.path_ret[cut].clone())
-            self.path_ret[cut] = 0.0
-            self.path_t[cut] = 0
+            ep_n += cut.sum()
+            ep_sum += torch.where(cut, self.path_ret, torch.zeros_like(self.path_ret)).sum()
+            self.path_ret = torch.where(cut, torch.zeros_like(self.path_ret), self.path_ret)
+            self.path_t = torch.where(cut, torch.zeros_like(self.path_t), self.path_t)
             self.obs = nobs.clone()
         return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
-                    episode_returns=torch.cat(finished) if finished else torch.zeros(0, device=dev))
+                    episode_count=ep_n, episode_return_sum=ep_sum)
 
     def process(self, batch):
         T, N = batch["rew"].shape
@@ -379,8 +381,7 @@ class TRPO:
         if timing:
             torch.cuda.synchronize(); t2 = time.perf_counter()
             stats.update(seconds_rollout=t1 - t0, seconds_update=t2 - t1)
-        er = batch["episode_returns"]
-        cnt = all_sum_(torch.tensor([float(er.numel()), float(er.sum())], dtype=torch.float64, device=er.device))
+        cnt = all_sum_(torch.stack([batch["episode_count"], batch["episode_return_sum"]]))
         per_env = batch["rew"].sum(0)                       # the one gather of the rollout batch (N per rank)
         stats.update(itr=self.itr, env_steps=batch["rew"].numel() * _world(), episodes=int(cnt[0]),
                      avg_return=float(cnt[1] / cnt[0]) if cnt[0] > 0 else float("nan"),
