@@ -2,39 +2,70 @@
 
 hipcc cross-compiles without a GPU, so this runs in the CPU-only container as well as on
 the MI355X box.  The shared object is kept in cassierl_amd/lib/ (git-ignored, shipped by gpurun).
+One translation unit per kernel family (csrc/tu_*.hip + the C-ABI in cassie_cabi.hip), compiled
+in parallel to objects under lib/obj/ and linked into one shared library.
 """
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcassie2d.so")
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))  # cassie_cabi.hip includes the rest
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("cassie2d.h", "cassie_vec.h")]
+UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_g32", "tu_ctrl", "tu_ctrl_g16", "tu_3d"]
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("CASSIE_HIPCC_FLAGS", "").split()
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    d += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return d
+
+
+def _units():
+    return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u + ".hip"))]
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/cassie_cabi.hip (which includes the kernels) into lib/libcassie2d.so."""
-    if not force and not needs_build():
+def build(force=False, verbose=False, only=None):
+    """Compile every translation unit (or those named in `only`, re-using the other objects) and link lib/libcassie2d.so."""
+    if not force and not only and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB, os.path.join(CSRC, "cassie_cabi.hip")]
+    os.makedirs(OBJDIR, exist_ok=True)
+    newest = max(os.path.getmtime(d) for d in _deps())
+
+    def compile_one(u):
+        obj = os.path.join(OBJDIR, u + ".o")
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < newest
+        if only is not None:
+            stale = u in only or not os.path.exists(obj)
+        if stale:
+            cmd = [HIPCC] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, _units()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    only = sys.argv[1:] or None
+    print(build(force=only is None, verbose=True, only=only))

@@ -1,0 +1,28 @@
+// cassie3d_layout.h -- HBM record, debug record and kernel parameter block of the batched Cassie3d physics
+// (shared by cassie3d_kernels.hip and the host side; not a public header).
+#ifndef CASSIE3D_LAYOUT_H_
+#define CASSIE3D_LAYOUT_H_
+
+namespace cassie3d {
+
+constexpr int MAXR = 64;        // constraint rows of the general kernel
+constexpr int MAXR_FAST = 32;   // ... of the high-occupancy kernel (8 KB instead of 32 KB for A): 6 connect rows + 8 contacts, say
+constexpr double MINVAL = 1e-15;
+// HBM record of one environment (doubles)
+constexpr int ENV3_STRIDE = 80;
+enum { E3_Q = 0, E3_V = 21, E3_WS = 41, E3_CTRL = 61, E3_TIME = 71, E3_NITER = 72, E3_NEFC = 73, E3_OVF = 74 };
+enum { K_NONE = 0, K_EQ = 1, K_LIM = 2, K_CN = 3, K_CT = 4 };
+// debug record (tests only)
+enum { D3_M = 0, D3_BIAS = 400, D3_QS = 420, D3_NEFC = 440, D3_QACC = 441, D3_F = 461, D3_AREF = 525, D3_J = 589, D3_STRIDE = 589 + 64 * 20 };
+
+struct Params3 {
+  double* state;           // [n][ENV3_STRIDE]
+  const double* actions;   // [n][10] motor commands (pre-clamp), device
+  double* debug;           // [n][D3_STRIDE] or null
+  const int* pending_in;   // [n] substeps to do per env (second pass) or null: n_sub for everyone
+  int* pending_out;        // [n] substeps NOT done because the env needed more rows than this kernel has, or null: flag E3_OVF
+  int n_envs, n_sub, integrate;
+};
+
+}  // namespace cassie3d
+#endif

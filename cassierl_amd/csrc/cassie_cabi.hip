@@ -14,11 +14,13 @@
 #include "../../include/cassie2d.h"
 #include "../../include/cassie_vec.h"
 #include "../../include/cassie3d_vec.h"
-#include "cassie_kernels.hip"
-#include "cassie_kernels_g16.hip"
-#include "cassie_ctrl.hip"
-#include "cassie_ctrl_g16.hip"
-#include "cassie3d_kernels.hip"
+#include "cassie2d_planar.h"
+#include "cassie3d_tables.h"
+#include "cassie_launch.h"
+
+namespace cassie { constexpr int NSLOT = CP_NSLOT; }
+namespace L2 = cassie::launch;
+namespace L3 = cassie3d::launch;
 
 static_assert(CASSIE_STATE_STRIDE == cassie::ENV_STRIDE, "public stride must match the kernel layout");
 static_assert(sizeof(StateGeneral) == 208 && sizeof(StateOperationalSpace) == 144 && sizeof(ControllerOsc) == 56 &&
@@ -63,9 +65,9 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
-constexpr int MAXACT = 32;                              // register-resident active constraint columns per row lane
+constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
-constexpr int MAXACT_DBG = 8;                            // debug build of the substep: forces the overflow path in tests
+constexpr int MAXACT_DBG = L2::K1_MAXACT_DBG;           // debug build of the substep: forces the overflow path in tests
 constexpr int OVF_STRIDE_DBG = (cassie::NSLOT - MAXACT_DBG) * 64;
 
 cassie::VecParams make_params(CassieVec* h) {
@@ -86,52 +88,39 @@ cassie::VecParams make_params(CassieVec* h) {
 }
 
 // controller-in-the-loop modes; zpos/zvel != null selects the scripted standing controllers
-template <int CTRL, bool SCRIPTED>
-void launch_ctrl_kernels(CassieVec* h, const cassie::VecParams& p, const double* zpos, const double* zvel) {
-  dim3 grid(h->n), block(64);
-  if (h->g16 && !p.debug) {
-    // 4 environments per wavefront, then the wave-per-environment kernel for the (rare) environments left pending
-    hipLaunchKernelGGL((cassie::g16::env_ctrl_step_g16_kernel<CTRL, SCRIPTED>), dim3((h->n + 3) / 4), block, 0, h->stream, p, zpos, zvel, h->pending);
-    cassie::VecParams pc = p;
-    pc.pending = h->pending;
-    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<CTRL, SCRIPTED>), grid, block, 0, h->stream, pc, zpos, zvel);
-  } else {
-    hipLaunchKernelGGL((cassie::env_ctrl_step_kernel<CTRL, SCRIPTED>), grid, block, 0, h->stream, p, zpos, zvel);
-  }
-}
-
 int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const double* zpos, const double* zvel) {
   const bool scripted = zpos != nullptr;
-  if (mode == CASSIE_CTRL_OSC) { if (scripted) launch_ctrl_kernels<2, true>(h, p, zpos, zvel); else launch_ctrl_kernels<2, false>(h, p, zpos, zvel); }
-  else if (mode == CASSIE_CTRL_JACOBIAN) { if (scripted) launch_ctrl_kernels<3, true>(h, p, zpos, zvel); else launch_ctrl_kernels<3, false>(h, p, zpos, zvel); }
-  else return fail(h, CASSIE_EINVAL, "controller-in-the-loop stepping exists for OSC and Jacobian modes only");
+  if (mode != CASSIE_CTRL_OSC && mode != CASSIE_CTRL_JACOBIAN)
+    return fail(h, CASSIE_EINVAL, "controller-in-the-loop stepping exists for OSC and Jacobian modes only");
+  const int ctrl = mode == CASSIE_CTRL_OSC ? 2 : 3;
+  if (h->g16 && !p.debug) {
+    // 4 environments per wavefront, then the wave-per-environment kernel for the (rare) environments left pending
+    L2::ctrl_g16(ctrl, scripted, h->n, h->stream, p, zpos, zvel, h->pending);
+    cassie::VecParams pc = p;
+    pc.pending = h->pending;
+    L2::ctrl_k4(ctrl, scripted, h->n, h->stream, pc, zpos, zvel);
+  } else {
+    L2::ctrl_k4(ctrl, scripted, h->n, h->stream, p, zpos, zvel);
+  }
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
 
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
-  dim3 grid(h->n), block(64);
   const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
-  if (h->g16 && !p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
+  const bool pdtq = mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE;
+  if (h->g16 && !p.debug && pdtq) {
     // fast path: 4 environments per wavefront; environments with more than 16 active constraint rows are finished
     // by the wave-per-environment kernel, which returns immediately for every other environment
-    dim3 grid4((h->n + 3) / 4);
-    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::g16::env_step_g16_kernel<0>), grid4, block, 0, h->stream, p, h->pending);
-    else hipLaunchKernelGGL((cassie::g16::env_step_g16_kernel<1>), grid4, block, 0, h->stream, p, h->pending);
+    L2::step_g16(mode, h->n, h->stream, p, h->pending);
     cassie::VecParams pc = p;
     pc.pending = h->pending;
-    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::env_step_kernel<0, 3, MAXACT>), grid, block, 0, h->stream, pc);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3, MAXACT>), grid, block, 0, h->stream, pc);
-  } else if (p.debug && (mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE)) {
+    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, pc);
+  } else if (p.debug && pdtq) {
     // test hook: same code with only MAXACT_DBG register-resident columns, so that the workspace path is exercised
-    if (mode == CASSIE_CTRL_PD) hipLaunchKernelGGL((cassie::env_step_kernel<0, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 2, MAXACT_DBG>), grid, block, 0, h->stream, p);
-  } else if (mode == CASSIE_CTRL_PD) {
-    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<0, 4, MAXACT>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<0, 3, MAXACT>), grid, block, 0, h->stream, p);
-  } else if (mode == CASSIE_CTRL_TORQUE) {
-    if (shallow) hipLaunchKernelGGL((cassie::env_step_kernel<1, 4, MAXACT>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((cassie::env_step_kernel<1, 3, MAXACT>), grid, block, 0, h->stream, p);
+    L2::step_k1(mode, L2::K1_DEBUG, h->n, h->stream, p);
+  } else if (pdtq) {
+    L2::step_k1(mode, shallow ? L2::K1_SHALLOW : L2::K1_DEEP, h->n, h->stream, p);
   }
   else if (mode == CASSIE_CTRL_OSC || mode == CASSIE_CTRL_JACOBIAN) {
     return launch_ctrl_step(h, mode, p, nullptr, nullptr);
@@ -147,10 +136,10 @@ int launch_reset(CassieVec* h, const uint8_t* mask, const double* q, const doubl
   if (keep) {
     // forward only: feed the current state back in as the "new" state
     HIPCHK(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(cassie::get_state_kernel, dim3((h->n * 13 + 255) / 256), dim3(256), 0, h->stream, h->state, h->n, h->d_q, h->d_v);
+    L2::get_state(h->n, h->stream, h->state, h->d_q, h->d_v);
     q = h->d_q; v = h->d_v;
   }
-  hipLaunchKernelGGL(cassie::env_reset_kernel, dim3(h->n), dim3(64), 0, h->stream, p, mask, q, v);
+  L2::reset(h->n, h->stream, p, mask, q, v);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -190,7 +179,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (h->cfg.flags & CASSIE_WAVE_PER_ENV) h->g16 = false;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
-  hipLaunchKernelGGL(cassie::env_init_kernel, dim3((n_envs * cassie::ENV_STRIDE + 255) / 256), dim3(256), 0, h->stream, h->state, n_envs);
+  L2::init_state(n_envs, h->stream, h->state);
   if (launch_reset(h, nullptr, nullptr, nullptr, nullptr, true) != CASSIE_OK) return bail(CASSIE_EHIP);
   if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
@@ -265,7 +254,7 @@ int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev
 int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev) {
   if (!h) return CASSIE_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(cassie::get_state_kernel, dim3((h->n * 13 + 255) / 256), dim3(256), 0, h->stream, h->state, h->n, qpos_dev, qvel_dev);
+  L2::get_state(h->n, h->stream, h->state, qpos_dev, qvel_dev);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -274,7 +263,7 @@ int CassieVecGetOpState(CassieVec* h, double* x18_dev) {
   if (!h || !x18_dev) return CASSIE_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   cassie::VecParams p = make_params(h);
-  hipLaunchKernelGGL(cassie::env_opstate_kernel, dim3(h->n), dim3(64), 0, h->stream, p, x18_dev);
+  L2::opstate(h->n, h->stream, p, x18_dev);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -446,15 +435,14 @@ struct Cassie3dVec {
 namespace {
 // fast kernel (<= 32 rows, 2 waves per SIMD) for everyone, then the general kernel for the environments it left pending
 void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
-  dim3 grid(h->n), block(64);
   if (p.debug) {
-    hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR, 1>), grid, block, 0, h->stream, p);
+    L3::step3d(1, h->n, h->stream, p);
     return;
   }
   p.pending_in = nullptr; p.pending_out = h->pending;
-  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR_FAST, 2>), grid, block, 0, h->stream, p);
+  L3::step3d(0, h->n, h->stream, p);
   p.pending_in = h->pending; p.pending_out = nullptr;
-  hipLaunchKernelGGL((cassie3d::env_step3d_kernel<cassie3d::MAXR, 1>), grid, block, 0, h->stream, p);
+  L3::step3d(1, h->n, h->stream, p);
 }
 int fail3(Cassie3dVec* h, int code, const char* msg) { if (h) h->err = msg; return code; }
 #define HIPCHK3(h, call)                                                                      \
@@ -519,7 +507,7 @@ int Cassie3dVecSynchronize(Cassie3dVec* h) {
 int Cassie3dVecReset(Cassie3dVec* h, const double* qpos_dev, const double* qvel_dev) {
   if (!h) return CASSIE_EINVAL;
   HIPCHK3(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(cassie3d::env_init3d_kernel, dim3(h->n), dim3(64), 0, h->stream, h->state, h->n, qpos_dev, qvel_dev);
+  L3::init3d(h->n, h->stream, h->state, qpos_dev, qvel_dev);
   cassie3d::Params3 p{};
   p.state = h->state; p.actions = nullptr; p.debug = nullptr; p.n_envs = h->n; p.n_sub = 1; p.integrate = 0;
   launch3d(h, p);  // mj_forward

@@ -21,6 +21,8 @@
 //               17 contact (normal,tangent) pairs in MuJoCo's contact order); lane i keeps row i of
 //               A = J M^-1 J' + R in registers and its own residual, so a PGS row update is
 //               "owner lane computes delta -> v_readlane -> one FMA on every lane".
+#ifndef CASSIE_KERNELS_HIP_
+#define CASSIE_KERNELS_HIP_
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -779,6 +781,8 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   store_state(st, sm, lane, qstate_l, time, niter_sum);
 }
 
+// The non-template kernels below are compiled by one translation unit only (tu_base.hip).
+#ifdef CASSIE_TU_BASE
 // ---------------------------------------------------------------- masked reset (Cassie2dEnv.reset / Cassie2d::Reset)
 __global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_t* mask, const double* qpos_in, const double* qvel_in) {
   __shared__ Smem sm;
@@ -846,4 +850,7 @@ __global__ void get_state_kernel(const double* state, int n_envs, double* qpos, 
   if (qvel) qvel[i] = state[(size_t)e * ENV_STRIDE + ES_V + k];
 }
 
+#endif  // CASSIE_TU_BASE
+
 }  // namespace cassie
+#endif  // CASSIE_KERNELS_HIP_

@@ -1,0 +1,40 @@
+// cassie_launch.h -- host-callable launchers of the kernels, one translation unit per kernel family so that the
+// extension builds in parallel (tu_*.hip); cassie_cabi.hip (the C-ABI) only sees these declarations.
+#ifndef CASSIE_LAUNCH_H_
+#define CASSIE_LAUNCH_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cassie_vec_layout.h"
+#include "cassie3d_layout.h"
+
+namespace cassie {
+namespace launch {
+
+// K1 instantiations of env_step_kernel<MODE, WPS, MAXACT>
+enum K1Variant { K1_DEEP = 0 /* <.,3,32> */, K1_SHALLOW = 1 /* <.,4,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
+constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
+
+// tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque)
+void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p);
+void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
+void opstate(int n_envs, hipStream_t s, const VecParams& p, double* out18);
+void init_state(int n_envs, hipStream_t s, double* state);
+void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel);
+// tu_g16.hip: four environments per wavefront
+void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
+// tu_ctrl.hip / tu_ctrl_g16.hip: controller in the loop (ctrl: 2 OSC, 3 Jacobian)
+void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
+void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel, int* pending);
+
+}  // namespace launch
+}  // namespace cassie
+
+namespace cassie3d {
+namespace launch {
+// tu_3d.hip
+void step3d(int variant /*0: <MAXR_FAST,2>, 1: <MAXR,1>*/, int n_envs, hipStream_t s, const Params3& p);
+void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const double* qvel);
+}  // namespace launch
+}  // namespace cassie3d
+#endif

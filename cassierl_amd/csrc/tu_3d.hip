@@ -1,0 +1,19 @@
+// tu_3d.hip -- translation unit of the Cassie3d kernels (cassie3d_kernels.hip).
+#include "cassie_kernels.hip"
+#include "cassie3d_kernels.hip"
+#include "cassie_launch.h"
+
+namespace cassie3d {
+namespace launch {
+
+void step3d(int variant, int n_envs, hipStream_t s, const Params3& p) {
+  dim3 grid(n_envs), block(64);
+  if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, 2>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((env_step3d_kernel<MAXR, 1>), grid, block, 0, s, p);
+}
+void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const double* qvel) {
+  hipLaunchKernelGGL(env_init3d_kernel, dim3(n_envs), dim3(64), 0, s, state, n_envs, qpos, qvel);
+}
+
+}  // namespace launch
+}  // namespace cassie3d

@@ -459,7 +459,7 @@ def emit_planar_header(mj, m3s, consts, planars, path):
     o.append("#define CP_TIMESTEP %.17g\n#define CP_ITERATIONS %d\n#define CP_TOLERANCE %.17g\n#define CP_GRAVITY %.17g\n"
              % (op["timestep"], op["iterations"], op["tolerance"], -op["gravity"][2]))
     o.append("#define CP_MEANINERTIA %.17g\n" % consts["mj"]["meaninertia"])
-    D = "__device__ __constant__ const "
+    D = "static __device__ __constant__ const "
     ca = lambda n, a, fmt="%.17g", ct="double", pl_=4: _carr(n, a, fmt, ct, pl_, static=D)
     o.append(ca("cp_link_parent", [L["parent"] for L in pl["links"]], "%d", "int", 11))
     o.append(ca("cp_link_dof", [L["dof"] for L in pl["links"]], "%d", "int", 11))
