@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the batched Cassie2d rollout (BASELINE.json metric).
 
-Workload at N=1 = BASELINE.json configs[1]: 4096 parallel Cassie2d envs (rllab/envs/cassie2d.py semantics: PD control
-mode, n=10 substeps per Env.step, reward / termination / auto-reset), random-policy rollout, one MI355X.
-One bench "step" = one vectorised Env.step over the whole batch = 4096 env-steps (40960 physics substeps).
-Weak scaling: every rank owns 4096 envs (global ids rank*4096 ..), no collective inside a step, ONE RCCL gather of the
-per-env returns at the end of the rollout batch (inside the timed region).
+Workload (every rank): 65 536 parallel Cassie2d envs -- the size BASELINE.json's target is quoted on ("64k parallel Cassie2d
+envs at 1 GPU"; configs[3] = 8 x 64k) -- rllab/envs/cassie2d.py semantics: PD control mode, n=10 physics substeps per
+Env.step, reward / termination / auto-reset, uniform random policy over the PD action box (configs[1]'s workload at the
+target size; `--envs-per-gpu 4096` gives configs[1] itself).  One bench "step" = one vectorised Env.step over the whole
+batch = 65 536 env-steps (655 360 physics substeps) per GPU.
 
-Inputs (actions of a uniform random policy over the PD action box, counter-based stream keyed by the global env id)
-are generated on the device before the timed region: the timed region starts with everything resident in HBM.
+Multi-GPU: weak scaling, one process per GPU.  Every rank owns `envs_per_gpu` envs (global ids rank*n ..), no collective
+inside a step, ONE RCCL all_gather of the per-env returns at the end of the rollout batch (inside the timed region).
+`python bench.py --gpus N` started WITHOUT torchrun spawns the N ranks itself -- before anything touches the GPU in the
+parent -- and fails non-zero unless exactly N ranks join; under torchrun (WORLD_SIZE set) it is one of the ranks.
+
+Inputs (actions, counter-based stream keyed by the global env id) are generated on the device before the timed region.
+At N=1 the line also carries `extra`: the same kernels on workloads where robots move and fall (share of env-substeps
+that leave the packed fast path included), configs[2] (OSC controller in the loop) and configs[4] (Cassie3d).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,19 +29,62 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ENVS_PER_GPU = 4096
+ENVS_PER_GPU = 65536
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
-FLOP_PER_SUBSTEP = 60e3              # SURVEY.md 8(d) estimate (3-D formulation); the planar kernel needs fewer
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ launcher (no GPU call)
+def spawn_ranks(args):
+    """Start one child process per GPU with the torchrun environment; the parent never initialises the GPU."""
+    import torch  # device_count() does not initialise the runtime on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d device(s) visible\n" % (args.gpus, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, deadline = 0, time.time() + 3600
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:  # a rank that died takes the others down with it (exact PIDs only)
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(traj, cores, budget_s=12.0):
-    """Oracle (C restatement, OpenMP over envs) on the host cores of this box, bounded sample of the same workload."""
+    """Oracle (C restatement, OpenMP over envs, -O3 -march=native build made on this box) on the host cores of this box,
+    bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     from cassierl_amd import rollout as R
     import torch
+    fast = O.use_fast_build() if hasattr(O, "use_fast_build") else False
     n = 16 * cores
     envs = [O.OracleEnv("walk", "PD", traj=traj) for _ in range(n)]
     for e in envs:
@@ -49,99 +100,223 @@ def cpu_baseline(traj, cores, budget_s=12.0):
         t_used += time.perf_counter() - t0
         steps += 1
     return dict(value=n * steps / t_used, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs" % (n, steps, t_used))
+                sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs, oracle built %s"
+                       % (n, steps, t_used, "-O3 -march=native" if fast else "-O2"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------ extra workloads (N=1)
+def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn, note):
+    import torch
+    from cassierl_amd.vec_env import CassieVecEnv
+    env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags, auto_reset=True, device=0)
+    if kind == "walk":
+        env.set_trajectory(traj["time"], traj["qpos"])
+    env.use_torch_stream()
+    out = env.alloc()
+    env.reset(out)
+    for t in range(warmup):
+        env.step(action_fn(t), out)
+    acts = [action_fn(warmup + t) for t in range(steps)]
+    env.reset_counters()
+    dones = torch.zeros((), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        _, _, d = env.step(acts[t], out)
+        dones += d.sum()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = env.counters()
+    q, v = env.get_state_host()
+    env.close()
+    return dict(workload=name, note=note, envs=n, warmup_steps=warmup, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3,
+                cleanup_frac=c["cleanup_frac"], k1_frac=c["k1_frac"], nonfinite_resets=c["nonfinite_resets"],
+                episodes_terminated_per_env_step=float(dones.item()) / (n * steps),
+                finite=bool(np.isfinite(q).all() and np.isfinite(v).all()))
 
+
+def extra_workloads(traj, n):
     import torch
     from cassierl_amd import rollout as R
+    from cassierl_amd import vec_env as VE
+    ids = torch.arange(n, device="cuda:0")
+    rows = []
+    pd_box = VE.action_space("PD")
+    tq_box = VE.action_space("Torque")
+    # (a) walk / PD with the reward reading the CURRENT joint angles: episodes run until the robot leaves z in [0.6, 1.2] or
+    #     drifts from the reference gait, so robots move, hit joint limits and fall before the auto-reset
+    rows.append(run_env_workload("walk_pd_fix_stale_qstate", n, "walk", "PD", VE.FIX_STALE_QSTATE, traj, 150, 40,
+                                 lambda t: R.random_actions(2, ids, t, pd_box.low, pd_box.high),
+                                 "cassie2d.py with quirk Q3 fixed (CASSIE_FIX_STALE_QSTATE), random PD policy"))
+    # (b) stand env / torque mode, U(+-ctrlrange): free falls onto the ground, reset at z < 0.5 (random_agent.py-style)
+    rows.append(run_env_workload("stand_torque_random", n, "stand", "Torque", 0, traj, 150, 40,
+                                 lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
+                                 "cassie_stand2d.py reward/termination, random torques in ctrlrange"))
+    # (c) configs[2]: OSC controller (QP) in every substep, cassie_stand2d Env.step with small random OSC targets
+    osc_lo, osc_hi = np.array([-2.0, -2.0, -2.0, 0.0, -2.0, 0.0, -2.0]), np.full(7, 2.0)
+    rows.append(run_env_workload("configs[2]_stand_osc_in_loop", n, "stand", "OSC", 0, traj, 20, 30,
+                                 lambda t: R.random_actions(4, ids, t, osc_lo, osc_hi),
+                                 "OSC_RBDL QP + mj_step per substep, 10 substeps per Env.step, random accelerations targets in +-2 m/s^2"))
+    # (c') the scripted standing controller of squatting.py-style loops: substeps/s (one controller call per substep)
+    env = VE.CassieVecEnv(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False, device=0)
+    env.use_torch_stream()
+    zp = torch.full((n,), 0.9, dtype=torch.float64, device="cuda:0")
+    zv = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    env._chk(env.L.CassieVecStandingStep(env.h, VE.CONTROL_MODES["OSC"], zp.data_ptr(), zv.data_ptr(), 20))
+    env.reset_counters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        env._chk(env.L.CassieVecStandingStep(env.h, VE.CONTROL_MODES["OSC"], zp.data_ptr(), zv.data_ptr(), 20))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = env.counters()
+    env.close()
+    rows.append(dict(workload="configs[2]_standing_controller_osc", note="standing_controller_osc(zpos=0.9) + StepOsc, 200 substeps",
+                     envs=n, controller_substeps_per_s=n * 200 / dt, env_steps_equiv_per_s=n * 20 / dt, cleanup_frac=c["cleanup_frac"], k1_frac=c["k1_frac"]))
+    # (d) configs[4]: Cassie3d, 16 384 envs, torque mode U(+-ctrlrange), 10 substeps per step
+    from cassierl_amd.vec_env3d import Cassie3dVec, CTRL_RANGE
+    n3 = 16384
+    e3 = Cassie3dVec(n3)
+    ids3 = torch.arange(n3, device="cuda:0")
+    acts = [R.random_actions(5, ids3, t, -CTRL_RANGE, CTRL_RANGE) for t in range(60)]
+    for t in range(30):
+        e3.step(acts[t], 10)
+    e3.synchronize()
+    t0 = time.perf_counter()
+    for t in range(30, 60):
+        e3.step(acts[t], 10)
+    e3.synchronize()
+    dt = time.perf_counter() - t0
+    row = dict(workload="configs[4]_cassie3d_torque_random", note="cassie3d_stiff.xml physics, random torques, robots fall during the run",
+               envs=n3, warmup_steps=30, steps=30, env_steps_per_s=n3 * 30 / dt, ms_per_step=dt / 30 * 1e3)
+    if hasattr(e3, "counters"):
+        row.update(e3.counters())
+    e3.close()
+    rows.append(row)
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def worker(args):
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd.trajectory import default_gait
     from cassierl_amd.vec_env import CassieVecEnv
 
     rank, local_rank, world = R.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node N for N>1"
+    if world != max(1, args.gpus):
+        sys.stderr.write("bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE); refusing to report a mislabelled number\n" % (args.gpus, world))
+        return 3
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
+    device = "cuda:%d" % dev
     n_local = args.envs_per_gpu
     lo, hi = R.shard_bounds(n_local * world, rank, world)
-    traj_npz = np.load(os.path.join(ROOT, "tests", "golden", "traj2d.npz"))
-    traj = dict(time=traj_npz["time"], qpos=traj_npz["qpos"])
+    gait = default_gait()
+    traj = dict(time=gait.time, qpos=gait.qpos)
 
     env = CassieVecEnv(n_local, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True, device=dev)
     env.set_trajectory(traj["time"], traj["qpos"])
     env.use_torch_stream()
     out = env.alloc()
-    ids = torch.arange(lo, hi, device="cuda:%d" % dev)
+    ids = torch.arange(lo, hi, device=device)
     low, high = env.action_space.low, env.action_space.high
     total = args.warmup + args.steps
     actions = [R.random_actions(1, ids, t, low, high) for t in range(total)]  # resident in HBM before timing
-    returns = torch.zeros(n_local, dtype=torch.float64, device="cuda:%d" % dev)
+    returns = torch.zeros(n_local, dtype=torch.float64, device=device)
+    dones = torch.zeros((), dtype=torch.float64, device=device)
     env.reset(out)
     for t in range(args.warmup):
         env.step(actions[t], out)
+    R.gather_returns(returns)  # RCCL communicator set-up happens here, outside the timed region
+    env.reset_counters()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     R.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(args.warmup, total):
-        _, rew, _ = env.step(actions[t], out)
+        _, rew, dn = env.step(actions[t], out)
         returns += rew
+        dones += dn.sum()
+    ev0.record()
     all_returns = R.gather_returns(returns)  # the single collective of the rollout batch (RCCL over xGMI)
+    ev1.record()
     torch.cuda.synchronize()
     R.barrier()
     torch.cuda.synchronize()
-    elapsed = R.max_over_ranks(time.perf_counter() - t0, device="cuda:%d" % dev)
+    elapsed = R.max_over_ranks(time.perf_counter() - t0, device=device)
+    gather_ms = ev0.elapsed_time(ev1)
+    ranks_joined = int(R.max_over_ranks(world, device=device))
+    counters = env.counters()
 
-    # kernel-only time of the dominant kernel, HIP events on the stream it is launched on
+    # kernel-only time of the dominant kernel pair, HIP events on the stream it is launched on
     kernel_ms = env.time_steps(actions[-1], args.steps, out)
     q, v = env.get_state_host()
     finite = bool(np.isfinite(q).all() and np.isfinite(v).all())
+    env.close()
 
+    rc = 0
     if rank == 0:
         n_total = n_local * world
         value = n_total * args.steps / elapsed
         achieved_gbps = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc.get("envs") == n_local else None
+        valu = pmc.get("valu_flop_per_env_step")  # counted from SQ_INSTS_VALU_* of the same kernel, see profiles/README.md
         line = {
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d parallel Cassie2d envs per GPU, random-policy rollout, PD mode, 10 substeps/step, "
-                                   "walk env reward/done/auto-reset" % n_local,
+            "config": {"workload": "%d parallel Cassie2d envs per GPU (BASELINE north_star target size; configs[1] workload), random-policy "
+                                   "rollout, PD mode, 10 substeps/step, walk env reward/done/auto-reset, reference semantics (flags=0)" % n_local,
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
-                       "collective": "one all_gather of per-env returns per rollout batch"},
+                       "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "cassie::g16::env_step_g16_kernel<0> (+ clean-up pass cassie::env_step_kernel<0,3,32>, ~1 % of the time)", "kernel_ms": kernel_ms, "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                         "kernel": "cassie::g16::env_step_g16_kernel<0> (+ its hand-over passes)", "kernel_ms": kernel_ms,
+                         "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d); see fp64_valu"},
-            "fp64_valu": {"achieved_tflops_est": FLOP_PER_SUBSTEP * 10 * n_local / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                          "flop_model": "60 kflop/substep estimate of SURVEY.md 8(d)"},
+            "fp64_valu": None if not valu else {
+                "achieved_tflops": valu * n_local / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                "frac": valu * n_local / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "flop_model": "counted: FP64 VALU instruction counters of the dominant kernel (profiles/pmc_traffic.json)"},
             "physics_substeps_per_s": value * 10, "returns_checksum": float(all_returns.sum().item()), "finite": finite,
+            "episodes_terminated_per_env_step": float(dones.item()) / (n_local * args.steps),
+            "cleanup_frac": counters["cleanup_frac"], "k1_frac": counters["k1_frac"], "nonfinite_resets": counters["nonfinite_resets"],
+            "workload_note": "reference quirk Q3 (stale qstate) makes reward < 0.6 on every step, so every env terminates and auto-resets "
+                             "each step: the headline is the reference-faithful but degenerate regime; `extra` holds the regimes where robots move",
         }
-        if not args.no_cpu_baseline:
+        if not finite or ranks_joined != max(1, args.gpus):
+            rc = 4
+        if world == 1 and not args.no_extra:
+            try:
+                line["extra"] = extra_workloads(traj, n_local)
+            except Exception as ex:  # the headline stays valid; say what failed
+                line["extra"] = [{"error": repr(ex)}]
+        if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(traj, cores)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
-    env.close()
+        print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ EXPORTS = [
     "GetOperationalSpaceState", "Display", "Render",
     # batched ABI (include/cassie_vec.h)
     "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
-    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecSetTrajectory", "CassieVecReset", "CassieVecResetTo",
+    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecSetTrajectory", "CassieVecReset", "CassieVecResetTo",
     "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
@@ -62,6 +62,8 @@ def load():
     L.CassieVecActionDim.argtypes = [vp]
     L.CassieVecSetStream.argtypes = [vp, vp]
     L.CassieVecSynchronize.argtypes = [vp]
+    L.CassieVecGetCounters.argtypes = [vp, ct.POINTER(ct.c_uint64)]
+    L.CassieVecResetCounters.argtypes = [vp]
     L.CassieVecSetTrajectory.argtypes = [vp, dp, dp, ct.c_int]
     L.CassieVecReset.argtypes = [vp, u8p, dp]
     L.CassieVecResetTo.argtypes = [vp, u8p, dp, dp, dp]

@@ -39,6 +39,8 @@ struct CassieVec {
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
   int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
+  unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
+  unsigned long long substeps_requested = 0; // host: env-substeps asked for since the counters were last cleared
   bool g16 = true;                           // CASSIE2D_G16=0 selects the wave-per-environment kernel only (A/B)
   uint8_t* d_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -84,6 +86,7 @@ cassie::VecParams make_params(CassieVec* h) {
   p.traj_n = h->traj_n;
   p.ovf = h->ovf;
   p.ovf_stride = OVF_STRIDE;
+  p.stats = h->stats;
   return p;
 }
 
@@ -175,6 +178,8 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->ovf, n * OVF_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->pending, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->stats, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMemset(h->stats, 0, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
   if (h->cfg.flags & CASSIE_WAVE_PER_ENV) h->g16 = false;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
@@ -190,7 +195,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->stats);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;
@@ -199,7 +204,34 @@ void CassieVecFree(CassieVec* h) {
 const char* CassieVecLastError(const CassieVec* h) { return h ? h->err.c_str() : "null handle"; }
 int CassieVecNumEnvs(const CassieVec* h) { return h ? h->n : 0; }
 int CassieVecActionDim(const CassieVec* h) { return h ? adim_of(h->cfg.control_mode) : 0; }
-int CassieVecSetStream(CassieVec* h, void* s) { if (!h) return CASSIE_EINVAL; h->stream = (hipStream_t)s; return CASSIE_OK; }
+int CassieVecSetStream(CassieVec* h, void* s) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // work queued on the old stream must not race with launches on the new one
+  h->stream = (hipStream_t)s;                  // NULL: back to the default stream
+  return CASSIE_OK;
+}
+
+int CassieVecGetCounters(CassieVec* h, uint64_t* out4) {
+  if (!h || !out4) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  unsigned long long host[cassie::STAT_N];
+  HIPCHK(h, hipMemcpyAsync(host, h->stats, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out4[0] = h->substeps_requested;
+  out4[1] = host[cassie::STAT_CLEANUP_SUBSTEPS];
+  out4[2] = host[cassie::STAT_K1_SUBSTEPS];
+  out4[3] = host[cassie::STAT_NONFINITE];
+  return CASSIE_OK;
+}
+
+int CassieVecResetCounters(CassieVec* h) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->stats, 0, cassie::STAT_N * sizeof(unsigned long long), h->stream));
+  h->substeps_requested = 0;
+  return CASSIE_OK;
+}
 int CassieVecSynchronize(CassieVec* h) { if (!h) return CASSIE_EINVAL; HIPCHK(h, hipStreamSynchronize(h->stream)); return CASSIE_OK; }
 void* CassieVecStatePtr(CassieVec* h) { return h ? h->state : nullptr; }
 
@@ -232,6 +264,7 @@ int CassieVecStep(CassieVec* h, const double* actions_dev, double* obs_dev, doub
   HIPCHK(h, hipSetDevice(h->device));
   cassie::VecParams p = make_params(h);
   p.actions = actions_dev; p.obs = obs_dev; p.reward = reward_dev; p.done = done_dev; p.terminal_obs = terminal_obs_dev;
+  h->substeps_requested += (unsigned long long)h->n * p.n_sub;
   return launch_step(h, h->cfg.control_mode, p);
 }
 
@@ -240,6 +273,7 @@ int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, 
   HIPCHK(h, hipSetDevice(h->device));
   cassie::VecParams p = make_params(h);
   p.actions = actions_dev; p.adim = adim_of(control_mode); p.n_sub = n_sub; p.obs = nullptr;
+  h->substeps_requested += (unsigned long long)h->n * n_sub;
   return launch_step(h, control_mode, p);
 }
 
@@ -248,6 +282,7 @@ int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev
   HIPCHK(h, hipSetDevice(h->device));
   cassie::VecParams p = make_params(h);
   p.actions = nullptr; p.n_sub = n_sub; p.obs = nullptr;
+  h->substeps_requested += (unsigned long long)h->n * n_sub;
   return launch_ctrl_step(h, control_mode, p, zpos_dev, zvel_dev);
 }
 

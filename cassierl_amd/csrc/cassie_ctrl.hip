@@ -387,6 +387,8 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
     for (int i = 0; i < 4; i++) dbg[110 + i] = g4[i];
     for (int i = 0; i < 16; i++) dbg[114 + i] = P4[i];
     for (int i = 0; i < NCR * NV; i++) dbg[130 + i] = cs.Jd[i / NV][i % NV];
+    for (int i = 0; i < NV * NV; i++) dbg[325 + i] = sm.minv[i];  // Hinv (RBDL semantics): inverse of DynamicState's M
+    for (int i = 0; i < NCR; i++) dbg[494 + i] = cs.acc[i];        // JdotQdot of every controller row (rows 0..3: JeqdotQdot)
   }
   // Jc6' f on the dof lanes: per foot the mean of the two 6-D site Jacobians; f = (My, Fx, Fz) (Cassie2d.cpp:139-163)
   if (c.dvalid && c.grp == 0 && rowok) {
@@ -562,6 +564,7 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   // clean-up pass of the 4-envs-per-wave kernel: only the envs it could not finish, only their remaining substeps
   const int n_sub = p.pending ? p.pending[env] : p.n_sub;
   if (n_sub == 0) return;
+  if (p.pending && p.stats && lane == 0) atomicAdd(p.stats + STAT_K1_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);
@@ -593,21 +596,23 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const
   if (c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;
   lds_sync();
   if (p.obs) {
-    // Env.step of cassie_stand2d.py (control_mode 'OSC'): observation, reward, termination
+    // Env.step with control_mode 'OSC' (cassie2d.py:97-225 walk env / cassie_stand2d.py:86-137): observation, reward, termination
     opstate18(sm, c, lane, fix_kin, s18);
     double sp = 0.0;
     if (lane < 17) sp = s18[lane + 1];
     if (lane == 5 || lane == 11) sp -= s18[0];
-    double a2 = 0.0;
-    for (int i = 0; i < ADIM; i++) { double a = SCRIPTED ? 0.0 : p.actions[(size_t)env * ADIM + i]; a2 += a * a; }
-    double z = s18[1];
-    double m = (rdlane(sp, 5) + rdlane(sp, 11)) / 2.0;
     double reward = 0.0;
-    reward -= 2 * (0.9 - z) * (0.9 - z);
-    reward -= 2 * m * m;
-    reward += 1;
-    reward -= 0.001 * a2;
-    int done = z < 0.5;
+    int done = 0;
+    env_outputs_wave(p, sm, s18, lane, SCRIPTED ? nullptr : p.actions + (size_t)env * ADIM, ADIM, qstate_l, time, sp, reward, done);
+    const bool bad = __ballot(lane < 26 && !in_range(lane < 13 ? sm.q[lane] : sm.v[lane - 13])) != 0 || !in_range(reward);  // failure guard
+    if (bad) {
+      sp = 0.0; reward = 0.0; done = 1;
+      if (lane == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      if (p.auto_reset) {
+        if (lane < 13) { sm.ws[lane] = 0.0; sm.kq[lane] = cp_env_qinit[lane]; sm.kv[lane] = 0.0; }
+        if (lane < NU) sm.ctrl[lane] = 0.0;
+      }
+    }
     if (p.terminal_obs && lane < 26) p.terminal_obs[(size_t)env * 26 + lane] = sp;
     if (done && p.auto_reset) {
       if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }

@@ -95,16 +95,24 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
     };
     double obs_a, obs_b;
     opstate_regs(obs_a, obs_b);
-    const double z = row_bcast<0>(obs_a);
-    double a2 = 0.0;
-    if (!SCRIPTED) for (int i = 0; i < ADIM; i++) { double a = p.actions[e * ADIM + i]; a2 += a * a; }
-    const double m = (row_bcast<5>(obs_a) + row_bcast<11>(obs_a)) / 2.0;
+    const double bodyx = sm.s18[0];  // s18 is not overlaid by anything the outputs touch
     double reward = 0.0;
-    reward -= 2 * (0.9 - z) * (0.9 - z);
-    reward -= 2 * m * m;
-    reward += 1;
-    reward -= 0.001 * a2;
-    const int done = z < 0.5;
+    int done = 0;
+    {
+      const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
+      const double qv = fixq ? sm.q[l < NV ? l : 0] : qstate_l;
+      env_outputs_row(p, l, SCRIPTED ? nullptr : p.actions + e * ADIM, ADIM, time, bodyx, qv, obs_a, obs_b, reward, done);
+    }
+    const bool badl = l < NV && !(in_range(sm.q[l < NV ? l : 0]) && in_range(sm.v[l < NV ? l : 0]));  // failure guard
+    const bool bad = live && ((((unsigned)(__ballot(badl) >> (16 * g))) & 0xFFFFu) != 0 || !in_range(reward));
+    if (bad) {
+      obs_a = 0.0; obs_b = 0.0; reward = 0.0; done = 1;
+      if (l == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      if (p.auto_reset) {
+        sm.ws[l] = 0.0; sm.kq[l] = l < NV ? cp_env_qinit[l] : 0.0; sm.kv[l] = 0.0;
+        if (l < NU) sm.ctrl[l] = 0.0;
+      }
+    }
     if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
     const bool do_reset = live && done && p.auto_reset;
     if (__ballot(do_reset) != 0) {
@@ -129,7 +137,10 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_step_g16_kernel(VecParams p, c
       st[ES_KQ + l] = sm.kq[l]; st[ES_KV + l] = sm.kv[l]; st[ES_QSTATE + l] = qstate_l;
     }
     if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
-    if (l == 0) { st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; if (CTRL == 2) st[ES_QPWSET] = (double)wset; pending[env] = pend; }
+    if (l == 0) {
+      st[ES_TIME] = time; st[ES_NITER] = (double)niter_sum; if (CTRL == 2) st[ES_QPWSET] = (double)wset; pending[env] = pend;
+      if (pend > 0 && p.stats) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
+    }
   }
 }
 

@@ -669,6 +669,92 @@ __device__ __forceinline__ void opstate18(SM& sm, const LaneConst& c, int lane, 
   lds_sync();
 }
 
+// ---------------------------------------------------------------- Env.step outputs (reward, termination, gait lookup)
+__device__ __forceinline__ bool in_range(double x) { return fabs(x) <= FINITE_BOUND; }  // false for NaN and +-inf
+
+// Wave-per-environment layout.  sp = obs[lane] (lane < 17: pos-invariant op-space state) on entry; the walk env fills lanes
+// 17..25 with the reference-gait joints.  qstate_l: lane 1 + j holds self.qstate[j].  act: this env's action vector or null.
+//   walk  rllab/envs/cassie2d.py:158-225         stand  rllab/envs/cassie_stand2d.py:114-137
+template <class SM>
+__device__ __forceinline__ void env_outputs_wave(const VecParams& p, const SM& sm, const double* s18, int lane, const double* act, int adim,
+                                                 double qstate_l, double time, double& sp, double& reward, int& done) {
+  if (p.env_kind == 0) {
+    // reference-gait lookup (cassie2d_trajectory.py:16-19)
+    double tmax = p.traj_tmax;
+    int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
+    const double* rq = p.traj_qpos + (size_t)idx * NV;
+    if (lane >= 17 && lane < 26) {
+      int k = lane - 17;  // columns 0,1,2,3,4,6,8,9,11
+      int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
+      sp = rq[col];
+    }
+    // reward (cassie2d.py:197-218); qstate is the reset pose unless FLAG_FIX_STALE_QSTATE (quirk Q3)
+    const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
+    auto qst = [&](int j) { return fixq ? sm.q[j] : rdlane(qstate_l, 1 + j); };
+    double j = qst(3) + qst(4) + qst(6);
+    j += qst(8) + qst(9) + qst(11);
+    double sum = 0.0;
+    for (int i = 20; i < 26; i++) sum += rdlane(sp, i);
+    j -= sum; j = exp(-(j * j));
+    double pp = s18[0] + s18[1];
+    pp -= rdlane(sp, 17) + rdlane(sp, 18); pp = exp(-(pp * pp));
+    double oo = s18[2];
+    oo -= rdlane(sp, 19); oo = exp(-(oo * oo));
+    reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+    done = (s18[1] < 0.6) || (s18[1] > 1.2) || (reward < 0.6);
+  } else {
+    double a2 = 0.0;
+    if (act) for (int i = 0; i < adim; i++) { double a = act[i]; a2 += a * a; }
+    double z = s18[1];
+    double m = (rdlane(sp, 5) + rdlane(sp, 11)) / 2.0;
+    reward = 0.0;
+    reward -= 2 * (0.9 - z) * (0.9 - z);
+    reward -= 2 * m * m;
+    reward += 1;
+    reward -= 0.001 * a2;
+    done = z < 0.5;
+  }
+}
+
+// Row layout (16 lanes per environment): lane l holds obs[l] in obs_a and obs[16 + l] in obs_b (lanes 0..9); qv on lane d is
+// the joint position the reward's joint term reads (self.qstate[d], or qpos[d] with FLAG_FIX_STALE_QSTATE).
+__device__ __forceinline__ void env_outputs_row(const VecParams& p, int l, const double* act, int adim, double time, double bodyx, double qv,
+                                                double obs_a, double& obs_b, double& reward, int& done) {
+  const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
+  if (p.env_kind == 0) {
+    double tmax = p.traj_tmax;
+    int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
+    const double* rq = p.traj_qpos + (size_t)idx * NV;
+    if (l >= 1 && l < 10) {
+      int k = l - 1;
+      int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
+      obs_b = rq[col];
+    }
+    double j = row_bcast<3>(qv) + row_bcast<4>(qv) + row_bcast<6>(qv);
+    j += row_bcast<8>(qv) + row_bcast<9>(qv) + row_bcast<11>(qv);
+    double sum = 0.0;
+    sum += row_bcast<4>(obs_b); sum += row_bcast<5>(obs_b); sum += row_bcast<6>(obs_b);
+    sum += row_bcast<7>(obs_b); sum += row_bcast<8>(obs_b); sum += row_bcast<9>(obs_b);
+    j -= sum; j = exp(-(j * j));
+    double pp = bodyx + z;
+    pp -= row_bcast<1>(obs_b) + row_bcast<2>(obs_b); pp = exp(-(pp * pp));
+    double oo = pitch;
+    oo -= row_bcast<3>(obs_b); oo = exp(-(oo * oo));
+    reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+    done = (z < 0.6) || (z > 1.2) || (reward < 0.6);
+  } else {
+    double a2 = 0.0;
+    if (act) for (int i = 0; i < adim; i++) { double a = act[i]; a2 += a * a; }
+    double m = (row_bcast<5>(obs_a) + row_bcast<11>(obs_a)) / 2.0;
+    reward = 0.0;
+    reward -= 2 * (0.9 - z) * (0.9 - z);
+    reward -= 2 * m * m;
+    reward += 1;
+    reward -= 0.001 * a2;
+    done = z < 0.5;
+  }
+}
+
 // ---------------------------------------------------------------- the fused Env.step kernel
 // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
 // WPS: waves per SIMD the register allocation is sized for.  4 (128 VGPRs, some spills) wins when the grid is only
@@ -684,6 +770,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   // anything else so that the (usual) no-op wave touches neither the state nor its scratch.
   const int n_sub = p.pending ? p.pending[env] : p.n_sub;
   if (n_sub == 0) return;
+  if (p.pending && p.stats && lane == 0) atomicAdd(p.stats + STAT_K1_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);
@@ -724,41 +811,17 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
     if (lane == 5 || lane == 11) sp -= s18[0];
     double reward = 0.0;
     int done = 0;
-    if (p.env_kind == 0) {
-      // reference-gait lookup (cassie2d_trajectory.py:16-19)
-      double tmax = p.traj_tmax;
-      int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
-      const double* rq = p.traj_qpos + (size_t)idx * NV;
-      if (lane >= 17 && lane < 26) {
-        int k = lane - 17;  // columns 0,1,2,3,4,6,8,9,11
-        int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
-        sp = rq[col];
+    env_outputs_wave(p, sm, s18, lane, p.actions ? p.actions + (size_t)env * p.adim : nullptr, p.adim, qstate_l, time, sp, reward, done);
+    // failure guard (MuJoCo's mj_checkPos/mj_checkVel): a state outside the finite range terminates the
+    // episode; the reset below then also clears everything a NaN could have reached (warm start, ctrl, setState copies)
+    const bool bad = __ballot(lane < 26 && !in_range(lane < 13 ? sm.q[lane] : sm.v[lane - 13])) != 0 || !in_range(reward);
+    if (bad) {
+      sp = 0.0; reward = 0.0; done = 1;
+      if (lane == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      if (p.auto_reset) {
+        if (lane < 13) { sm.ws[lane] = 0.0; sm.kq[lane] = cp_env_qinit[lane]; sm.kv[lane] = 0.0; }
+        if (lane < NU) sm.ctrl[lane] = 0.0;
       }
-      // reward (cassie2d.py:197-218); qstate is the reset pose unless FLAG_FIX_STALE_QSTATE (quirk Q3)
-      const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
-      auto qst = [&](int j) { return fixq ? sm.q[j] : rdlane(qstate_l, 1 + j); };
-      double j = qst(3) + qst(4) + qst(6);
-      j += qst(8) + qst(9) + qst(11);
-      double sum = 0.0;
-      for (int i = 20; i < 26; i++) sum += rdlane(sp, i);
-      j -= sum; j = exp(-(j * j));
-      double pp = s18[0] + s18[1];
-      pp -= rdlane(sp, 17) + rdlane(sp, 18); pp = exp(-(pp * pp));
-      double oo = s18[2];
-      oo -= rdlane(sp, 19); oo = exp(-(oo * oo));
-      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
-      done = (s18[1] < 0.6) || (s18[1] > 1.2) || (reward < 0.6);
-    } else {
-      double a2 = 0.0;
-      for (int i = 0; i < p.adim; i++) { double a = p.actions[(size_t)env * p.adim + i]; a2 += a * a; }
-      double z = s18[1];
-      double m = (rdlane(sp, 5) + rdlane(sp, 11)) / 2.0;
-      reward = 0.0;
-      reward -= 2 * (0.9 - z) * (0.9 - z);
-      reward -= 2 * m * m;
-      reward += 1;
-      reward -= 0.001 * a2;
-      done = z < 0.5;
     }
     if (p.terminal_obs && lane < 26) p.terminal_obs[(size_t)env * 26 + lane] = sp;
     if (done && p.auto_reset) {

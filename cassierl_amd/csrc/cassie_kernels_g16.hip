@@ -463,41 +463,21 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     }
     double obs_a = oa, obs_b = ob, reward = 0.0;
     int done = 0;
-    const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
-    if (p.env_kind == 0) {
-      double tmax = p.traj_tmax;
-      const double time = sm.tim[0];
-      int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
-      const double* rq = p.traj_qpos + (size_t)idx * NV;
-      if (l >= 1 && l < 10) {
-        int k = l - 1;
-        int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));
-        obs_b = rq[col];
-      }
+    {
       const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
-      double qv = fixq ? sm.q[l < NV ? l : 0] : sm.qst[l];
-      double j = row_bcast<3>(qv) + row_bcast<4>(qv) + row_bcast<6>(qv);
-      j += row_bcast<8>(qv) + row_bcast<9>(qv) + row_bcast<11>(qv);
-      double sum = 0.0;
-      sum += row_bcast<4>(obs_b); sum += row_bcast<5>(obs_b); sum += row_bcast<6>(obs_b);
-      sum += row_bcast<7>(obs_b); sum += row_bcast<8>(obs_b); sum += row_bcast<9>(obs_b);
-      j -= sum; j = exp(-(j * j));
-      double pp = bodyx + z;
-      pp -= row_bcast<1>(obs_b) + row_bcast<2>(obs_b); pp = exp(-(pp * pp));
-      double oo = pitch;
-      oo -= row_bcast<3>(obs_b); oo = exp(-(oo * oo));
-      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
-      done = (z < 0.6) || (z > 1.2) || (reward < 0.6);
-    } else {
-      double a2 = 0.0;
-      for (int i = 0; i < p.adim; i++) { double a = p.actions[e * p.adim + i]; a2 += a * a; }
-      double m = (row_bcast<5>(obs_a) + row_bcast<11>(obs_a)) / 2.0;
-      reward = 0.0;
-      reward -= 2 * (0.9 - z) * (0.9 - z);
-      reward -= 2 * m * m;
-      reward += 1;
-      reward -= 0.001 * a2;
-      done = z < 0.5;
+      const double qv = fixq ? sm.q[l < NV ? l : 0] : sm.qst[l];
+      env_outputs_row(p, l, p.actions ? p.actions + e * p.adim : nullptr, p.adim, sm.tim[0], bodyx, qv, obs_a, obs_b, reward, done);
+    }
+    // failure guard (see env_step_kernel): non-finite / diverged state => forced termination, reset clears every NaN carrier
+    const bool badl = l < NV && !(in_range(sm.q[l < NV ? l : 0]) && in_range(sm.v[l < NV ? l : 0]));
+    const bool bad = live && ((((unsigned)(__ballot(badl) >> (16 * g))) & 0xFFFFu) != 0 || !in_range(reward));
+    if (bad) {
+      obs_a = 0.0; obs_b = 0.0; reward = 0.0; done = 1;
+      if (l == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      if (p.auto_reset) {
+        sm.ws[l] = 0.0; sm.kq2[l] = l < NV ? cp_env_qinit[l] : 0.0; sm.kv2[l] = 0.0;
+        if (l < NU) sm.ctrl[l] = 0.0;
+      }
     }
     if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
     if (live) {
@@ -520,7 +500,10 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       st[ES_KQ + l] = sm.kq2[l]; st[ES_KV + l] = sm.kv2[l]; st[ES_QSTATE + l] = sm.qst[l];
     }
     if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
-    if (l == 0) { st[ES_TIME] = sm.tim[0]; st[ES_NITER] = (double)niter_sum; pending[env] = pend; }
+    if (l == 0) {
+      st[ES_TIME] = sm.tim[0]; st[ES_NITER] = (double)niter_sum; pending[env] = pend;
+      if (pend > 0 && p.stats) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
+    }
   }
 }
 

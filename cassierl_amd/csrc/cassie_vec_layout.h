@@ -26,6 +26,13 @@ enum {
 // route of the controllers' pseudo-inverses even where the certified shortcut applies
 enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2, FLAG_NO_PINV_SHORTCUT = 8 };
 
+// Event counters (CassieVecGetCounters).  Only rare paths touch them, so the common case issues no atomics.
+//   STAT_CLEANUP_SUBSTEPS  env-substeps the packed fast-path kernels handed to a slower general kernel (any tier)
+//   STAT_K1_SUBSTEPS       ... of those, env-substeps that went all the way to the wave-per-environment kernel
+//   STAT_NONFINITE         environments whose state left the finite range (|q|,|v| <= 1e10, NaN) and were force-terminated
+enum { STAT_CLEANUP_SUBSTEPS = 0, STAT_K1_SUBSTEPS = 1, STAT_NONFINITE = 2, STAT_N = 4 };
+constexpr double FINITE_BOUND = 1e10;  // mjMAXVAL of MuJoCo's mj_checkPos / mj_checkVel
+
 struct VecParams {
   double* state;          // [n_envs][ENV_STRIDE]
   const double* actions;  // [n_envs][adim] device
@@ -40,6 +47,7 @@ struct VecParams {
   double* ovf;            // [n_envs][ovf_stride]: A columns beyond the register-resident ones (rare slow path)
   int ovf_stride;
   const int* pending;     // [n_envs] substeps left per env (clean-up pass after the 4-envs-per-wave kernel) or null
+  unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };
 

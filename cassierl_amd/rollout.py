@@ -50,7 +50,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # CASSIE_FORCE_PROCESS_GROUP=1: build the process group even for a single rank, so that a 1-GPU box exercises the RCCL
+    # communicator and the gather exactly as an N-rank run does (tests/test_gpu_bench.py)
+    force = os.environ.get("CASSIE_FORCE_PROCESS_GROUP", "") == "1" and "MASTER_ADDR" in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -62,7 +65,7 @@ def init_distributed(backend=None):
 def gather_returns(local_returns):
     """The one collective of the path: all ranks receive the concatenated per-env episode returns
     (N/G float64 per rank; 32 KiB per rank at 4096 envs/GPU -> latency-bound on xGMI)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local_returns.clone()
     world = dist.get_world_size()
     out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)

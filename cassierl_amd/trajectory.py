@@ -3,10 +3,14 @@
 `stepdata.bin` holds 1682 rows x 98 float64 (t, qpos35, qvel32, torque10, mpos10, mvel10)
 (cassie2d_trajectory.py:6-14).  The 3-D -> 2-D conversion keeps x, z, pitch (from the base
 quaternion) and hip/knee/ankle/toe + the conrod pitch of each leg (cassie2d_trajectory.py:31-134).
-The file itself is reference data and is not shipped; tests use the small golden fixture
-tests/golden/traj2d.npz generated from it.
+The file itself is reference data and is not shipped: the 2-D table derived from it is package data
+(cassierl_amd/data/gait2d.npz, written offline by cassierl_amd/model/compile_gait.py) and `default_gait()` loads it.
 """
+import os
+
 import numpy as np
+
+GAIT_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gait2d.npz")
 
 QPOS_DROP = [1, 3, 5, 6, 7, 8, 11, 14, 15, 16, 17, 19, 20, 21, 22, 25, 28, 29, 30, 31, 33, 34]
 QVEL_DROP = [1, 3, 5, 6, 7, 10, 13, 14, 15, 16, 18, 19, 20, 23, 26, 27, 28, 29, 31]
@@ -58,6 +62,12 @@ class Cassie2dTraj:
         mpos = None if self.mpos is None else self.mpos[i]
         mvel = None if self.mvel is None else self.mvel[i]
         return (mpos, mvel, self.torque[i])
+
+
+def default_gait():
+    """The reference gait of rllab/trajectory/stepdata.bin as 2-D arrays (what Cassie2dEnv's reward reads)."""
+    d = np.load(GAIT_NPZ)
+    return Cassie2dTraj.from_arrays(d["time"], d["qpos"], d["qvel"], d["torque"])
 
 
 def pd_targets(traj, t, kp=10.0, kd=5.0):

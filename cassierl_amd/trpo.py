@@ -250,10 +250,17 @@ class AnalyticFisher:
 # --------------------------------------------------------------------------------------------- TRPO
 class TRPO:
     def __init__(self, env_step, env_reset, policy, baseline, n_envs, obs_dim, act_map, batch_size=15000, max_path_length=1000,
-                 discount=0.99, step_size=0.005, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15, seed=1):
+                 discount=0.99, step_size=0.005, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15, seed=1,
+                 env_reset_masked=None):
         """env_step(actions[N, adim] float64) -> (obs[N, obs_dim], reward[N], done[N] uint8/bool), auto-resetting;
-        env_reset() -> obs.  batch_size counts env-steps over ALL ranks, as rllab's batch_size does."""
-        self.env_step, self.env_reset = env_step, env_reset
+        env_reset() -> obs; env_reset_masked(mask uint8[N]) -> obs with the masked envs reset (used when a path is truncated
+        at max_path_length, where rllab's sampler calls env.reset()).  batch_size counts env-steps over ALL ranks, as
+        rllab's batch_size does.
+        Deviations from rllab's TRPO, on purpose: paths cut by the end of the batch are bootstrapped with the baseline's
+        value of the next observation (rllab's batch sampler discards/truncates the tail instead; with 65 536 envs x few steps
+        per iteration nearly every path is cut, so dropping the tail would bias every return); the policy runs in float32."""
+        self.env_step, self.env_reset, self.env_reset_masked = env_step, env_reset, env_reset_masked
+        self._steps_since_start = 0  # host-side upper bound of path_t: truncation cannot happen before max_path_length steps
         self.policy, self.baseline, self.act_map = policy, baseline, act_map
         self.n_envs, self.obs_dim = n_envs, obs_dim
         self.horizon = max(1, int(math.ceil(batch_size / (n_envs * _world()))))
@@ -300,6 +307,10 @@ class TRPO:
             ep_sum += torch.where(cut, self.path_ret, torch.zeros_like(self.path_ret)).sum()
             self.path_ret = torch.where(cut, torch.zeros_like(self.path_ret), self.path_ret)
             self.path_t = torch.where(cut, torch.zeros_like(self.path_t), self.path_t)
+            self._steps_since_start += 1
+            if self.env_reset_masked is not None and self._steps_since_start >= self.max_path_length:
+                # path truncated at max_path_length while the env is still alive: rllab resets the env there
+                nobs = self.env_reset_masked((cut & ~done).to(torch.uint8))
             self.obs = nobs.clone()
         return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
                     episode_count=ep_n, episode_return_sum=ep_sum)
@@ -390,17 +401,37 @@ class TRPO:
         self.itr += 1
         return stats
 
-    # ---- snapshot_mode="last" (trpo_cassie.py:50): policy, baseline, env-independent counters
-    def save(self, path, extra=None):
-        if dist.is_initialized() and dist.get_rank() != 0:
-            return
-        torch.save(dict(policy=self.policy.state_dict(), baseline=self.baseline.coeffs, itr=self.itr, extra=extra), path)
+    # ---- snapshot_mode="last" (trpo_cassie.py:9-19,50; sim_policy.py:19-23): everything a resumed run needs to BE the
+    # interrupted run -- policy, baseline, iteration, and per rank the sampler state (action-noise generator, current
+    # observation, path clocks/returns) and the resident env state records.  Rank 0 writes `path`, rank r > 0 `path.rank<r>`.
+    def _rank_path(self, path):
+        r = dist.get_rank() if dist.is_initialized() else 0
+        return path if r == 0 else "%s.rank%d" % (path, r)
 
-    def load(self, path):
-        ck = torch.load(path, map_location=next(self.policy.parameters()).device)
+    def save(self, path, extra=None):
+        env = getattr(self, "env", None)
+        ck = dict(policy=self.policy.state_dict(), baseline=self.baseline.coeffs, itr=self.itr, extra=extra,
+                  gen_state=self.gen.get_state(), obs=None if self.obs is None else self.obs.cpu(),
+                  path_t=self.path_t.cpu(), path_ret=self.path_ret.cpu(), steps_since_start=self._steps_since_start,
+                  env_state=None if env is None or not hasattr(env, "get_full_state_host") else torch.from_numpy(env.get_full_state_host()))
+        torch.save(ck, self._rank_path(path))
+
+    def load(self, path, restore_sampler=True):
+        dev = next(self.policy.parameters()).device
+        mine = self._rank_path(path)
+        import os
+        ck = torch.load(mine if os.path.exists(mine) else path, map_location="cpu", weights_only=False)
         self.policy.load_state_dict(ck["policy"])
-        self.baseline.coeffs = ck["baseline"]
+        self.baseline.coeffs = None if ck["baseline"] is None else ck["baseline"].to(dev)
         self.itr = ck["itr"]
+        env = getattr(self, "env", None)
+        if restore_sampler and os.path.exists(mine) and ck.get("env_state") is not None and env is not None \
+                and tuple(ck["env_state"].shape) == (self.n_envs, 88):
+            env.set_full_state_host(ck["env_state"].numpy())
+            self.gen.set_state(ck["gen_state"])
+            self.obs = None if ck["obs"] is None else ck["obs"].to(dev)
+            self.path_t, self.path_ret = ck["path_t"].to(dev), ck["path_ret"].to(dev)
+            self._steps_since_start = ck.get("steps_since_start", 0)
         return ck.get("extra")
 
 
@@ -411,8 +442,14 @@ def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajector
     env.use_torch_stream()
     dev = "cuda:%d" % device
     bufs = env.alloc()
+    torch.manual_seed(seed)  # trpo_cassie.py:53 seed=1: every rank builds the same initial policy ...
     policy = GaussianMLPPolicy(26, env.adim, (32, 32), init_std=2.0).to(dev)
+    if dist.is_initialized() and dist.get_world_size() > 1:  # ... and rank 0's parameters are authoritative anyway
+        theta = flat_params(policy)
+        dist.broadcast(theta, 0)
+        set_flat_params(policy, theta)
     act_map = NormalizedActions(env.action_space.low, env.action_space.high, dev)
-    algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, 26, act_map, seed=seed, **kw)
+    algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, 26, act_map, seed=seed,
+                env_reset_masked=lambda m: env.reset(bufs, mask=m), **kw)
     algo.env = env
     return algo

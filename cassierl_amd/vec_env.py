@@ -86,6 +86,18 @@ class CassieVecEnv:
     def synchronize(self):
         self._chk(self.L.CassieVecSynchronize(self.h))
 
+    def counters(self):
+        """Event counters since create / reset_counters(): env-substeps requested, env-substeps that left the packed fast
+        path, of those the ones done by the wave-per-environment kernel, environments stopped by the failure guard."""
+        out = (ct.c_uint64 * 4)()
+        self._chk(self.L.CassieVecGetCounters(self.h, out))
+        req, cleanup, k1, bad = (int(x) for x in out)
+        return dict(substeps=req, cleanup_substeps=cleanup, k1_substeps=k1, nonfinite_resets=bad,
+                    cleanup_frac=(cleanup / req if req else 0.0), k1_frac=(k1 / req if req else 0.0))
+
+    def reset_counters(self):
+        self._chk(self.L.CassieVecResetCounters(self.h))
+
     @property
     def observation_space(self):
         high = np.full((26,), 1e20)  # cassie2d.py:337-341

@@ -64,8 +64,18 @@ void CassieVecFree(CassieVec* h);
 const char* CassieVecLastError(const CassieVec* h);
 int CassieVecNumEnvs(const CassieVec* h);
 int CassieVecActionDim(const CassieVec* h);
-int CassieVecSetStream(CassieVec* h, void* hip_stream);
+int CassieVecSetStream(CassieVec* h, void* hip_stream); /* synchronises the previous stream; NULL = default stream */
 int CassieVecSynchronize(CassieVec* h);
+
+/* Event counters since create / the last CassieVecResetCounters (synchronises the stream):
+ *   out4[0] env-substeps requested (n_envs x substeps of every step call)
+ *   out4[1] env-substeps the packed fast-path kernels could not do (more constraint rows than they hold) and handed over
+ *   out4[2] ... of those, env-substeps done by the wave-per-environment kernel (the slowest tier)
+ *   out4[3] environments force-terminated by the failure guard: a state with NaN or |q|,|v| > 1e10 ends the episode
+ *           (done = 1, reward 0, observation 0 / the reset observation) instead of poisoning the batch.  The reference
+ *           has no such guard (it exits on load failure only, Cassie2d.cpp:49-52); MuJoCo's mj_checkPos/Vel is the model. */
+int CassieVecGetCounters(CassieVec* h, uint64_t* out4);
+int CassieVecResetCounters(CassieVec* h);
 
 /* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */
 int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* qpos_host, int n);

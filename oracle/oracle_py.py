@@ -24,10 +24,26 @@ def build(force=False):
     return so
 
 
+_FAST = False
+
+
+def use_fast_build():
+    """bench.py's cpu_baseline leg only: (re)build the oracle with -O3 -march=native on THIS machine and bind it instead of
+    the -O2 -ffp-contract=off parity build.  Must be called before the first lib().  Returns False if that build fails."""
+    global _FAST
+    assert _LIB is None, "use_fast_build() must come before the oracle library is first used"
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "liboracle_fast.so"])
+        _FAST = True
+    except Exception:
+        _FAST = False
+    return _FAST
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = ct.CDLL(build())
+        L = ct.CDLL(os.path.join(HERE, "liboracle_fast.so") if _FAST else build())
         L.orc_create.restype = ct.c_void_p
         L.orc_env_create.restype = ct.c_void_p
         L.orc_env_oracle.restype = ct.c_void_p

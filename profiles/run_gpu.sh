@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box session: the -m gpu suite, the bench line as the driver runs it, and the rocprofv3 kernel statistics of the same
+# command.   usage (repo root, MI355X box):  bash profiles/run_gpu.sh <tag> [tests|bench|prof ...]
+set -u
+tag=${1:-r02_x}; shift || true
+what=${*:-tests bench prof}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+rm -f "$root/gpurun_out/fullsize.jsonl"
+for w in $what; do
+  case $w in
+    tests)
+      timeout 3000 python3 -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+      tail -5 "$out/pytest_gpu.log"
+      [ -f "$root/gpurun_out/fullsize.jsonl" ] && cp "$root/gpurun_out/fullsize.jsonl" "$out/fullsize.jsonl" ;;
+    bench)
+      timeout 900 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
+      tail -c 3000 "$out/bench.json" ;;
+    prof)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
+          python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline > "$out/stats_bench.log" 2>&1 )
+      find "$out/stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
+  esac
+done

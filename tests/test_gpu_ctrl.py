@@ -292,3 +292,45 @@ def test_standing_controller_osc_with_current_kinematics_flag(vec, oracle_mod, w
         worst = max(worst, np.abs(sg[0, :13] - q1).max(), np.abs(sg[0, 13:26] - v1).max() / (1 + np.abs(v1).max()))
     assert worst < 1e-5, worst
     env.close()
+
+
+def test_dynamic_state_terms_match_the_oracle(vec, oracle_mod):
+    """SURVEY.md row R5, directly: DynamicState::UpdateDynamicState (src/DynamicState.cpp:45-91) -- M (CRBA + rotor inertia),
+    bias (NonlinearEffects + damping*qvel), the contact-site Jacobians Jc, the loop-closure Jacobian Jeq and JeqdotQdot -- as
+    the controller kernel builds them (RBDL-semantics tables), against oracle/cassie_oracle.c:update_dynamic_state on random
+    moving states.  The kernel keeps Hinv = M^-1 (never M), so M is compared through the inverse."""
+    rng = np.random.default_rng(77)
+    n = 6
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    q0, _ = o.state()
+    states, refs = [], []
+    for i in range(n):
+        q = q0 + rng.uniform(-0.15, 0.15, 13) * (i > 0)
+        v = rng.uniform(-1.5, 1.5, 13) * (i > 0)
+        o.reset(q, v)
+        refs.append(o.dynamic_state())
+        states.append(state_vec(q, v))
+    env.set_full_state_host(np.array(states))
+    dbg = env.debug_substep_host("Jacobian", np.zeros((n, 6)))
+    for i, ref in enumerate(refs):
+        d = dbg[i]
+        Hinv = d[325:325 + 169].reshape(13, 13)
+        M = np.linalg.inv(Hinv)
+        assert np.abs(M - ref["M"]).max() < 1e-9 * np.abs(ref["M"]).max(), i
+        assert np.abs(Hinv - np.linalg.inv(ref["M"])).max() < 1e-9 * np.abs(Hinv).max()
+        assert np.abs(d[97:110] - ref["bias"]).max() < 1e-9 * (1 + np.abs(ref["bias"]).max()), i
+        Jd = d[130:130 + 195].reshape(15, 13)
+        acc = d[494:509]
+        # loop closures: oracle rows (x, y, z) per connect, kernel rows (x, z); the world-y rows are identically zero
+        assert np.abs(ref["Jeq"][[1, 4]]).max() < 1e-14 and np.abs(ref["JeqdotQdot"][[1, 4]]).max() < 1e-12
+        assert np.abs(Jd[0:4] - ref["Jeq"][[0, 2, 3, 5]]).max() < 1e-11, i
+        assert np.abs(acc[0:4] - ref["JeqdotQdot"][[0, 2, 3, 5]]).max() < 1e-9 * (1 + np.abs(ref["JeqdotQdot"]).max()), i
+        # contact sites 2..5: oracle Jc rows 3 s + (0, 1, 2); kernel controller rows 6.. (x, z per site)
+        Jc = ref["Jc"].reshape(4, 3, 13)
+        assert np.abs(Jc[:, 1]).max() < 1e-14
+        assert np.abs(Jd[6:14].reshape(4, 2, 13) - Jc[:, [0, 2]]).max() < 1e-11, i
+        # selector matrix: gear on the actuated dofs (DynamicModel.cpp:197-216)
+        Bt = ref["Bt"]
+        assert np.count_nonzero(Bt) == 6 and [Bt[j, k] for k, j in enumerate((3, 4, 6, 8, 9, 11))] == [16, 16, 100, 16, 16, 100]
+    env.close()

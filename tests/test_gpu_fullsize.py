@@ -1,0 +1,328 @@
+"""Full-size runs of every BASELINE.json config on the HIP path: sampled environments against the oracle where the dynamics
+allow it, size-independent properties (determinism across grid positions, finiteness, bands, counters) everywhere.  -m gpu only.
+Each test appends one JSON line to gpurun_out/fullsize.jsonl (copied into profiles/ per round)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PD_LO, PD_HI = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+TQ = np.array([12.0, 12.0, 0.9] * 2)
+FIXQ = 2
+
+
+def record(**kw):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "fullsize.jsonl"), "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from cassierl_amd.vec_env import CassieVecEnv
+    return CassieVecEnv
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]
+@pytest.mark.parametrize("flags,steps,tol", [(0, 20, 1e-8), (FIXQ, 8, 1e-6)])
+def test_configs1_4096_walk_pd_sampled_envs_follow_the_oracle(vec, oracle_mod, traj, flags, steps, tol):
+    """configs[1]: 4096 envs, walk env, PD mode, random policy.  64 sampled environments are replayed by the oracle env with
+    the same actions.  flags=0 is the reference-faithful regime (quirk Q3: every step terminates and auto-resets, so the
+    comparison holds for any number of steps); with CASSIE_FIX_STALE_QSTATE the robots run free, so the window is the
+    first 80 substeps (PD is chaotic beyond ~100, see test_gpu_parity.py)."""
+    import torch
+    from cassierl_amd import rollout as R
+    n = 4096
+    env = vec(n, kind="walk", control_mode="PD", n_substeps=10, flags=flags, auto_reset=True)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    sample = np.unique(np.concatenate([np.arange(0, n, 67), [1, 2, 3, n - 1]]))[:64]
+    oes = [oracle_mod.OracleEnv("walk", "PD", flags=flags, traj=traj) for _ in sample]
+    out = env.alloc()
+    obs0 = env.reset(out).cpu().numpy()
+    for k, e in enumerate(oes):
+        assert np.abs(e.reset() - obs0[sample[k]]).max() < 1e-12
+    ids = torch.arange(n, device="cuda")
+    worst, ndone = 0.0, 0
+    for t in range(steps):
+        a = R.random_actions(1, ids, t, PD_LO, PD_HI)
+        o, r, d = env.step(a, out)
+        o, r, d, ah = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), a.cpu().numpy()
+        ndone += int(d.sum())
+        for k, e in enumerate(oes):
+            i = sample[k]
+            oo, rr, dd = e.step(ah[i])
+            assert bool(d[i]) == dd, (t, i)
+            if dd:
+                oo = e.reset()  # the kernel returns the reset observation of a terminated env (auto_reset)
+            worst = max(worst, abs(r[i] - rr), np.abs(o[i] - oo).max())
+    assert worst < tol, worst
+    c = env.counters()
+    assert c["nonfinite_resets"] == 0
+    record(test="configs1_4096_walk_pd", flags=flags, steps=steps, sampled=len(sample), worst=worst, episodes=ndone, **c)
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]
+def test_configs2_65536_osc_standing_controller_properties(vec):
+    """configs[2]: 65 536 envs with the OSC controller (QP) in every substep -- standing_controller_osc(zpos=0.9).  17 distinct
+    initial perturbations are tiled over the batch (17 is coprime to the 4 envs per wavefront and to the grid), so every
+    state is integrated by many different (workgroup, 16-lane row) positions: all replicas must agree BIT FOR BIT, stay finite,
+    keep the pelvis inside the standing band and never need the slow path."""
+    import torch
+    n, nsub = 65536, 100
+    env = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    rng = np.random.default_rng(5)
+    s = env.get_full_state_host()
+    pert = rng.uniform(-0.01, 0.01, (17, 13))
+    pert[0] = 0
+    k = np.arange(n) % 17
+    s[:, 0:13] += pert[k]
+    s[:, 39:52] += pert[k]
+    env.set_full_state_host(s)
+    zp = torch.full((n,), 0.9, dtype=torch.float64, device="cuda")
+    zv = torch.zeros(n, dtype=torch.float64, device="cuda")
+    env.reset_counters()
+    t0 = time.perf_counter()
+    env._chk(env.L.CassieVecStandingStep(env.h, 2, zp.data_ptr(), zv.data_ptr(), nsub))
+    env.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = env.get_full_state_host()
+    assert np.isfinite(s1).all()
+    for j in range(17):
+        grp = s1[k == j]
+        assert (grp[:, :39] == grp[0, :39]).all(), j  # qpos, qvel, warm start: bit-identical across grid positions
+    z = s1[:, 1]
+    assert z.min() > 0.8 and z.max() < 1.0, (z.min(), z.max())
+    assert np.abs(s1[:, 2]).max() < 0.2  # pitch
+    c = env.counters()
+    assert c["nonfinite_resets"] == 0 and c["k1_substeps"] == 0
+    record(test="configs2_65536_osc", substeps=nsub, seconds=dt, controller_substeps_per_s=n * nsub / dt, zmin=float(z.min()), zmax=float(z.max()), **c)
+    env.close()
+
+
+def test_configs2_65536_stand_env_osc_step_replicas(vec):
+    """cassie_stand2d Env.step with OSC actions at 65 536 envs: replicas of the same (state, action) agree bit for bit across the
+    grid, outputs finite, reward consistent with its definition (cassie_stand2d.py:118-125)."""
+    import torch
+    n = 65536
+    env = vec(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
+    rng = np.random.default_rng(6)
+    base_act = rng.uniform(-1, 1, (13, 7)) * np.array([2, 2, 1, 1, 1, 1, 2.0])
+    base_act[:, 3], base_act[:, 5] = np.abs(base_act[:, 3]), np.abs(base_act[:, 5])
+    k = np.arange(n) % 13
+    a = torch.as_tensor(base_act[k], device="cuda")
+    out = env.alloc()
+    env.reset(out)
+    for _ in range(5):
+        o, r, d = env.step(a, out)
+    o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+    assert np.isfinite(o).all() and np.isfinite(r).all()
+    for j in range(13):
+        m = k == j
+        assert (o[m] == o[m][0]).all() and (r[m] == r[m][0]).all() and (d[m] == d[m][0]).all(), j
+    z = o[:, 0]
+    keep = d == 0
+    expect = 1 - 2 * (0.9 - z) ** 2 - 2 * ((o[:, 5] + o[:, 11]) / 2) ** 2 - 0.001 * (base_act[k] ** 2).sum(1)
+    assert np.abs(r[keep] - expect[keep]).max() < 1e-12
+    record(test="configs2_65536_stand_osc_step", done=int(d.sum()), **env.counters())
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ 65 536 envs, PD / torque
+@pytest.mark.parametrize("kind,mode,flags", [("walk", "PD", FIXQ), ("stand", "Torque", 0)])
+def test_65536_envs_moving_robots_fast_path_vs_general_kernel(vec, traj, kind, mode, flags):
+    """The regime the headline does NOT see: robots that move, hit joint limits and fall (more than 16 constraint rows).
+    After 60 free-running Env.steps the whole batch is stepped once more by the packed kernels and, from the same states,
+    by the wave-per-environment kernel: results agree to 1e-10, episodes keep terminating, nothing is non-finite, and the
+    share of env-substeps that left the fast path is recorded."""
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 65536
+    a_env = vec(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags, auto_reset=True)
+    b_env = vec(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags | WAVE_PER_ENV, auto_reset=True)
+    for e in (a_env, b_env):
+        e.set_trajectory(traj["time"], traj["qpos"])
+    lo, hi = (PD_LO, PD_HI) if mode == "PD" else (-TQ, TQ)
+    ids = torch.arange(n, device="cuda")
+    out, outb = a_env.alloc(), b_env.alloc()
+    a_env.reset(out)
+    a_env.reset_counters()
+    ndone = 0
+    for t in range(60):
+        _, _, d = a_env.step(R.random_actions(9, ids, t, lo, hi), out)
+        ndone += int(d.sum())
+    c = a_env.counters()
+    b_env.set_full_state_host(a_env.get_full_state_host())
+    act = R.random_actions(9, ids, 60, lo, hi)
+    oa, ra, da = (x.cpu().numpy() for x in a_env.step(act, out))
+    ob, rb, db = (x.cpu().numpy() for x in b_env.step(act, outb))
+    sa, sb = a_env.get_full_state_host(), b_env.get_full_state_host()
+    assert np.isfinite(sa).all() and np.isfinite(oa).all()
+    err = np.abs(sa[:, :26] - sb[:, :26]).max(axis=1) / (1.0 + np.abs(sb[:, :26]).max(axis=1))
+    assert err.max() < 1e-10 and np.abs(oa - ob).max() < 1e-9 and np.abs(ra - rb).max() < 1e-10
+    assert (da != db).sum() == 0
+    assert ndone > n  # episodes end and restart (robots fall)
+    assert c["nonfinite_resets"] == 0
+    record(test="65536_moving_robots", kind=kind, mode=mode, flags=flags, episodes=ndone, worst=float(err.max()), **c)
+    a_env.close(); b_env.close()
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_configs4_16384_cassie3d_properties():
+    """configs[4]: 16 384 Cassie3d envs, random torques, robots collapse onto the floor.  No env may be dropped (every constraint
+    count is handled), replicas tiled with period 11 agree bit for bit, states stay finite."""
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd.vec_env3d import Cassie3dVec, CTRL_RANGE
+    n = 16384
+    e3 = Cassie3dVec(n)
+    ids = torch.arange(n, device="cuda") % 11
+    t0 = time.perf_counter()
+    for t in range(120):
+        e3.step(R.random_actions(5, ids, t, -CTRL_RANGE, CTRL_RANGE), 10)
+    e3.synchronize()
+    dt = time.perf_counter() - t0
+    s = e3.get_state_host()
+    assert np.isfinite(s).all()
+    assert (s[:, 74] == 0).all(), "environments frozen by a constraint-row overflow: %d" % int((s[:, 74] != 0).sum())
+    k = np.arange(n) % 11
+    for j in range(11):
+        grp = s[k == j]
+        assert (grp[:, :61] == grp[0, :61]).all(), j
+    assert s[:, 2].min() < 0.5  # robots did fall (pelvis height)
+    row = dict(test="configs4_16384_cassie3d", steps=120, env_steps_per_s=n * 120 / dt, max_rows=float(s[:, 73].max()))
+    if hasattr(e3, "counters"):
+        row.update(e3.counters())
+    record(**row)
+    e3.close()
+
+
+# ------------------------------------------------------------------------------------------------ configs[3], one rank's share
+def test_configs3_one_rank_trpo_iteration_65536_envs():
+    """configs[3] is 8 x 65 536 envs under TRPO; this is one rank's share on one GPU: a full TRPO iteration (policy rollout of
+    65 536 envs x 8 Env.steps = 524 288 samples, baseline fit, CG + line search) and a second one from the updated policy."""
+    import torch
+    from cassierl_amd.trajectory import default_gait
+    from cassierl_amd.trpo import make_cassie_trpo
+    n = 65536
+    algo = make_cassie_trpo(n, kind="stand", control_mode="Torque", device=0, trajectory=default_gait(), seed=1, batch_size=n * 8)
+    t0 = time.perf_counter()
+    st = [algo.train_iteration() for _ in range(2)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for s in st:
+        assert s["env_steps"] == n * 8 and s["gathered"] == n
+        assert np.isfinite([s["loss_before"], s["loss_after"], s["avg_reward"]]).all()
+        assert 0 <= s["kl"] <= 0.005 + 1e-9 and s["loss_after"] <= s["loss_before"]
+    assert st[0]["backtracks"] >= 0
+    c = algo.env.counters()
+    assert c["nonfinite_resets"] == 0
+    record(test="configs3_one_rank_trpo_65536", seconds_two_iterations=dt, env_steps_per_s=2 * n * 8 / dt,
+           kl=[s["kl"] for s in st], avg_reward=[s["avg_reward"] for s in st], **c)
+    algo.env.close()
+
+
+# ------------------------------------------------------------------------------------------------ stress / soak (were scripts)
+@pytest.mark.parametrize("kind,mode", [("walk", "PD"), ("stand", "Torque"), ("stand", "OSC"), ("stand", "Jacobian")])
+def test_stress_packed_kernels_agree_with_wave_per_env(vec, traj, kind, mode):
+    """4099 envs (not a multiple of 4), 25 teacher-forced Env.steps: the packed kernels with their hand-over passes against the
+    wave-per-environment kernels, every control mode, random actions over (and beyond) the action box."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n, steps = 4099, 25
+    rng = np.random.default_rng(0)
+    a = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+    b = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
+    for e in (a, b):
+        e.set_trajectory(traj["time"], traj["qpos"])
+    a.reset_host(); b.reset_host()
+    lo, hi = a.action_space.low, a.action_space.high
+    if mode == "OSC":
+        lo, hi = np.array([-6, -6, -2, 0, -2, 0, -6.0]), np.array([6, 6, 2, 2, 2, 2, 6.0])
+    if mode == "Jacobian":
+        lo, hi = np.array([-60.0, 0.0, -25.0] * 2), np.array([60.0, 250.0, 25.0] * 2)
+    worst, ndone, bad = 0.0, 0, 0
+    for t in range(steps):
+        acts = rng.uniform(lo, hi, (n, a.adim))
+        b.set_full_state_host(a.get_full_state_host())
+        oa, ra, da = a.step_host(acts)
+        ob, rb, db = b.step_host(acts)
+        sa, sb = a.get_full_state_host(), b.get_full_state_host()
+        err = np.abs(sa[:, :26] - sb[:, :26]).max(axis=1) / (1.0 + np.abs(sb[:, :26]).max(axis=1))
+        worst = max(worst, float(err.max()), float(np.abs(oa - ob).max()), float(np.abs(ra - rb).max()))
+        bad += int((da != db).sum()) + int((~np.isfinite(sa)).any())
+        ndone += int(da.sum())
+    assert worst < 1e-9 and bad == 0, (worst, bad)
+    record(test="stress_agree", kind=kind, mode=mode, n=n, steps=steps, worst=worst, episodes=ndone, **a.counters())
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind,mode,n,steps", [("walk", "PD", 65536, 120), ("stand", "Torque", 65536, 120), ("stand", "OSC", 16384, 60),
+                                               ("stand", "Jacobian", 16384, 60)])
+def test_soak_long_random_rollouts_stay_finite(vec, traj, kind, mode, n, steps):
+    import torch
+    from cassierl_amd import rollout as R
+    env = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    out = env.alloc()
+    env.reset(out)
+    ids = torch.arange(n, device="cuda")
+    lo, hi = env.action_space.low, env.action_space.high
+    if mode == "Jacobian":
+        lo, hi = np.array([-80.0, -50.0, -40.0] * 2), np.array([80.0, 400.0, 40.0] * 2)
+    t0 = time.perf_counter()
+    ndone = torch.zeros((), dtype=torch.int64, device="cuda")
+    for t in range(steps):
+        o, r, done = env.step(R.random_actions(3, ids, t, lo, hi), out)
+        ndone += done.sum()
+    env.synchronize()
+    dt = time.perf_counter() - t0
+    q, v = env.get_state_host()
+    assert np.isfinite(q).all() and np.isfinite(v).all() and bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
+    c = env.counters()
+    record(test="soak", kind=kind, mode=mode, n=n, steps=steps, seconds=dt, env_steps_per_s=n * steps / dt, episodes=int(ndone), vmax=float(np.abs(v).max()), **c)
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------------ failure guard
+@pytest.mark.parametrize("mode,wave_per_env", [("PD", False), ("PD", True), ("OSC", False), ("OSC", True)])
+def test_failure_guard_terminates_and_resets_poisoned_envs(vec, traj, mode, wave_per_env):
+    """SURVEY.md section 5 'failure detection': an env whose state goes NaN / diverges is force-terminated (done = 1, reward 0),
+    counted, and -- with auto_reset -- comes back clean; its neighbours in the same wavefront are untouched."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 12
+    kind = "walk" if mode == "PD" else "stand"
+    env = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV if wave_per_env else 0)
+    ref = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV if wave_per_env else 0)
+    for e in (env, ref):
+        e.set_trajectory(traj["time"], traj["qpos"])
+        e.reset_host()
+    s = env.get_full_state_host()
+    s[1, 4] = np.nan          # qpos
+    s[6, 13 + 2] = np.inf     # qvel
+    s[9, 26 + 3] = np.nan     # warm start only: poisons qacc -> the state after one substep
+    s[10, 3] = 5e10           # diverged, still finite
+    env.set_full_state_host(s)
+    rng = np.random.default_rng(1)
+    a = rng.uniform(env.action_space.low, env.action_space.high, (n, env.adim)) * (0.1 if mode == "OSC" else 1.0)
+    o, r, d = env.step_host(a)
+    o2, r2, d2 = ref.step_host(a)
+    badset = [1, 6, 9, 10]
+    good = [i for i in range(n) if i not in badset]
+    assert d[badset].all() and (r[badset] == 0).all()
+    assert np.isfinite(o).all() and np.isfinite(r).all()
+    assert np.array_equal(o[good], o2[good]) and np.array_equal(r[good], r2[good]) and np.array_equal(d[good], d2[good])
+    assert env.counters()["nonfinite_resets"] == 4
+    s1 = env.get_full_state_host()
+    assert np.isfinite(s1).all()
+    # the poisoned envs restart from the reset pose exactly like an env that terminated normally
+    o3, r3, d3 = env.step_host(a)
+    assert np.isfinite(o3).all() and np.isfinite(r3).all()
+    assert env.counters()["nonfinite_resets"] == 4
+    env.close(); ref.close()

@@ -130,6 +130,71 @@ def test_checkpoint_roundtrip(tmp_path):
     assert torch.equal(other.baseline.coeffs, algo.baseline.coeffs)
 
 
+class SnapshotToyEnv(ToyVecEnv):
+    """ToyVecEnv with the two state-record hooks the snapshot uses (88 doubles per env, like the Cassie2d record)."""
+
+    def get_full_state_host(self):
+        s = np.zeros((self.n, 88))
+        s[:, 0], s[:, 1], s[:, 2], s[:, 3] = self.x.numpy(), self.v.numpy(), self.tg.numpy(), self.t.numpy()
+        return s
+
+    def set_full_state_host(self, s):
+        self.x, self.v, self.tg = (torch.tensor(s[:, i].copy()) for i in range(3))
+        self.t = torch.tensor(s[:, 3].astype(np.int64))
+
+
+def _snap_algo(seed):
+    env = SnapshotToyEnv(32, seed)
+    env.g = None  # resets draw no randomness below (episodes of 20 steps never end inside the compared window)
+    torch.manual_seed(seed)
+    pol = T.GaussianMLPPolicy(4, 2, (32, 32), init_std=1.0, dtype=torch.float64)
+    algo = T.TRPO(env.step, env.reset, pol, T.LinearFeatureBaseline(), 32, 4, T.NormalizedActions([-1, -1], [1, 1], "cpu"),
+                  batch_size=32 * 4, seed=seed)
+    algo.env = env
+    return algo
+
+
+def test_resumed_run_is_the_interrupted_run(tmp_path):
+    """SURVEY.md section 5 checkpoint/resume: the snapshot carries policy, baseline AND the sampler state (env records,
+    action-noise generator, observation, path clocks), so iteration k+1 after a resume equals iteration k+1 without one."""
+    a = _snap_algo(2)
+    a.env.g = torch.Generator().manual_seed(2); a.env.reset(); a.obs = None
+    a.train_iteration()
+    p = str(tmp_path / "snap.pt")
+    a.save(p)
+    ref = a.train_iteration()
+    b = _snap_algo(7)  # different seed: everything must come from the snapshot
+    b.env.g = torch.Generator().manual_seed(99)
+    b.load(p)
+    got = b.train_iteration()
+    assert got["itr"] == ref["itr"] == 1
+    assert abs(got["avg_reward"] - ref["avg_reward"]) < 1e-12 and abs(got["loss_before"] - ref["loss_before"]) < 1e-12
+    assert torch.allclose(T.flat_params(a.policy), T.flat_params(b.policy), atol=1e-12)
+
+
+def test_truncated_paths_reset_the_env():
+    """rllab's sampler calls env.reset() when a path reaches max_path_length: the masked-reset hook is called
+    with exactly the envs that were cut without terminating, and the next observation is the reset one."""
+    env = ToyVecEnv(8, 0)
+    calls = []
+
+    def reset_masked(mask):
+        calls.append(mask.clone())
+        idx = mask.bool().nonzero().squeeze(-1)
+        env.x[idx] = 0; env.v[idx] = 0; env.t[idx] = 0
+        return env._obs()
+
+    torch.manual_seed(0)
+    pol = T.GaussianMLPPolicy(4, 2, (32, 32), init_std=1.0, dtype=torch.float64)
+    algo = T.TRPO(env.step, env.reset, pol, T.LinearFeatureBaseline(), 8, 4, T.NormalizedActions([-1, -1], [1, 1], "cpu"),
+                  batch_size=8 * 12, max_path_length=5, env_reset_masked=reset_masked)
+    batch = algo.collect()
+    assert len(calls) == 12 - 4  # possible from the 5th step on
+    assert all(int(c.sum()) == (8 if (i + 5) % 5 == 0 else 0) for i, c in enumerate(calls))
+    assert batch["done"][4].all() and batch["done"][9].all() and not batch["done"][5].any()
+    assert (batch["t"][5] == 0).all() and (batch["obs"][5][:, 0] == 0).all()  # x was reset to 0
+
+
 # ---- data-parallel update: 2 ranks with half the batch each == 1 process with the whole batch
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()

@@ -30,12 +30,11 @@ def main():
     args = ap.parse_args()
     import torch
     from cassierl_amd import rollout as R
-    from cassierl_amd.trajectory import Cassie2dTraj
+    from cassierl_amd.trajectory import default_gait
     from cassierl_amd.trpo import make_cassie_trpo
     rank, local_rank, world = R.init_distributed()
     torch.cuda.set_device(local_rank if world > 1 else 0)
-    d = np.load(os.path.join(ROOT, "tests", "golden", "traj2d.npz"))
-    traj = Cassie2dTraj.from_arrays(d["time"], d["qpos"])
+    traj = default_gait()
     algo = make_cassie_trpo(args.envs_per_gpu, kind=args.kind, control_mode=args.control_mode, device=local_rank if world > 1 else 0,
                             trajectory=traj, seed=1, batch_size=args.envs_per_gpu * world * args.horizon)
     algo.timing = args.timing
