@@ -105,10 +105,10 @@ def cpu_baseline(traj, cores, budget_s=12.0):
 
 
 # ------------------------------------------------------------------------------------------------ extra workloads (N=1)
-def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn, note):
+def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn, note, auto_reset=True):
     import torch
     from cassierl_amd.vec_env import CassieVecEnv
-    env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags, auto_reset=True, device=0)
+    env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags, auto_reset=auto_reset, device=0)
     if kind == "walk":
         env.set_trajectory(traj["time"], traj["qpos"])
     env.use_torch_stream()
@@ -143,15 +143,21 @@ def extra_workloads(traj, n):
     rows = []
     pd_box = VE.action_space("PD")
     tq_box = VE.action_space("Torque")
-    # (a) walk / PD with the reward reading the CURRENT joint angles: episodes run until the robot leaves z in [0.6, 1.2] or
-    #     drifts from the reference gait, so robots move, hit joint limits and fall before the auto-reset
-    rows.append(run_env_workload("walk_pd_fix_stale_qstate", n, "walk", "PD", VE.FIX_STALE_QSTATE, traj, 150, 40,
+    # (a) stand env / PD mode, random joint targets over the PD box: robots thrash, hit joint limits and fall; reset at z < 0.5.
+    #     (The walk env cannot serve here: its reward needs the pose to track the reference gait, so under a random policy every
+    #     step ends the episode even with quirk Q3 fixed -- measured, episodes_terminated_per_env_step = 1.0.)
+    rows.append(run_env_workload("stand_pd_random", n, "stand", "PD", 0, traj, 150, 40,
                                  lambda t: R.random_actions(2, ids, t, pd_box.low, pd_box.high),
-                                 "cassie2d.py with quirk Q3 fixed (CASSIE_FIX_STALE_QSTATE), random PD policy"))
+                                 "cassie_stand2d.py reward/termination, StepPd with random joint targets"))
     # (b) stand env / torque mode, U(+-ctrlrange): free falls onto the ground, reset at z < 0.5 (random_agent.py-style)
     rows.append(run_env_workload("stand_torque_random", n, "stand", "Torque", 0, traj, 150, 40,
                                  lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
                                  "cassie_stand2d.py reward/termination, random torques in ctrlrange"))
+    # (b') the floor: no auto-reset, so after the warm-up every robot lies on the ground with many contacts and joint limits
+    #      active -- the regime in which environments leave the 16-row packed kernel
+    rows.append(run_env_workload("torque_random_no_reset_fallen", n, "stand", "Torque", 0, traj, 200, 20,
+                                 lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
+                                 "random torques, auto_reset off: robots on the ground (throughput floor of the PD/torque path)", auto_reset=False))
     # (c) configs[2]: OSC controller (QP) in every substep, cassie_stand2d Env.step with small random OSC targets
     osc_lo, osc_hi = np.array([-2.0, -2.0, -2.0, 0.0, -2.0, 0.0, -2.0]), np.full(7, 2.0)
     rows.append(run_env_workload("configs[2]_stand_osc_in_loop", n, "stand", "OSC", 0, traj, 20, 30,
@@ -304,11 +310,18 @@ def worker(args):
             line["cpu_baseline"] = cpu_baseline(traj, cores)
         else:
             line["cpu_baseline"] = None
+    if R.dist.is_initialized():
+        R.dist.barrier()
+        R.dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its banner ("Librccl path : ...") through C stdio, which is flushed at exit when stdout is a pipe: flush
+        # it now so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
     return rc
 
 

@@ -136,6 +136,7 @@ struct Oracle {
   /* test knobs */
   double gravity_z, damping[NV];
   int contact_enabled;
+  int assume; /* ORC_ASSUME_* bits: the places where closed MuJoCo Pro 1.50 may differ from the published 2.x pipeline */
   /* constants derived at create (what MuJoCo's compiler / LoadModel derive) */
   double eq_anchor2[2][NEQ][3];
   double dof_invweight0[NV], body_invweight0[NB], meaninertia;
@@ -416,12 +417,13 @@ static void make_constraints(Oracle* o) {
   }
 }
 
-static double impedance(const double* solimp, double pos, double margin) {
+static double impedance(const double* solimp, double pos, double margin, int smoothstep) {
   if (solimp[0] == solimp[1] || solimp[2] <= MINVAL) return 0.5 * (solimp[0] + solimp[1]);
   double x = fabs((pos - margin) / solimp[2]);
   if (x >= 1) return solimp[1];
   if (x <= 0) return solimp[0];
-  double y = x <= 0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x); /* midpoint 0.5, power 2 */
+  double y = x <= 0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x); /* MuJoCo 2.x defaults: midpoint 0.5, power 2 */
+  if (smoothstep) y = x * x * (3 - 2 * x);                      /* ORC_ASSUME_IMP_SMOOTHSTEP: cubic sigmoid candidate */
   return solimp[0] + y * (solimp[1] - solimp[0]);
 }
 
@@ -436,7 +438,14 @@ static void make_impedance(Oracle* o) {
     double tc = solref[0], dr = solref[1], dmax = solimp[1];
     if (tc < 2 * CM_TIMESTEP) tc = 2 * CM_TIMESTEP; /* refsafe */
     double kk = 1.0 / (dmax * dmax * tc * tc * dr * dr), bb = 2.0 / (dmax * tc);
-    double imp = impedance(solimp, o->efc_pos[i], o->efc_margin[i]);
+    double ipos = o->efc_pos[i];
+    if ((o->assume & ORC_ASSUME_CONNECT_NORM_IMP) && o->efc_type[i] == CT_EQUALITY) {
+      /* candidate: one impedance per connect constraint, evaluated at the NORM of its 3-vector violation */
+      int i0 = i;
+      while (i0 > 0 && o->efc_type[i0 - 1] == CT_EQUALITY && o->efc_id[i0 - 1] == o->efc_id[i]) i0--;
+      ipos = sqrt(o->efc_pos[i0] * o->efc_pos[i0] + o->efc_pos[i0 + 1] * o->efc_pos[i0 + 1] + o->efc_pos[i0 + 2] * o->efc_pos[i0 + 2]);
+    }
+    double imp = impedance(solimp, ipos, o->efc_margin[i], o->assume & ORC_ASSUME_IMP_SMOOTHSTEP);
     double R = (1 - imp) / imp * o->efc_diagApprox[i];
     o->efc_R[i] = R > MINVAL ? R : MINVAL;
     o->efc_aref[i] = -bb * o->efc_vel[i] - kk * imp * (o->efc_pos[i] - o->efc_margin[i]);
@@ -591,7 +600,7 @@ void orc_forward(Oracle* o) {
   int n = o->nefc;
   if (n == 0) {
     memcpy(o->qacc, o->qacc_smooth, sizeof o->qacc);
-    memcpy(o->qacc_ws, o->qacc, sizeof o->qacc);
+    if (!(o->assume & ORC_ASSUME_WS_STEP_ONLY)) memcpy(o->qacc_ws, o->qacc, sizeof o->qacc);
     o->solver_niter = 0;
     return;
   }
@@ -638,7 +647,7 @@ void orc_forward(Oracle* o) {
     for (int i = 0; i < n; i++) s += MinvJT[i * NV + j] * o->efc_force[i];
     o->qacc[j] = s;
   }
-  memcpy(o->qacc_ws, o->qacc, sizeof o->qacc);
+  if (!(o->assume & ORC_ASSUME_WS_STEP_ONLY)) memcpy(o->qacc_ws, o->qacc, sizeof o->qacc);
 }
 
 static void euler(Oracle* o) { /* mj_Euler: joint damping integrated implicitly, then semi-implicit positions */
@@ -679,7 +688,11 @@ static void euler(Oracle* o) { /* mj_Euler: joint damping integrated implicitly,
   }
 }
 
-static void mj_step(Oracle* o) { orc_forward(o); euler(o); }
+static void mj_step(Oracle* o) {
+  orc_forward(o);
+  memcpy(o->qacc_ws, o->qacc, sizeof o->qacc); /* a step always leaves its qacc as the next warm start */
+  euler(o);
+}
 
 /* ------------------------------------------------------------------ Part 3: DynamicModel / DynamicState / Cassie2d */
 static void set_state(Oracle* o) { /* DynamicModel::setState (DynamicModel.cpp:237-242) */
@@ -857,6 +870,13 @@ void orc_set_state_raw(Oracle* o, const double* qpos, const double* qvel, const 
 void orc_set_gravity(Oracle* o, double gz) { o->gravity_z = gz; }
 void orc_set_damping_scale(Oracle* o, double s) { for (int j = 0; j < NV; j++) o->damping[j] = s * cm_dof_damping[j]; }
 void orc_set_contact_enabled(Oracle* o, int e) { o->contact_enabled = e; }
+void orc_set_assumptions(Oracle* o, int mask) { o->assume = mask; }
+void orc_get_efc_extra(const Oracle* o, double* R, double* vel, double* diagApprox, double* b) {
+  if (R) memcpy(R, o->efc_R, sizeof(double) * o->nefc);
+  if (vel) memcpy(vel, o->efc_vel, sizeof(double) * o->nefc);
+  if (diagApprox) memcpy(diagApprox, o->efc_diagApprox, sizeof(double) * o->nefc);
+  if (b) memcpy(b, o->efc_b, sizeof(double) * o->nefc);
+}
 int orc_nefc(const Oracle* o) { return o->nefc; }
 int orc_ncon(const Oracle* o) { return o->ncon; }
 int orc_solver_niter(const Oracle* o) { return o->solver_niter; }

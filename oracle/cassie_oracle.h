@@ -62,6 +62,14 @@ void orc_set_state_raw(Oracle* o, const double* qpos, const double* qvel, const 
 void orc_set_gravity(Oracle* o, double gz);
 void orc_set_damping_scale(Oracle* o, double s);
 void orc_set_contact_enabled(Oracle* o, int enabled);
+/* Where closed MuJoCo Pro 1.50 (the reference's physics, src/Makefile:5,20) might differ from the published 2.x pipeline
+ * this oracle restates.  0 = the 2.x semantics (default, what the HIP kernels implement); each bit
+ * switches ONE candidate 1.50 behaviour on so that its effect on a trajectory can be measured (tests/test_oracle_mj_kats.py). */
+#define ORC_ASSUME_IMP_SMOOTHSTEP 1   /* impedance sigmoid y = x^2 (3 - 2x) instead of the piecewise quadratic (midpoint .5, power 2) */
+#define ORC_ASSUME_CONNECT_NORM_IMP 2 /* connect rows: one impedance from the norm of the 3-vector violation, not per row */
+#define ORC_ASSUME_WS_STEP_ONLY 4     /* qacc_warmstart written by mj_step only, not by a bare mj_forward (Reset) */
+void orc_set_assumptions(Oracle* o, int mask);
+void orc_get_efc_extra(const Oracle* o, double* R, double* vel, double* diagApprox, double* b);
 int orc_nefc(const Oracle* o);
 int orc_ncon(const Oracle* o);
 int orc_solver_niter(const Oracle* o);

@@ -118,6 +118,16 @@ class Oracle:
     def set_contact_enabled(self, e):
         self.L.orc_set_contact_enabled(self.h, ct.c_int(int(e)))
 
+    def set_assumptions(self, mask):
+        """ORC_ASSUME_* bits (cassie_oracle.h): 1 smoothstep impedance, 2 norm impedance on connect rows, 4 warm start by mj_step only."""
+        self.L.orc_set_assumptions(self.h, ct.c_int(mask))
+
+    def efc_extra(self):
+        n = self.nefc
+        R, vel, diag, b = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+        self.L.orc_get_efc_extra(self.h, _p(R), _p(vel), _p(diag), _p(b))
+        return dict(R=R, vel=vel, diagApprox=diag, b=b)
+
     @property
     def nefc(self):
         return self.L.orc_nefc(self.h)

@@ -20,6 +20,12 @@ def _run(args, env_extra=None, timeout=900):
     return p.returncode, p.stdout, p.stderr
 
 
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), "the JSON line must be the last line of stdout: %r" % lines[-3:]
+    return json.loads(lines[-1])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -31,7 +37,7 @@ def _free_port():
 def test_bench_line_contract_small():
     rc, out, err = _run(["--steps", "6", "--warmup", "2", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--no-extra"])
     assert rc == 0, err[-2000:]
-    line = json.loads(out.strip().splitlines()[-1])
+    line = _line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -48,7 +54,7 @@ def test_rccl_gather_with_a_forced_single_rank_process_group():
                WORLD_SIZE="1")
     rc, out, err = _run(["--steps", "4", "--warmup", "1", "--envs-per-gpu", "1024", "--no-cpu-baseline", "--no-extra"], env)
     assert rc == 0, err[-2000:]
-    line = json.loads(out.strip().splitlines()[-1])
+    line = _line(out)
     assert line["n_gpus"] == 1 and line["config"]["gather_ms"] >= 0.0 and line["finite"]
 
 
@@ -59,7 +65,7 @@ def test_gpus_n_spawns_n_ranks_or_fails_loudly():
     rc, out, err = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "1024", "--no-cpu-baseline"])
     if torch.cuda.device_count() >= 2:
         assert rc == 0, err[-2000:]
-        line = json.loads(out.strip().splitlines()[-1])
+        line = _line(out)
         assert line["n_gpus"] == 2 and line["config"]["envs_total"] == 2048
     else:
         assert rc != 0 and "only 1 device" in err
