@@ -272,52 +272,58 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   const bool isS = (kind == RK_EQ) | (kind == RK_LIM), isLim = kind == RK_LIM, isN = kind == RK_CN;
   const double hAdiag = 0.5 * Adiag, hApart = 0.5 * Apart;
   bool sS = false, sN = false;  // this sweep: my environment still iterates and my row is a single row / a contact normal
+  // The two step functions are inlined at two call sites each (the straight-line sweep and the general sweep below).  Which of
+  // the two a wavefront runs depends on ALL four of its environments, so their roundings must be identical or an environment's
+  // result would depend on its neighbours (measured in r02: 1e-13 after two substeps).  Contraction is therefore off inside
+  // them and every fused multiply-add is written out.
   // one single-row step (connect or joint limit) at row K of every environment
   auto single_step = [&](auto kk) {
+#pragma clang fp contract(off)
     constexpr int K = decltype(kk)::value;
-    double cand = f - res * Ainv;
+    double cand = __builtin_fma(-res, Ainv, f);
     cand = isLim ? fmax(cand, 0.0) : cand;
     double d = cand - f;
-    double chg = d * (hAdiag * d + res);
+    double chg = d * __builtin_fma(hAdiag, d, res);
     const bool keep = (chg <= 1e-10) & sS;
     d = keep ? d : 0.0;
     acc += (keep & (l == K)) ? chg : 0.0;
     double Dd = row_bcast<K>(d);
     f += (l == K) ? d : 0.0;
-    res += Ac[K] * Dd;
+    res = __builtin_fma(Ac[K], Dd, res);
   };
   // one elliptic contact pair at rows (K, K+1), K even; branch-free so that steps can be scheduled across each other
   auto pair_step = [&](auto kk) {
+#pragma clang fp contract(off)
     constexpr int K = decltype(kk)::value;
     double rt = swap1(res), ot = swap1(f);
     double rn = res, on = f;
     double Ann = Adiag, Att = Apart;
     // normal-only update (taken when the normal force is ~0)
-    double fn_n = fmax(on - rn * Ainv, 0.0);
+    double fn_n = fmax(__builtin_fma(-rn, Ainv, on), 0.0);
     // ray update
-    double denom = on * (Ann * on + Ant * ot) + ot * (Ant * on + Att * ot);
-    double x = -(on * rn + ot * rt) * fast_rcp(denom);
+    double denom = __builtin_fma(ot, __builtin_fma(Att, ot, Ant * on), on * __builtin_fma(Ant, ot, Ann * on));
+    double x = -__builtin_fma(ot, rt, on * rn) * fast_rcp(denom);
     x = fmax(x, -1.0);
     x = denom >= MINVAL ? x : 0.0;
     const bool use_n = on < MINVAL;
-    double fn = use_n ? fn_n : on + x * on;
-    double ft = use_n ? 0.0 : ot + x * ot;
+    double fn = use_n ? fn_n : __builtin_fma(x, on, on);
+    double ft = use_n ? 0.0 : __builtin_fma(x, ot, ot);
     // friction on one dimension: unconstrained minimiser unless it leaves the cone
-    double bc = rt - Att * ot + Ant * (fn - on);
+    double bc = __builtin_fma(Ant, fn - on, __builtin_fma(-Att, ot, rt));
     double x0 = -bc * AttInv;
     double v1 = x0 * (1.0 / mu);
-    double val = v1 * v1 - fn * fn;
+    double val = __builtin_fma(v1, v1, -(fn * fn));
     const bool on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
     double ftc = on_cone ? __builtin_copysign(mu * fn, x0) : x0;
     ft = fn >= MINVAL ? ftc : ft;
     double dn = fn - on, dt = ft - ot;
-    double chg = dn * (hAdiag * dn + Ant * dt + rn) + dt * (hApart * dt + rt);
+    double chg = __builtin_fma(dn, __builtin_fma(hAdiag, dn, __builtin_fma(Ant, dt, rn)), dt * __builtin_fma(hApart, dt, rt));
     const bool keep = (chg <= 1e-10) & sN;
     dn = keep ? dn : 0.0; dt = keep ? dt : 0.0;
     acc += (keep & (l == K)) ? chg : 0.0;
     double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
     f += (l == K) ? dn : ((l == K + 1) ? Dt : 0.0);
-    res += Ac[K] * Dn + Ac[K + 1] * Dt;
+    res = __builtin_fma(Ac[K], Dn, __builtin_fma(Ac[K + 1], Dt, res));
   };
   // common configuration (robot on its feet): no active joint limit and at most 4 contacts in every environment of the
   // wave => rows are exactly 4 connect rows + pairs at rows 4,6,8,10: straight-line sweep without per-step branches

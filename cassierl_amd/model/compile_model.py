@@ -337,12 +337,14 @@ def planar_reduce(m3, consts):
         bid = g["body"]
         tran = consts["body_invweight0_tran"][bid]
         if g["type"] == "sphere":
-            li, d = on_link(bid, xpos[bid] + xmat[bid] @ g["pos"])
-            spheres.append(dict(geom=names[bid] + ":sphere", link=li, d=d, r=g["radius"], invweight=tran))
+            pw = xpos[bid] + xmat[bid] @ g["pos"]
+            li, d = on_link(bid, pw)
+            spheres.append(dict(geom=names[bid] + ":sphere", link=li, d=d, r=g["radius"], invweight=tran, y=float(pw[1])))
         else:
             for end, tag in ((g["to"], "to"), (g["from"], "from")):
-                li, d = on_link(bid, xpos[bid] + xmat[bid] @ end)
-                spheres.append(dict(geom=names[bid] + ":capsule:" + tag, link=li, d=d, r=g["radius"], invweight=tran))
+                pw = xpos[bid] + xmat[bid] @ end
+                li, d = on_link(bid, pw)
+                spheres.append(dict(geom=names[bid] + ":capsule:" + tag, link=li, d=d, r=g["radius"], invweight=tran, y=float(pw[1])))
     eqs = []
     for e, a2 in zip(mj["eqs"], consts["eq_anchor2"]):
         l1, d1 = on_link(e["body1"], xpos[e["body1"]] + xmat[e["body1"]] @ e["anchor"])
@@ -482,6 +484,8 @@ def emit_planar_header(mj, m3s, consts, planars, path):
     o.append(ca("cp_sph_link", [s["link"] for s in pl["spheres"]], "%d", "int", 17))
     o.append(ca("cp_sph_d", [s["d"] for s in pl["spheres"]]))
     o.append(ca("cp_sph_r", [s["r"] for s in pl["spheres"]]))
+    o.append("/* world y of each sphere centre (constant: the mechanism moves in the x-z plane); only the height-field lookup reads it */\n")
+    o.append(ca("cp_sph_y", [s["y"] for s in pl["spheres"]]))
     o.append(ca("cp_sph_invweight", [s["invweight"] for s in pl["spheres"]]))
     col = [g for g in mj["geoms"] if g["type"] != "plane"][0]
     o.append(ca("cp_contact_solref", col["solref"]))

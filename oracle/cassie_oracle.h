@@ -69,6 +69,10 @@ void orc_set_contact_enabled(Oracle* o, int enabled);
 #define ORC_ASSUME_CONNECT_NORM_IMP 2 /* connect rows: one impedance from the norm of the 3-vector violation, not per row */
 #define ORC_ASSUME_WS_STEP_ONLY 4     /* qacc_warmstart written by mj_step only, not by a bare mj_forward (Reset) */
 void orc_set_assumptions(Oracle* o, int mask);
+/* terrain (N4): heights in metres, [nrow][ncol] row-major, row r at y = -size_y + r*2*size_y/(nrow-1), column c likewise in x;
+ * the array is NOT copied.  NULL restores the flat floor. */
+void orc_set_hfield(Oracle* o, const double* heights_m, int nrow, int ncol, double size_x, double size_y);
+void orc_get_contacts(const Oracle* o, double* dist, double* pos3, double* frame9);
 void orc_get_efc_extra(const Oracle* o, double* R, double* vel, double* diagApprox, double* b);
 int orc_nefc(const Oracle* o);
 int orc_ncon(const Oracle* o);

@@ -122,6 +122,21 @@ class Oracle:
         """ORC_ASSUME_* bits (cassie_oracle.h): 1 smoothstep impedance, 2 norm impedance on connect rows, 4 warm start by mj_step only."""
         self.L.orc_set_assumptions(self.h, ct.c_int(mask))
 
+    def set_hfield(self, heights_m, size_x, size_y):
+        """Height-field terrain (metres, [nrow, ncol]); None restores the flat floor.  The array is shared, not copied."""
+        if heights_m is None:
+            self._hf = None
+            self.L.orc_set_hfield(self.h, None, 0, 0, ct.c_double(0), ct.c_double(0))
+            return
+        self._hf = np.ascontiguousarray(heights_m, dtype=np.float64)
+        self.L.orc_set_hfield(self.h, _p(self._hf), ct.c_int(self._hf.shape[0]), ct.c_int(self._hf.shape[1]), ct.c_double(size_x), ct.c_double(size_y))
+
+    def contacts(self):
+        n = self.ncon
+        dist, pos, frame = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 9))
+        self.L.orc_get_contacts(self.h, _p(dist), _p(pos), _p(frame))
+        return dict(dist=dist, pos=pos, frame=frame)
+
     def efc_extra(self):
         n = self.nefc
         R, vel, diag, b = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)

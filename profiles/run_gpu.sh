@@ -11,7 +11,7 @@ rm -f "$root/gpurun_out/fullsize.jsonl"
 for w in $what; do
   case $w in
     tests)
-      timeout 3000 python3 -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
+      timeout 3000 python3 -m pytest tests -m gpu -q > "$out/pytest_gpu.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest_gpu.log"
       tail -5 "$out/pytest_gpu.log"
       [ -f "$root/gpurun_out/fullsize.jsonl" ] && cp "$root/gpurun_out/fullsize.jsonl" "$out/fullsize.jsonl" ;;
     bench)
