@@ -19,7 +19,7 @@ EXPORTS = [
     "GetOperationalSpaceState", "Display", "Render",
     # batched ABI (include/cassie_vec.h)
     "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
-    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecSetTrajectory", "CassieVecReset", "CassieVecResetTo",
+    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecSetTrajectory", "CassieVecSetHeightField", "CassieVecReset", "CassieVecResetTo",
     "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
@@ -65,6 +65,7 @@ def load():
     L.CassieVecGetCounters.argtypes = [vp, ct.POINTER(ct.c_uint64)]
     L.CassieVecResetCounters.argtypes = [vp]
     L.CassieVecSetTrajectory.argtypes = [vp, dp, dp, ct.c_int]
+    L.CassieVecSetHeightField.argtypes = [vp, dp, ct.c_int, ct.c_int, ct.c_double, ct.c_double]
     L.CassieVecReset.argtypes = [vp, u8p, dp]
     L.CassieVecResetTo.argtypes = [vp, u8p, dp, dp, dp]
     L.CassieVecStep.argtypes = [vp, dp, dp, dp, u8p, dp]

@@ -35,6 +35,7 @@ struct CassieVec {
   double* traj_qpos = nullptr;
   double traj_tmax = 0.0;
   int traj_n = 0;
+  cassie::Terrain hf{};  // device height field (N4) or {null}
   // scratch for the host-pointer conveniences
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
@@ -87,6 +88,7 @@ cassie::VecParams make_params(CassieVec* h) {
   p.ovf = h->ovf;
   p.ovf_stride = OVF_STRIDE;
   p.stats = h->stats;
+  p.hf = h->hf;
   return p;
 }
 
@@ -112,7 +114,19 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
   const bool pdtq = mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE;
-  if (h->g16 && !p.debug && pdtq) {
+  if (h->hf.h) {
+    // height-field terrain: PD / torque physics only (the controllers' contact model assumes the flat floor, OSC_RBDL.cpp:41-71)
+    if (!pdtq) return fail(h, CASSIE_EINVAL, "a height field is set: only PD and torque control modes step on terrain");
+    if (p.debug) return fail(h, CASSIE_EINVAL, "the debug substep has no height-field variant");
+    if (h->g16) {
+      L2::step_g16_hf(mode, h->n, h->stream, p, h->pending);
+      cassie::VecParams pc = p;
+      pc.pending = h->pending;
+      L2::step_k1_hf(mode, h->n, h->stream, pc);
+    } else {
+      L2::step_k1_hf(mode, h->n, h->stream, p);
+    }
+  } else if (h->g16 && !p.debug && pdtq) {
     // fast path: 4 environments per wavefront; environments with more than 16 active constraint rows are finished
     // by the wave-per-environment kernel, which returns immediately for every other environment
     L2::step_g16(mode, h->n, h->stream, p, h->pending);
@@ -142,7 +156,8 @@ int launch_reset(CassieVec* h, const uint8_t* mask, const double* q, const doubl
     L2::get_state(h->n, h->stream, h->state, h->d_q, h->d_v);
     q = h->d_q; v = h->d_v;
   }
-  L2::reset(h->n, h->stream, p, mask, q, v);
+  if (h->hf.h) L2::reset_hf(h->n, h->stream, p, mask, q, v);
+  else L2::reset(h->n, h->stream, p, mask, q, v);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -194,7 +209,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
 void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  hipFree(h->state); hipFree(h->traj_qpos); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
+  hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
   hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->stats);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -243,6 +258,21 @@ int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* 
   HIPCHK(h, hipMemcpy(h->traj_qpos, qpos_host, (size_t)n * 13 * sizeof(double), hipMemcpyHostToDevice));
   h->traj_tmax = time_host[n - 1];  // cassie2d_trajectory.py:17
   h->traj_n = n;
+  return CASSIE_OK;
+}
+
+int CassieVecSetHeightField(CassieVec* h, const double* heights_host, int nrow, int ncol, double size_x, double size_y) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->hf.h) { hipFree((void*)h->hf.h); h->hf = cassie::Terrain{}; }
+  if (!heights_host) return CASSIE_OK;  // back to the flat floor
+  if (nrow < 2 || ncol < 2 || !(size_x > 0) || !(size_y > 0)) return fail(h, CASSIE_EINVAL, "bad height field");
+  double* d = nullptr;
+  const size_t bytes = (size_t)nrow * ncol * sizeof(double);
+  HIPCHK(h, hipMalloc(&d, bytes));
+  HIPCHK(h, hipMemcpy(d, heights_host, bytes, hipMemcpyHostToDevice));
+  h->hf.h = d; h->hf.nrow = nrow; h->hf.ncol = ncol; h->hf.sx = size_x; h->hf.sy = size_y;
   return CASSIE_OK;
 }
 

@@ -154,6 +154,32 @@ __device__ __forceinline__ double impedance(double d0, double d1, double width, 
   return d0 + y * (d1 - d0);
 }
 
+// ---------------------------------------------------------------- height-field terrain (N4)
+// Sphere (world centre wx, wy, wz) against the terrain: the cell under the centre is split along its (c,r)-(c+1,r+1) diagonal,
+// the triangle under the centre gives the local plane z = z00 + a X + b Y, and the sphere is tested against that plane's
+// slice at its own y (the mechanism lives in the sagittal plane): normal (-a, 1)/sqrt(1 + a^2) in (x, z), distance measured in
+// that plane.  Outside the field: the floor plane z = 0.  Same arithmetic, in the same order, as oracle/cassie_oracle.c:
+// hfield_sphere (a restatement; MuJoCo's own prism/convex test has no closed form -- see DESIGN.md).
+__device__ __forceinline__ void terrain_sphere(const Terrain& t, double wx, double wy, double wz, double radius, double& dist, double& nx, double& nz) {
+  const int nr = t.nrow, nc = t.ncol;
+  const double dx = 2.0 * t.sx / (nc - 1), dy = 2.0 * t.sy / (nr - 1);
+  const double gx = (wx + t.sx) / dx, gy = (wy + t.sy) / dy;
+  nx = 0.0; nz = 1.0; dist = wz - radius;
+  if (!(gx >= 0.0 && gx <= (double)(nc - 1) && gy >= 0.0 && gy <= (double)(nr - 1))) return;
+  int ci = (int)gx, ri = (int)gy;
+  ci = ci > nc - 2 ? nc - 2 : ci;
+  ri = ri > nr - 2 ? nr - 2 : ri;
+  const double fx = gx - ci, fy = gy - ri;
+  const double* h0 = t.h + (size_t)ri * nc + ci;
+  const double z00 = h0[0], z10 = h0[1], z01 = h0[nc], z11 = h0[nc + 1];
+  double a, b;
+  if (fy <= fx) { a = (z10 - z00) / dx; b = (z11 - z10) / dy; }
+  else { a = (z11 - z01) / dx; b = (z01 - z00) / dy; }
+  const double zs = z00 + a * (fx * dx) + b * (fy * dy);
+  nz = 1.0 / sqrt(1.0 + a * a); nx = -a * nz;
+  dist = (wz - zs) * nz - radius;
+}
+
 // ---------------------------------------------------------------- planar forward kinematics on the link lanes
 // Reads sm.q/sm.v-like arrays (qsrc, vsrc), writes link arrays.  SEM selects the model semantics table.
 template <int SEM, class SM>
@@ -344,8 +370,9 @@ __device__ __forceinline__ double arow_entry(const Smem& sm, const double (&X)[N
 
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler integration)
 // On entry sm.q/v/ws hold the state; ctrl is this dof lane's actuator command (pre-clamp).
-template <bool INTEGRATE, int MAXACT>
-__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg, double* ovf) {
+template <bool INTEGRATE, int MAXACT, bool HF = false>
+__device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, double ctrl, StepOut& out, double* dbg, double* ovf,
+                                        const Terrain* terrain = nullptr) {
   // ---- kinematics
   planar_fk<0>(sm, sm.q, sm.v, c, lane);
   // ---- mass-matrix row on every dof lane (group 1 adds h*damping on the diagonal), then both inverses at once
@@ -407,12 +434,29 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
   } else if (c.kind >= 2) {
     double cx, cz;
     link_point(sm, c.link1, rc.d1x, rc.d1z, cx, cz);
-    double dist = basez + cz - rc.radius;
-    if (dist < 0) {
-      active = true;
-      double pz = 0.5 * dist - basez;
-      jac_compact(sm, c.pm1, legbase, c.comp, cx, pz, 1.0, J);
-      pos = dist;  // both rows of the pair keep the normal distance (shared regulariser); the tangent row's own pos is 0
+    if constexpr (HF) {
+      // terrain: contact frame from the cell under the sphere; normal row along (nx, nz), tangent row along (nz, -nx)
+      const double basex = sm.q[0] - cp_qpos0[0] + cp_link_off[0][0][0];
+      const int sph = opaque(lane >= SLOT_CON && lane < NSLOT ? (lane - SLOT_CON) >> 1 : 0);
+      double dist, nx, nz;
+      terrain_sphere(*terrain, basex + cx, cp_sph_y[sph], basez + cz, rc.radius, dist, nx, nz);
+      if (dist < 0) {
+        active = true;
+        const double back = rc.radius + 0.5 * dist;
+        const double px = cx - nx * back, pz = cz - nz * back;
+        const double dirx = c.kind == 2 ? nx : nz, dirz = c.kind == 2 ? nz : -nx;
+        jac_compact(sm, c.pm1, legbase, 0, px, pz, dirx, J);
+        jac_compact(sm, c.pm1, legbase, 1, px, pz, dirz, J);
+        pos = dist;
+      }
+    } else {
+      double dist = basez + cz - rc.radius;
+      if (dist < 0) {
+        active = true;
+        double pz = 0.5 * dist - basez;
+        jac_compact(sm, c.pm1, legbase, c.comp, cx, pz, 1.0, J);
+        pos = dist;  // both rows of the pair keep the normal distance (shared regulariser); the tangent row's own pos is 0
+      }
     }
   }
   amask = __ballot(active);
@@ -759,7 +803,7 @@ __device__ __forceinline__ void env_outputs_row(const VecParams& p, int l, const
 // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
 // WPS: waves per SIMD the register allocation is sized for.  4 (128 VGPRs, some spills) wins when the grid is only
 // ~4 waves per SIMD deep (4096 envs); 3 (168 VGPRs, fewer spills) wins on deep grids (measured, profiles/r01_b_*).
-template <int MODE, int WPS, int MAXACT>
+template <int MODE, int WPS, int MAXACT, bool HF = false>
 __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   __shared__ Smem sm;
   __shared__ double s18[18];
@@ -796,7 +840,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
       ctrl = act_l;
     }
     lds_sync();
-    substep<true, MAXACT>(sm, c, lane, ctrl, so, dbg, ovf);
+    substep<true, MAXACT, HF>(sm, c, lane, ctrl, so, dbg, ovf, &p.hf);
     niter_sum += so.niter;
     time += 0.0005;
     if (sub == n_sub - 1 && c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;  // mj_data->ctrl
@@ -831,7 +875,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
       if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
       time = 0.0;
       lds_sync();
-      substep<false, MAXACT>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf);
+      substep<false, MAXACT, HF>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf, &p.hf);
       opstate18(sm, c, lane, fix_kin, s18);
       sp = 0.0;
       if (lane < 17) sp = s18[lane + 1];
@@ -844,9 +888,8 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   store_state(st, sm, lane, qstate_l, time, niter_sum);
 }
 
-// The non-template kernels below are compiled by one translation unit only (tu_base.hip).
-#ifdef CASSIE_TU_BASE
 // ---------------------------------------------------------------- masked reset (Cassie2dEnv.reset / Cassie2d::Reset)
+template <bool HF>
 __global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_t* mask, const double* qpos_in, const double* qvel_in) {
   __shared__ Smem sm;
   __shared__ double s18[18];
@@ -866,7 +909,7 @@ __global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_
   lds_sync();
   double qstate_l = (lane >= 1 && lane < 14) ? sm.q[lane - 1] : 0.0;
   StepOut so;
-  substep<false, 32>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, p.ovf + (size_t)env * p.ovf_stride);
+  substep<false, 32, HF>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, p.ovf + (size_t)env * p.ovf_stride, &p.hf);
   if (p.obs) {
     opstate18(sm, c, lane, (p.flags & FLAG_FIX_STALE_KIN) != 0, s18);
     double sp = 0.0;
@@ -877,6 +920,8 @@ __global__ void __launch_bounds__(64) env_reset_kernel(VecParams p, const uint8_
   store_state(st, sm, lane, qstate_l, 0.0, so.niter);
 }
 
+// The non-template kernels below are compiled by one translation unit only (tu_base.hip).
+#ifdef CASSIE_TU_BASE
 // op-space state only (GetOperationalSpaceState for every env)
 __global__ void __launch_bounds__(64) env_opstate_kernel(VecParams p, double* out18) {
   __shared__ Smem sm;

@@ -63,8 +63,9 @@ struct G16Out { int niter; bool overflow; };
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
 // `integrate` (wave-uniform) = false gives mj_forward only (Cassie2d::Reset); it is a run-time flag so that a kernel carries ONE
 // copy of this code (two copies doubled the code size and the register spills around the second one).
-template <class SM>
-__device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, int g, double ctrl, bool live, bool integrate, G16Out& out) {
+template <class SM, bool HF = false>
+__device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, int g, double ctrl, bool live, bool integrate, G16Out& out,
+                                        const Terrain* terrain = nullptr) {
   // Per-lane model constants are re-read from constant memory in every substep (K$/L1 hits).  Without these barriers the
   // compiler hoists ~50 loop-invariant table loads out of the substep loop and then spills them to scratch, which costs
   // HBM write traffic at every kernel boundary (profiles/r01_c_pmc: 32 MB per launch against 3.7 MB algorithmic).
@@ -100,12 +101,19 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     double qd = sm.q[dof];
     lim_act = (qd - cp_jnt_range[dof][0] < 0) || (cp_jnt_range[dof][1] - qd < 0);
   }
+  const double basex = HF ? sm.q[0] - cp_qpos0[0] + cp_link_off[0][0][0] : 0.0;
   auto sphere_active = [&](int sph) {
     const int so = opaque(sph);
     const int lk = cp_sph_link[so];
     double cx, cz;
     link_point(sm, lk, cp_sph_d[so][0], cp_sph_d[so][1], cx, cz);
-    return basez + cz - cp_sph_r[so] < 0;
+    if constexpr (HF) {
+      double dist, nx, nz;
+      terrain_sphere(*terrain, basex + cx, cp_sph_y[so], basez + cz, cp_sph_r[so], dist, nx, nz);
+      return dist < 0;
+    } else {
+      return basez + cz - cp_sph_r[so] < 0;
+    }
   };
   const bool con_act0 = sphere_active(l);
   const bool con_act1 = (l == 0) ? sphere_active(16) : false;
@@ -166,10 +174,23 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     } else if (kind == RK_CN || kind == RK_CT) {
       double cx, cz;
       link_point(sm, link1, d1x, d1z, cx, cz);
-      double dist = basez + cz - radius;
-      double pz = 0.5 * dist - basez;
-      jac_compact(sm, pm1, legbase, comp, cx, pz, 1.0, J);
-      pos = dist;
+      if constexpr (HF) {
+        // terrain: contact frame from the cell under the sphere; normal row along (nx, nz), tangent row along (nz, -nx)
+        const int sph = opaque(so >= SLOT_CON ? (so - SLOT_CON) >> 1 : 0);
+        double dist, nx, nz;
+        terrain_sphere(*terrain, basex + cx, cp_sph_y[sph], basez + cz, radius, dist, nx, nz);
+        const double back = radius + 0.5 * dist;
+        const double px = cx - nx * back, pz = cz - nz * back;
+        const double dirx = kind == RK_CN ? nx : nz, dirz = kind == RK_CN ? nz : -nx;
+        jac_compact(sm, pm1, legbase, 0, px, pz, dirx, J);
+        jac_compact(sm, pm1, legbase, 1, px, pz, dirz, J);
+        pos = dist;
+      } else {
+        double dist = basez + cz - radius;
+        double pz = 0.5 * dist - basez;
+        jac_compact(sm, pm1, legbase, comp, cx, pz, 1.0, J);
+        pos = dist;
+      }
     }
     double vel = J[0] * sm.v[0] + J[1] * sm.v[1] + J[2] * sm.v[2];
     double bq = J[0] * sm.qs[0] + J[1] * sm.qs[1] + J[2] * sm.qs[2];
@@ -406,7 +427,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
 
 // ---------------------------------------------------------------- fused Env.step, 4 envs per wave
 // MODE: 0 PD, 1 torque.  pending[env] = substeps this kernel did NOT do (0 in the normal case).
-template <int MODE>
+template <int MODE, bool HF = false>
 __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* pending) {
   __shared__ EnvLds sm4[4];
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
@@ -444,7 +465,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     double cnew;
     if (reset_pass) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
     else { const double act_l = sm.actl[l]; cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l; }
-    substep(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so);  // reset pose: 12 active rows, cannot overflow
+    substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf);  // reset pose on the flat floor: 12 active rows
     if (!reset_pass) {
       if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
       if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; }  // setState of this substep

@@ -18,6 +18,10 @@ constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
 // tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque)
 void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p);
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
+// tu_hf.hip: the same kernels with the height-field collision stage (p.hf.h != null); PD / torque modes
+void step_k1_hf(int mode, int n_envs, hipStream_t s, const VecParams& p);
+void step_g16_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
+void reset_hf(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
 void opstate(int n_envs, hipStream_t s, const VecParams& p, double* out18);
 void init_state(int n_envs, hipStream_t s, double* state);
 void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel);

@@ -33,6 +33,14 @@ enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2, FLAG_NO_PINV_SHORTCUT 
 enum { STAT_CLEANUP_SUBSTEPS = 0, STAT_K1_SUBSTEPS = 1, STAT_NONFINITE = 2, STAT_N = 4 };
 constexpr double FINITE_BOUND = 1e10;  // mjMAXVAL of MuJoCo's mj_checkPos / mj_checkVel
 
+// Height-field terrain (rllab/envs/terrain_random.py): heights in metres, [nrow][ncol] row-major in HBM
+// (row r at y = -sy + r * 2 sy / (nrow - 1), column c likewise in x).  h == null: flat floor.
+struct Terrain {
+  const double* h;
+  int nrow, ncol;
+  double sx, sy;
+};
+
 struct VecParams {
   double* state;          // [n_envs][ENV_STRIDE]
   const double* actions;  // [n_envs][adim] device
@@ -47,6 +55,7 @@ struct VecParams {
   double* ovf;            // [n_envs][ovf_stride]: A columns beyond the register-resident ones (rare slow path)
   int ovf_stride;
   const int* pending;     // [n_envs] substeps left per env (clean-up pass after the 4-envs-per-wave kernel) or null
+  Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };

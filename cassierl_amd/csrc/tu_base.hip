@@ -20,7 +20,7 @@ void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecPa
   }
 }
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel) {
-  hipLaunchKernelGGL(env_reset_kernel, dim3(n_envs), dim3(64), 0, s, p, mask, qpos, qvel);
+  hipLaunchKernelGGL(env_reset_kernel<false>, dim3(n_envs), dim3(64), 0, s, p, mask, qpos, qvel);
 }
 void opstate(int n_envs, hipStream_t s, const VecParams& p, double* out18) {
   hipLaunchKernelGGL(env_opstate_kernel, dim3(n_envs), dim3(64), 0, s, p, out18);

@@ -83,6 +83,17 @@ class CassieVecEnv:
         assert q.shape == (len(t), 13)
         self._chk(self.L.CassieVecSetTrajectory(self.h, t.ctypes.data, q.ctypes.data, len(t)))
 
+    def set_heightfield(self, heights_m, size_x=10.0, size_y=10.0):
+        """Terrain under every robot (counterpart of the <hfield>/<geom type=hfield> pair terrain_random.py writes into the
+        MJCF): heights in metres, [nrow, ncol], spanning [-size_x, size_x] x [-size_y, size_y]; None = flat floor.
+        See cassierl_amd.terrain for the PNG loader and the random terrain choice."""
+        if heights_m is None:
+            self._chk(self.L.CassieVecSetHeightField(self.h, None, 0, 0, 0.0, 0.0))
+            return
+        hm = np.ascontiguousarray(heights_m, dtype=np.float64)
+        assert hm.ndim == 2
+        self._chk(self.L.CassieVecSetHeightField(self.h, hm.ctypes.data, hm.shape[0], hm.shape[1], float(size_x), float(size_y)))
+
     def synchronize(self):
         self._chk(self.L.CassieVecSynchronize(self.h))
 

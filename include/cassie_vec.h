@@ -80,6 +80,13 @@ int CassieVecResetCounters(CassieVec* h);
 /* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */
 int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* qpos_host, int n);
 
+/* Height-field terrain under every robot of the batch (what rllab/envs/terrain_random.py:38-76 adds to the MJCF as
+ * <hfield size="sx sy sz base" file=...> + <geom type="hfield">): heights_host[nrow][ncol] in METRES above the floor (row r at
+ * y = -size_y + r * 2 size_y / (nrow - 1), column c likewise in x; host pointer, copied once).  NULL restores the flat floor.
+ * With a field set only PD / torque modes step (CassieVecStep / CassieVecSubstep return CASSIE_EINVAL otherwise).
+ * Collision model: sphere vs the triangle of the grid cell under its centre, in the robot's sagittal plane. */
+int CassieVecSetHeightField(CassieVec* h, const double* heights_host, int nrow, int ncol, double size_x, double size_y);
+
 /* masked reset to the Cassie2dEnv.reset pose; mask_dev == NULL resets every env; obs_dev may be NULL */
 int CassieVecReset(CassieVec* h, const uint8_t* mask_dev, double* obs_dev);
 /* Cassie2d::Reset with caller-provided states ([n][13] each, device) */

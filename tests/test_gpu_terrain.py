@@ -1,0 +1,170 @@
+"""N4: height-field terrain on the HIP path (CassieVecSetHeightField) against the oracle's hfield_sphere on the same seeded inputs:
+a synthetic ramp and one of the reference's terrain images (tests/golden/terrain_png.npz).  -m gpu only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, state_vec
+from cassierl_amd import terrain as T
+
+pytestmark = pytest.mark.gpu
+
+TQ = np.array([12.0, 12.0, 0.9] * 2)
+PD_LO, PD_HI = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+
+
+@pytest.fixture(scope="module")
+def vec():
+    from cassierl_amd.vec_env import CassieVecEnv
+    return CassieVecEnv
+
+
+@pytest.fixture(scope="module")
+def png_field():
+    gray = np.load(os.path.join(GOLDEN, "terrain_png.npz"))["gray"].astype(np.float64)
+    hm = T.hfield_from_gray(gray, (10, 10, 0.2, 0.001))
+    return hm - max(T.height_at(hm, 10, 10, x, y) for x in np.linspace(-0.2, 0.3, 26) for y in (-0.1305, 0.1305)) - 1e-4
+
+
+def rel_err(sg, q1, v1):
+    return max(np.abs(sg[:13] - q1).max() / np.abs(q1).max(), np.abs(sg[13:26] - v1).max() / (1e-3 + np.abs(v1).max()))
+
+
+def _oracles(oracle_mod, hm, shifts):
+    os_ = []
+    for dx, dz in shifts:
+        o = oracle_mod.Oracle()
+        o.set_hfield(hm, 10.0, 10.0)
+        q, v = o.state()
+        q[0] += dx; q[1] += dz
+        o.set_state_raw(q, v, np.zeros(13))
+        os_.append(o)
+    return os_
+
+
+@pytest.mark.parametrize("wave_per_env", [False, True])
+@pytest.mark.parametrize("mode", ["Torque", "PD"])
+def test_ramp_teacher_forced_substeps(vec, oracle_mod, mode, wave_per_env):
+    """300 substeps, teacher-forced each step, robots on the flat part, across the kink and on the slope (0.1) of the ramp."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    hm = T.ramp(nrow=64, ncol=2001, size_x=10.0, slope=0.1, x0=0.5)
+    shifts = [(-1.0, 0.0), (0.4, 0.0), (0.45, 0.002), (1.0, 0.05), (2.0, 0.15), (3.3, 0.28)]
+    os_ = _oracles(oracle_mod, hm, shifts)
+    n = len(os_)
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=WAVE_PER_ENV if wave_per_env else 0)
+    env.set_heightfield(hm, 10.0, 10.0)
+    rng = np.random.default_rng(12)
+    worst, sloped = 0.0, 0
+    for t in range(300):
+        if t % 10 == 0:
+            a = rng.uniform(-1, 1, (n, 6)) * TQ if mode == "Torque" else rng.uniform(PD_LO, PD_HI, (n, 6))
+        env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in os_]))
+        env.substep_host(mode, a, 1)
+        sg = env.get_full_state_host()
+        for i, o in enumerate(os_):
+            (o.step_torque if mode == "Torque" else o.step_pd)(a[i])
+            q1, v1 = o.state()
+            worst = max(worst, np.abs(sg[i, :13] - q1).max(), np.abs(sg[i, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+            if o.ncon and np.abs(o.contacts()["frame"][:, 0]).max() > 0.05:
+                sloped += 1
+    assert worst < 1e-9, worst
+    assert sloped > 300  # contacts with a tilted frame were really exercised
+    env.close()
+
+
+def test_png_terrain_free_running_1000_substeps(vec, oracle_mod, png_field):
+    """North-star bar on terrain: 1000 free-running torque-mode substeps on one of the reference's terrain images, 8 robots
+    dropped at different x; (qpos, qvel) within 1e-5 relative of the oracle throughout (robots land, tumble, lie on the relief)."""
+    hm = png_field
+    shifts = [(x, T.height_at(hm, 10, 10, x, 0.0) - T.height_at(hm, 10, 10, 0.0, 0.0) + 0.03) for x in (0.0, -2.5, 1.7, 3.1, -4.2, 5.5, 0.8, -0.9)]
+    os_ = _oracles(oracle_mod, hm, shifts)
+    n = len(os_)
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
+    env.set_heightfield(hm, 10.0, 10.0)
+    env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in os_]))
+    rng = np.random.default_rng(5)
+    worst, maxcon, tilted = 0.0, 0, 0.0
+    for t in range(100):
+        acts = rng.uniform(-1, 1, (n, 6)) * TQ
+        env.substep_host("Torque", acts, 10)
+        sg = env.get_full_state_host()
+        for i, o in enumerate(os_):
+            for _ in range(10):
+                o.step_torque(acts[i])
+            worst = max(worst, rel_err(sg[i], *o.state()))
+            maxcon = max(maxcon, o.ncon)
+            if o.ncon:
+                tilted = max(tilted, float(np.abs(o.contacts()["frame"][:, 0]).max()))
+    assert worst < 1e-5, worst
+    assert maxcon >= 5 and tilted > 0.02
+    c = env.counters()
+    assert c["nonfinite_resets"] == 0
+    env.close()
+
+
+def test_env_step_on_terrain_packed_vs_wave_per_env(vec, traj, png_field):
+    """Cassie2dEnv.step (stand env, PD and torque) on the terrain: 257 robots spread over 12 m of relief, the packed kernel with
+    its hand-over pass against the wave-per-environment kernel, teacher-forced per Env.step; resets land on the terrain too."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    hm = png_field
+    n = 257
+    for mode in ("Torque", "PD"):
+        a = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True)
+        b = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
+        for e in (a, b):
+            e.set_heightfield(hm, 10.0, 10.0)
+            e.reset_host()
+        s = a.get_full_state_host()
+        xs = np.linspace(-6, 6, n)
+        s[:, 0] += xs
+        s[:, 39] += xs
+        s[:, 1] += np.array([T.height_at(hm, 10, 10, x, 0.0) for x in xs]) - T.height_at(hm, 10, 10, 0.0, 0.0) + 0.02
+        a.set_full_state_host(s)
+        rng = np.random.default_rng(2)
+        lo, hi = (-TQ, TQ) if mode == "Torque" else (PD_LO, PD_HI)
+        worst, ndone = 0.0, 0
+        for t in range(40):
+            acts = rng.uniform(lo, hi, (n, 6))
+            b.set_full_state_host(a.get_full_state_host())
+            oa, ra, da = a.step_host(acts)
+            ob, rb, db = b.step_host(acts)
+            sa, sb = a.get_full_state_host(), b.get_full_state_host()
+            assert np.isfinite(sa).all()
+            err = np.abs(sa[:, :26] - sb[:, :26]).max(axis=1) / (1.0 + np.abs(sb[:, :26]).max(axis=1))
+            worst = max(worst, float(err.max()), float(np.abs(ra - rb).max()))
+            assert (da != db).sum() == 0
+            ndone += int(da.sum())
+        assert worst < (1e-10 if mode == "Torque" else 1e-7), (mode, worst)
+        assert ndone > 20
+        a.close(); b.close()
+
+
+def test_zero_field_equals_flat_floor_and_field_can_be_removed(vec):
+    n = 8
+    a = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    b = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    b.set_heightfield(np.zeros((8, 16)), 10.0, 10.0)
+    rng = np.random.default_rng(4)
+    a.reset_host(); b.reset_host()
+    for t in range(30):
+        acts = rng.uniform(-1, 1, (n, 6)) * TQ
+        oa, ra, da = a.step_host(acts)
+        ob, rb, db = b.step_host(acts)
+        assert np.abs(oa - ob).max() < 1e-8 and np.abs(ra - rb).max() < 1e-9 and (da == db).all()
+    b.set_heightfield(None)
+    b.set_full_state_host(a.get_full_state_host())
+    oa, ra, da = a.step_host(acts)
+    ob, rb, db = b.step_host(acts)
+    assert np.array_equal(oa, ob) and np.array_equal(ra, rb)
+    a.close(); b.close()
+
+
+def test_controllers_refuse_terrain(vec):
+    env = vec(4, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    env.set_heightfield(np.zeros((4, 4)), 10.0, 10.0)
+    with pytest.raises(RuntimeError, match="height field"):
+        env.step_host(np.zeros((4, 7)))
+    env.set_heightfield(None)
+    env.step_host(np.zeros((4, 7)))
+    env.close()
