@@ -158,8 +158,8 @@ __device__ __forceinline__ double impedance(double d0, double d1, double width, 
 // Sphere (world centre wx, wy, wz) against the terrain: the cell under the centre is split along its (c,r)-(c+1,r+1) diagonal,
 // the triangle under the centre gives the local plane z = z00 + a X + b Y, and the sphere is tested against that plane's
 // slice at its own y (the mechanism lives in the sagittal plane): normal (-a, 1)/sqrt(1 + a^2) in (x, z), distance measured in
-// that plane.  Outside the field: the floor plane z = 0.  Same arithmetic, in the same order, as oracle/cassie_oracle.c:
-// hfield_sphere (a restatement; MuJoCo's own prism/convex test has no closed form -- see DESIGN.md).
+// that plane.  Outside the field: the floor plane z = 0.  Same arithmetic, in the same order, as the CPU restatement the
+// parity tests check against (a restatement; MuJoCo's own prism/convex test has no closed form -- see DESIGN.md).
 __device__ __forceinline__ void terrain_sphere(const Terrain& t, double wx, double wy, double wz, double radius, double& dist, double& nx, double& nz) {
   const int nr = t.nrow, nc = t.ncol;
   const double dx = 2.0 * t.sx / (nc - 1), dy = 2.0 * t.sy / (nr - 1);
