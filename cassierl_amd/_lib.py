@@ -25,7 +25,7 @@ EXPORTS = [
     "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
     # batched Cassie3d physics (include/cassie3d_vec.h)
     "Cassie3dVecCreate", "Cassie3dVecFree", "Cassie3dVecLastError", "Cassie3dVecSetStream", "Cassie3dVecSynchronize",
-    "Cassie3dVecReset", "Cassie3dVecStep", "Cassie3dVecStatePtr", "Cassie3dVecStepHost", "Cassie3dVecGetStateHost",
+    "Cassie3dVecReset", "Cassie3dVecStep", "Cassie3dVecStatePtr", "Cassie3dVecGetCounters", "Cassie3dVecResetCounters", "Cassie3dVecStepHost", "Cassie3dVecGetStateHost",
     "Cassie3dVecSetStateHost", "Cassie3dVecDebugForwardHost", "Cassie3dVecTimeSteps",
 ]
 
@@ -92,6 +92,8 @@ def load():
     L.Cassie3dVecStep.argtypes = [vp, dp, ct.c_int]
     L.Cassie3dVecStatePtr.argtypes = [vp]
     L.Cassie3dVecStatePtr.restype = ct.c_void_p
+    L.Cassie3dVecGetCounters.argtypes = [vp, ct.POINTER(ct.c_uint64)]
+    L.Cassie3dVecResetCounters.argtypes = [vp]
     L.Cassie3dVecStepHost.argtypes = [vp, dp, ct.c_int]
     L.Cassie3dVecGetStateHost.argtypes = [vp, dp]
     L.Cassie3dVecSetStateHost.argtypes = [vp, dp]

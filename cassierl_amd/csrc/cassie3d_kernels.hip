@@ -14,8 +14,11 @@
 //   row  lanes 0..63   ACTIVE constraint rows compacted in MuJoCo order (6 connect rows, active limits, 3 rows per active
 //                      contact); lane i owns force / residual i and fills column i of A = J M^-1 J' + R in LDS
 // PGS walks the rows with a wave-uniform loop: the owner's (f, residual) come by v_readlane, the update is computed
-// redundantly on every lane, and each lane applies A[i][K] * delta to its own residual.  More than 64 active rows (possible
-// only with >= 13 simultaneous contacts plus joint limits) is not handled: the environment is frozen and flagged (E3_OVF).
+// redundantly on every lane, and each lane applies A[i][K] * delta to its own residual.  The model can produce at most
+// 6 + 12 + 3 * 17 = 69 rows; beyond the 64 this kernel holds (>= 15 of the 17 collision spheres down at once, plus limits) the
+// LAST contacts in MuJoCo order are left out for that substep (row cap).  That is a stated deviation for a robot lying flat
+// with 14+ other contacts holding it -- never a frozen environment: E3_OVF counts such substeps per environment and the
+// handle's counters report them (Cassie3dVecGetCounters); the oracle has the same cap as a switch, so parity covers it.
 #ifndef CASSIE3D_KERNELS_HIP_
 #define CASSIE3D_KERNELS_HIP_
 
@@ -108,10 +111,10 @@ __device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
   });
 }
 
-struct Out3 { int niter, nefc; bool overflow; };
+struct Out3 { int niter, nefc; bool overflow, capped; };
 
 // ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
-template <int MR>
+template <int MR, bool CAP>
 __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, bool integrate, Out3& out, double* dbg) {
   // ================= kinematics: links 0..14 on lanes 0..14, one tree level at a time
   const int lk = lane < NL ? lane : 0;
@@ -326,8 +329,15 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     if (dlo < 0) { lim_act = true; lim_dist = dlo; lim_sgn = 1.0; }
     else if (dhi < 0) { lim_act = true; lim_dist = dhi; lim_sgn = -1.0; }
   }
-  const unsigned con_mask = (unsigned)__ballot(con_act), lim_mask = (unsigned)__ballot(lim_act);
-  const int ncon = __popc(con_mask), nlim = __popc(lim_mask);
+  unsigned con_mask = (unsigned)__ballot(con_act);
+  const unsigned lim_mask = (unsigned)__ballot(lim_act);
+  int ncon = __popc(con_mask);
+  const int nlim = __popc(lim_mask);
+  out.capped = false;
+  if (CAP) {  // last-resort kernel: keep the first contacts (MuJoCo order) that fit, say so
+    const int room = (MR - 3 * NEQ - nlim) / 3;
+    while (ncon > room) { con_mask &= ~(1u << (31 - __clz(con_mask))); ncon--; out.capped = true; }
+  }
   const int nrows = 3 * NEQ + nlim + 3 * ncon;
   out.nefc = nrows;
   out.overflow = nrows > MR;
@@ -609,15 +619,13 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
 template <int MR, int WPS>
 __global__ void __launch_bounds__(64, WPS) env_step3d_kernel(Params3 p) {
   __shared__ Smem3<MR> sm;
+  constexpr bool CAP = MR == MAXR;  // the general kernel is the last resort: it caps instead of handing over
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= p.n_envs) return;
   const int n_sub = p.pending_in ? p.pending_in[env] : p.n_sub;
   if (n_sub == 0) return;
+  if (p.pending_in && p.stats && lane == 0) atomicAdd(p.stats + S3_GENERAL_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV3_STRIDE;
-  if (st[E3_OVF] != 0.0) {  // frozen earlier (more than MAXR constraint rows)
-    if (lane == 0 && p.pending_out) p.pending_out[env] = 0;
-    return;
-  }
   if (lane < NQ) sm.q[lane] = st[E3_Q + lane];
   if (lane < NV) { sm.v[lane] = st[E3_V + lane]; sm.ws[lane] = st[E3_WS + lane]; }
   double time = st[E3_TIME];
@@ -625,19 +633,16 @@ __global__ void __launch_bounds__(64, WPS) env_step3d_kernel(Params3 p) {
   double ctrl_l = 0.0;
   if (a >= 0) ctrl_l = p.actions ? p.actions[(size_t)env * NU + a] : st[E3_CTRL + a];
   lds_sync();
-  Out3 out; out.niter = 0; out.nefc = 0; out.overflow = false;
+  Out3 out; out.niter = 0; out.nefc = 0; out.overflow = false; out.capped = false;
   int niter_sum = p.pending_in ? (int)st[E3_NITER] : 0;
   double* dbg = p.debug ? p.debug + (size_t)env * D3_STRIDE : nullptr;
-  int left = 0;
+  int left = 0, ncapped = 0;
   for (int sub = 0; sub < n_sub; sub++) {
-    substep3<MR>(sm, lane, ctrl_l, p.integrate != 0, out, dbg);
-    if (out.overflow) { left = n_sub - sub; break; }  // detected before anything of this substep was written
+    substep3<MR, CAP>(sm, lane, ctrl_l, p.integrate != 0, out, dbg);
+    if (out.overflow) { left = n_sub - sub; break; }  // (never with CAP) detected before anything of this substep was written
     niter_sum += out.niter;
+    ncapped += out.capped ? 1 : 0;
     if (p.integrate) time += H;
-  }
-  if (left != 0 && !p.pending_out) {  // nobody to hand over to: freeze the environment as it was before the launch
-    if (lane == 0) st[E3_OVF] = 1.0;
-    return;
   }
   if (lane < NQ) st[E3_Q + lane] = sm.q[lane];
   if (lane < NV) { st[E3_V + lane] = sm.v[lane]; st[E3_WS + lane] = sm.ws[lane]; }
@@ -645,6 +650,7 @@ __global__ void __launch_bounds__(64, WPS) env_step3d_kernel(Params3 p) {
   if (lane == 0) {
     st[E3_TIME] = time; st[E3_NITER] = (double)niter_sum;
     if (left == 0) st[E3_NEFC] = (double)out.nefc;
+    if (ncapped) { st[E3_OVF] += (double)ncapped; if (p.stats) atomicAdd(p.stats + S3_CAPPED_SUBSTEPS, (unsigned long long)ncapped); }
     if (p.pending_out) p.pending_out[env] = left;
   }
 }

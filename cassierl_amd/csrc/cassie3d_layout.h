@@ -21,8 +21,12 @@ struct Params3 {
   double* debug;           // [n][D3_STRIDE] or null
   const int* pending_in;   // [n] substeps to do per env (second pass) or null: n_sub for everyone
   int* pending_out;        // [n] substeps NOT done because the env needed more rows than this kernel has, or null: flag E3_OVF
+  unsigned long long* stats;  // [S3_N] event counters of the handle (rare-path atomics only)
   int n_envs, n_sub, integrate;
 };
+// S3_GENERAL_SUBSTEPS: env-substeps the 32-row kernel handed to the 64-row kernel; S3_CAPPED_SUBSTEPS: env-substeps in which
+// the 64-row kernel had to leave contacts out (more than 64 constraint rows)
+enum { S3_GENERAL_SUBSTEPS = 0, S3_CAPPED_SUBSTEPS = 1, S3_N = 4 };
 
 }  // namespace cassie3d
 #endif

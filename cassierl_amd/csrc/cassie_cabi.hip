@@ -493,6 +493,8 @@ struct Cassie3dVec {
   hipStream_t stream = nullptr, own_stream = nullptr;  // kernels run on `stream`; `own_stream` is the one this handle created
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
   int* pending = nullptr;
+  unsigned long long* stats = nullptr;
+  unsigned long long substeps_requested = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 };
@@ -500,6 +502,7 @@ struct Cassie3dVec {
 namespace {
 // fast kernel (<= 32 rows, 2 waves per SIMD) for everyone, then the general kernel for the environments it left pending
 void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
+  p.stats = h->stats;
   if (p.debug) {
     L3::step3d(1, h->n, h->stream, p);
     return;
@@ -538,6 +541,8 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
   return CASSIE_OK;
@@ -547,7 +552,7 @@ void Cassie3dVecFree(Cassie3dVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending);
+  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending); hipFree(h->stats);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -585,12 +590,34 @@ int Cassie3dVecStep(Cassie3dVec* h, const double* torques_dev, int n_sub) {
   HIPCHK3(h, hipSetDevice(h->device));
   cassie3d::Params3 p{};
   p.state = h->state; p.actions = torques_dev; p.debug = nullptr; p.n_envs = h->n; p.n_sub = n_sub; p.integrate = 1;
+  h->substeps_requested += (unsigned long long)h->n * n_sub;
   launch3d(h, p);
   HIPCHK3(h, hipGetLastError());
   return CASSIE_OK;
 }
 
 double* Cassie3dVecStatePtr(Cassie3dVec* h) { return h ? h->state : nullptr; }
+
+int Cassie3dVecGetCounters(Cassie3dVec* h, uint64_t* out4) {
+  if (!h || !out4) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  unsigned long long host[cassie3d::S3_N];
+  HIPCHK3(h, hipMemcpyAsync(host, h->stats, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK3(h, hipStreamSynchronize(h->stream));
+  out4[0] = h->substeps_requested;
+  out4[1] = host[cassie3d::S3_GENERAL_SUBSTEPS];
+  out4[2] = host[cassie3d::S3_CAPPED_SUBSTEPS];
+  out4[3] = 0;
+  return CASSIE_OK;
+}
+
+int Cassie3dVecResetCounters(Cassie3dVec* h) {
+  if (!h) return CASSIE_EINVAL;
+  HIPCHK3(h, hipSetDevice(h->device));
+  HIPCHK3(h, hipMemsetAsync(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long), h->stream));
+  h->substeps_requested = 0;
+  return CASSIE_OK;
+}
 
 int Cassie3dVecStepHost(Cassie3dVec* h, const double* torques, int n_sub) {
   if (!h || !torques) return CASSIE_EINVAL;

@@ -43,6 +43,16 @@ class Cassie3dVec:
     def synchronize(self):
         self._chk(self.L.Cassie3dVecSynchronize(self.h))
 
+    def counters(self):
+        """env-substeps requested / done by the 64-row kernel / with the 64-row cap leaving contacts out."""
+        out = (ct.c_uint64 * 4)()
+        self._chk(self.L.Cassie3dVecGetCounters(self.h, out))
+        req, gen, cap = int(out[0]), int(out[1]), int(out[2])
+        return dict(substeps=req, general_kernel_substeps=gen, capped_substeps=cap, general_frac=(gen / req if req else 0.0))
+
+    def reset_counters(self):
+        self._chk(self.L.Cassie3dVecResetCounters(self.h))
+
     # ---- device API (torch tensors are only the allocator here)
     def reset(self, qpos=None, qvel=None):
         self._chk(self.L.Cassie3dVecReset(self.h, None if qpos is None else qpos.data_ptr(), None if qvel is None else qvel.data_ptr()))

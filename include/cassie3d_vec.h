@@ -34,7 +34,7 @@ extern "C" {
 #define CASSIE3D_OFF_TIME 71
 #define CASSIE3D_OFF_NITER 72
 #define CASSIE3D_OFF_NEFC 73
-#define CASSIE3D_OFF_OVERFLOW 74 /* != 0: the environment needed more than 64 constraint rows and was frozen */
+#define CASSIE3D_OFF_OVERFLOW 74 /* number of substeps of this environment in which the 64-row cap left contacts out (see below) */
 
 typedef struct Cassie3dVec Cassie3dVec;
 
@@ -48,6 +48,15 @@ int Cassie3dVecReset(Cassie3dVec* h, const double* qpos_dev, const double* qvel_
 /* n_sub mj_steps with torques_dev [n][10] (pre-clamp motor commands, as Cassie2d::Step takes them) */
 int Cassie3dVecStep(Cassie3dVec* h, const double* torques_dev, int n_sub);
 double* Cassie3dVecStatePtr(Cassie3dVec* h); /* device [n][CASSIE3D_STATE_STRIDE] */
+/* Event counters since create / the last reset of the counters (synchronises the stream):
+ *   out4[0] env-substeps requested
+ *   out4[1] env-substeps the 32-row kernel handed to the 64-row kernel
+ *   out4[2] env-substeps in which more than 64 constraint rows were active (the model's maximum is 69: 6 connect + 12 limit rows
+ *           + 17 contacts x 3) and the LAST contacts in MuJoCo order were left out for that substep.  The environment keeps
+ *           stepping (no frozen environment); record slot CASSIE3D_OFF_OVERFLOW counts the same per environment.
+ *   out4[3] reserved (0) */
+int Cassie3dVecGetCounters(Cassie3dVec* h, uint64_t* out4);
+int Cassie3dVecResetCounters(Cassie3dVec* h);
 /* host-pointer conveniences (tests, small batches) */
 int Cassie3dVecStepHost(Cassie3dVec* h, const double* torques, int n_sub);
 int Cassie3dVecGetStateHost(Cassie3dVec* h, double* state /*[n][80]*/);

@@ -140,6 +140,7 @@ struct Oracle {
   const double* hf;
   int hf_nrow, hf_ncol;
   double hf_sx, hf_sy;
+  int row_cap; /* > 0: at most this many constraint rows; the last contacts (MuJoCo order) that do not fit are dropped (Cassie3d kernel's cap) */
   int assume; /* ORC_ASSUME_* bits: the places where closed MuJoCo Pro 1.50 may differ from the published 2.x pipeline */
   /* constants derived at create (what MuJoCo's compiler / LoadModel derive) */
   double eq_anchor2[2][NEQ][3];
@@ -443,6 +444,7 @@ static void make_constraints(Oracle* o) {
       }
     }
   }
+  if (o->row_cap > 0 && o->nefc + 3 * o->ncon > o->row_cap) o->ncon = (o->row_cap - o->nefc) / 3; /* test switch, see row_cap */
   /* contacts, elliptic cone, condim 3 (mj_instantiateContact) */
   for (int c = 0; c < o->ncon; c++) {
     const Contact* cc = &o->con[c];
@@ -911,6 +913,7 @@ void orc_set_gravity(Oracle* o, double gz) { o->gravity_z = gz; }
 void orc_set_damping_scale(Oracle* o, double s) { for (int j = 0; j < NV; j++) o->damping[j] = s * cm_dof_damping[j]; }
 void orc_set_contact_enabled(Oracle* o, int e) { o->contact_enabled = e; }
 void orc_set_assumptions(Oracle* o, int mask) { o->assume = mask; }
+void orc_set_row_cap(Oracle* o, int cap) { o->row_cap = cap; }
 void orc_get_contacts(const Oracle* o, double* dist, double* pos, double* frame) {
   for (int i = 0; i < o->ncon; i++) {
     if (dist) dist[i] = o->con[i].dist;

@@ -69,6 +69,8 @@ void orc_set_contact_enabled(Oracle* o, int enabled);
 #define ORC_ASSUME_CONNECT_NORM_IMP 2 /* connect rows: one impedance from the norm of the 3-vector violation, not per row */
 #define ORC_ASSUME_WS_STEP_ONLY 4     /* qacc_warmstart written by mj_step only, not by a bare mj_forward (Reset) */
 void orc_set_assumptions(Oracle* o, int mask);
+/* cap > 0: keep at most `cap` constraint rows by dropping the last contacts (mirrors the 64-row cap of the Cassie3d kernel) */
+void orc_set_row_cap(Oracle* o, int cap);
 /* terrain (N4): heights in metres, [nrow][ncol] row-major, row r at y = -size_y + r*2*size_y/(nrow-1), column c likewise in x;
  * the array is NOT copied.  NULL restores the flat floor. */
 void orc_set_hfield(Oracle* o, const double* heights_m, int nrow, int ncol, double size_x, double size_y);

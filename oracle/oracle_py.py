@@ -329,6 +329,9 @@ class Oracle3D:
     def set_contact_enabled(self, e):
         self.L.orc_set_contact_enabled(self.h, ct.c_int(int(e)))
 
+    def set_row_cap(self, cap):
+        self.L.orc_set_row_cap(self.h, ct.c_int(cap))
+
     @property
     def nefc(self):
         return self.L.orc_nefc(self.h)

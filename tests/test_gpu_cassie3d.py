@@ -196,3 +196,45 @@ def test_many_contacts_hand_over_to_the_general_kernel(V3, kat):
     np.testing.assert_allclose(s[0, :21], q1, atol=1e-6)
     np.testing.assert_allclose(s[0, 21:41], v1, atol=1e-4 * (1 + np.abs(v1).max()))
     env.close()
+
+
+def test_row_cap_beyond_64_rows_matches_the_capped_oracle(V3, kat):
+    """The model's worst case is 69 rows (6 connect + 12 limits + 17 contacts x 3); the 64-row kernel then leaves the last
+    contacts out for that substep instead of freezing the environment.  A pressed-down, folded-up robot reaches
+    that regime: the kernel must match the oracle run with the same cap, count the event, and keep stepping."""
+    import oracle_py
+    rng = np.random.default_rng(9)
+    o = oracle_py.Oracle3D()
+    o.set_row_cap(64)
+    q = np.array(kat["qpos_init"])
+    q[2] = -0.7                                             # pressed into the floor: every collision sphere is down
+    q[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]
+    # every limited hinge beyond its range (cassie3d_stiff.xml; dofs 6..11 and 13..18, qpos address = dof + 1)
+    lim_dof = [6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18]
+    lim_rng = np.radians([[-15, 22.5], [-22.5, 22.5], [-50, 80], [-164, -37], [50, 170], [-140, -30]] * 2)
+    for k, dof in enumerate(lim_dof):
+        q[dof + 1] = lim_rng[k, 1] + 0.02 if k % 2 else lim_rng[k, 0] - 0.02
+    v = rng.uniform(-0.02, 0.02, 20)
+    o.reset(q, v)
+    free = oracle_py.Oracle3D()
+    free.reset(q, v)
+    assert free.nefc == 69 and o.nefc == 63, (free.nefc, o.nefc)  # 6 + 12 + 3 * 17; the cap keeps 15 contacts
+    env = V3.Cassie3dVec(2)
+    env.reset_counters()
+    u = np.zeros(10)
+    worst, capped = 0.0, 0
+    for i in range(12):
+        qo, vo = o.state()
+        env.set_state_host(np.tile(V3.state_record(qo, vo, o.warmstart()), (2, 1)))
+        env.step_host(np.tile(u, (2, 1)), 1)
+        o.step_torque(u)
+        free.reset(*o.state())
+        capped += free.nefc > 64
+        s = env.get_state_host()
+        q1, v1 = o.state()
+        assert np.isfinite(s).all() and s[0, 73] == o.nefc
+        worst = max(worst, np.abs(s[0, :21] - q1).max(), np.abs(s[0, 21:41] - v1).max() / (1.0 + np.abs(v1).max()))
+    assert worst < 1e-7, worst
+    c = env.counters()
+    assert c["capped_substeps"] >= 10 and capped >= 4 and c["general_kernel_substeps"] == 24
+    env.close()
