@@ -40,6 +40,7 @@ struct CassieVec {
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
   int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
+  unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
   unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
   unsigned long long substeps_requested = 0; // host: env-substeps asked for since the counters were last cleared
   bool g16 = true;                           // CASSIE2D_G16=0 selects the wave-per-environment kernel only (A/B)
@@ -89,6 +90,7 @@ cassie::VecParams make_params(CassieVec* h) {
   p.ovf_stride = OVF_STRIDE;
   p.stats = h->stats;
   p.hf = h->hf;
+  p.phase = h->phase;
   return p;
 }
 
@@ -97,13 +99,22 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
   const bool scripted = zpos != nullptr;
   if (mode != CASSIE_CTRL_OSC && mode != CASSIE_CTRL_JACOBIAN)
     return fail(h, CASSIE_EINVAL, "controller-in-the-loop stepping exists for OSC and Jacobian modes only");
+  if (h->hf.h) return fail(h, CASSIE_EINVAL, "a height field is set: only PD and torque control modes step on terrain");
   const int ctrl = mode == CASSIE_CTRL_OSC ? 2 : 3;
   if (h->g16 && !p.debug) {
-    // 4 environments per wavefront, then the wave-per-environment kernel for the (rare) environments left pending
-    L2::ctrl_g16(ctrl, scripted, h->n, h->stream, p, zpos, zvel, h->pending);
-    cassie::VecParams pc = p;
-    pc.pending = h->pending;
-    L2::ctrl_k4(ctrl, scripted, h->n, h->stream, pc, zpos, zvel);
+    // Per StepOsc / StepJacobian: the packed controller kernel writes the motor commands into the state record, the packed
+    // physics kernel (mode 2: commands from the record) does the mj_step, and the wave-per-environment physics kernel finishes the
+    // (rare) environments with more than 16 constraint rows.  Observation / reward / reset ride on the last substep.
+    for (int sub = 0; sub < p.n_sub; sub++) {
+      cassie::VecParams ps = p;
+      ps.n_sub = 1;
+      if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
+      L2::ctrl_g16(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
+      L2::step_g16(2, h->n, h->stream, ps, h->pending);
+      cassie::VecParams pc = ps;
+      pc.pending = h->pending;
+      L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, pc);
+    }
   } else {
     L2::ctrl_k4(ctrl, scripted, h->n, h->stream, p, zpos, zvel);
   }
@@ -193,6 +204,10 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->ovf, n * OVF_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->pending, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+#ifdef CASSIE_PHASE_TIMING
+  if (hipMalloc(&h->phase, 16 * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMemset(h->phase, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
+#endif
   if (hipMalloc(&h->stats, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
@@ -239,6 +254,16 @@ int CassieVecGetCounters(CassieVec* h, uint64_t* out4) {
   out4[3] = host[cassie::STAT_NONFINITE];
   return CASSIE_OK;
 }
+
+#ifdef CASSIE_PHASE_TIMING
+extern "C" int CassieVecPhaseCycles(CassieVec* h, unsigned long long* out16) {  // profiling builds only; not part of the public ABI
+  if (!h || !h->phase) return CASSIE_EINVAL;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return CASSIE_EHIP;
+  if (hipMemcpy(out16, h->phase, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return CASSIE_EHIP;
+  hipMemset(h->phase, 0, 16 * sizeof(unsigned long long));
+  return CASSIE_OK;
+}
+#endif
 
 int CassieVecResetCounters(CassieVec* h) {
   if (!h) return CASSIE_EINVAL;

@@ -239,10 +239,12 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 // iterations (typically 8 -> 1 or 2), not the solution.
 constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
 template <class SM>
-__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false) {
+__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false,
+                                         PhaseClock* pc = nullptr) {
   const int lane = rowok ? l : 63;
   double P4[16], g4[4];
   ctrl_dyn(sm, cs, c, l, rowok, P4, g4, noshort);
+  PHASE_MARK(*pc, 1);
   // ---- column lanes: 0..5 motors, 6..13 friction-cone generators of contact sites 2..5, 14 the bias column
   {
     double w[NV];
@@ -285,6 +287,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
     }
   }
   lds_sync();
+  PHASE_MARK(*pc, 2);
   // ---- QP data: row i of G and c_i on lane i (< 14)
   double G[NZ], cq = 0.0;
   {
@@ -318,8 +321,12 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
   double z = bound ? (atlo ? lo : hi) : 0.0;  // feasible start: bound variables on their bound, free ones at 0 (inside every box)
   if (l >= 6) z = 0.0;                          // generators have no upper bound
   bool busy = rowok;  // uniform inside a row
+  PHASE_MARK(*pc, 3);
   for (int it = 0; it < 60; it++) {
     if (__ballot(busy) == 0) break;
+#ifdef CASSIE_PHASE_TIMING
+    pc->acc[8] += 1;
+#endif
     double g = cq;
     static_for<0, NZ>([&](auto jj) { constexpr int Jv = decltype(jj)::value; g += G[Jv] * row_bcast<Jv>(z); });
     const unsigned bm = (unsigned)(__ballot(bound && isvar) >> (16 * rowid)) & 0xFFFFu;
@@ -373,6 +380,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
   }
   if (lane < 6) cs.u[lane] = z;
   lds_sync();
+  PHASE_MARK(*pc, 4);
 }
 
 // ---------------------------------------------------------------- Cassie2d::StepJacobian controller: cs.act[6] -> cs.u[6]

@@ -115,6 +115,23 @@ struct RowConst { double d1x, d1z, d2x, d2z, radius, invw, lim_lo, lim_hi, solre
 
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
+// Phase timing (profiling builds only): PHASE_MARK(acc, k) adds the shader cycles since the previous mark to acc[k].
+#ifdef CASSIE_PHASE_TIMING
+struct PhaseClock {
+  unsigned long long t, acc[16];
+  __device__ __forceinline__ void start() { for (int i = 0; i < 16; i++) acc[i] = 0; t = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int k) { unsigned long long n = __builtin_readcyclecounter(); acc[k] += n - t; t = n; }
+  __device__ __forceinline__ void flush(unsigned long long* dst, int lane) { if (dst && lane == 0) for (int i = 0; i < 16; i++) atomicAdd(dst + i, acc[i]); }
+};
+#define PHASE_MARK(pc, k) (pc).mark(k)
+#else
+struct PhaseClock {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void flush(unsigned long long*, int) {}
+};
+#define PHASE_MARK(pc, k) ((void)0)
+#endif
+
 __device__ __forceinline__ void load_lane_const(LaneConst& c, int lane) {
   int l = lane < NL ? lane : 0;
   c.ancmask = lane < NL ? cp_link_ancmask[l] : 0;
@@ -800,7 +817,8 @@ __device__ __forceinline__ void env_outputs_row(const VecParams& p, int l, const
 }
 
 // ---------------------------------------------------------------- the fused Env.step kernel
-// MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step)
+// MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (written by the controller
+// kernel of cassie_ctrl_g16.hip; hand-over pass of the split StepOsc / StepJacobian path)
 // WPS: waves per SIMD the register allocation is sized for.  4 (128 VGPRs, some spills) wins when the grid is only
 // ~4 waves per SIMD deep (4096 envs); 3 (168 VGPRs, fewer spills) wins on deep grids (measured, profiles/r01_b_*).
 template <int MODE, int WPS, int MAXACT, bool HF = false>
@@ -821,10 +839,11 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   double s1 = load_state(st, sm, lane);
   double qstate_l = s1;  // lane 1+j holds qstate[j]
   double time = rdlane(s1, 20);
+  double wset_keep = MODE == 2 ? st[ES_QPWSET] : 0.0;
   lds_sync();
   // action for this dof lane
   double act_l = 0.0;
-  if (p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[(size_t)env * p.adim + c.act];
+  if (MODE != 2 && p.actions && c.act >= 0 && c.dvalid) act_l = p.actions[(size_t)env * p.adim + c.act];
   double* dbg = p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr;
   double* ovf = p.ovf + (size_t)env * p.ovf_stride;
   StepOut so; so.niter = 0; so.active = 0;
@@ -836,6 +855,8 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
     if (MODE == 0) {
       int dd = c.d < NV ? c.d : 0;
       ctrl = 10.0 * (act_l - sm.q[dd]) + 5.0 * (0.0 - sm.v[dd]);
+    } else if (MODE == 2) {
+      ctrl = c.act >= 0 ? sm.ctrl[c.act] : 0.0;
     } else {
       ctrl = act_l;
     }
@@ -874,6 +895,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
       if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }
       if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
       time = 0.0;
+      wset_keep = 0.0;  // new episode: cold start of the OSC QP too
       lds_sync();
       substep<false, MAXACT, HF>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf, &p.hf);
       opstate18(sm, c, lane, fix_kin, s18);
@@ -886,6 +908,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   }
   // ---- coalesced state write-back
   store_state(st, sm, lane, qstate_l, time, niter_sum);
+  if (MODE == 2 && lane == 0) st[ES_QPWSET] = wset_keep;  // store_state clears the slot; the OSC hot start survives a hand-over
 }
 
 // ---------------------------------------------------------------- masked reset (Cassie2dEnv.reset / Cassie2d::Reset)

@@ -426,7 +426,8 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
 }
 
 // ---------------------------------------------------------------- fused Env.step, 4 envs per wave
-// MODE: 0 PD, 1 torque.  pending[env] = substeps this kernel did NOT do (0 in the normal case).
+// MODE: 0 PD, 1 torque, 2 motor commands from the state record (the controller kernel of cassie_ctrl_g16.hip wrote them: StepOsc /
+// StepJacobian = controller launch + this kernel with n_sub = 1).  pending[env] = substeps this kernel did NOT do (0 normally).
 template <int MODE, bool HF = false>
 __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* pending) {
   __shared__ EnvLds sm4[4];
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   }
   if (l < NU) sm.ctrl[l] = st[ES_CTRL + l];
   if (l == 0) sm.tim[0] = st[ES_TIME];
-  sm.actl[l] = (p.actions && c.act >= 0 && c.dvalid) ? p.actions[e * p.adim + c.act] : 0.0;
+  sm.actl[l] = (MODE != 2 && p.actions && c.act >= 0 && c.dvalid) ? p.actions[e * p.adim + c.act] : 0.0;
   lds_sync();
   bool live = valid;
   int pend = 0, niter_sum = 0;
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     const int dd = c.d < NV ? c.d : 0;
     const double q_d = sm.q[dd], v_d = sm.v[dd];
     double cnew;
-    if (reset_pass) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
+    if (reset_pass || MODE == 2) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
     else { const double act_l = sm.actl[l]; cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l; }
     substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf);  // reset pose on the flat floor: 12 active rows
     if (!reset_pass) {
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     if (__ballot(do_reset) == 0) break;
     // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
     if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; sm.qst[l] = cp_env_qinit[l]; }
-    if (do_reset && l == 0) sm.tim[0] = 0.0;
+    if (do_reset && l == 0) { sm.tim[0] = 0.0; st[ES_QPWSET] = 0.0; }  // new episode: cold start of the OSC QP too
     lds_sync();
     reset_pass = true;
   }

@@ -15,7 +15,8 @@ namespace launch {
 enum K1Variant { K1_DEEP = 0 /* <.,3,32> */, K1_SHALLOW = 1 /* <.,4,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
 constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
 
-// tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque)
+// tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque, 2 motor commands from the state record; mode 2 has the
+// K1_DEEP variant only)
 void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p);
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
 // tu_hf.hip: the same kernels with the height-field collision stage (p.hf.h != null); PD / torque modes
@@ -29,7 +30,8 @@ void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, dou
 void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tu_ctrl.hip / tu_ctrl_g16.hip: controller in the loop (ctrl: 2 OSC, 3 Jacobian)
 void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
-void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel, int* pending);
+// (the packed controller kernel only writes the motor commands; step_g16 / step_k1 with mode 2 then do the mj_step)
+void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
 
 }  // namespace launch
 }  // namespace cassie

@@ -56,6 +56,7 @@ struct VecParams {
   int ovf_stride;
   const int* pending;     // [n_envs] substeps left per env (clean-up pass after the 4-envs-per-wave kernel) or null
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
+  unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };

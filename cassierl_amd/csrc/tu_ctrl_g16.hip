@@ -1,6 +1,5 @@
 // tu_ctrl_g16.hip -- translation unit of the four-environments-per-wavefront controller kernels (cassie_ctrl_g16.hip).
 #include "cassie_kernels.hip"
-#include "cassie_kernels_g16.hip"
 #include "cassie_ctrl.hip"
 #include "cassie_ctrl_g16.hip"
 #include "cassie_launch.h"
@@ -8,14 +7,14 @@
 namespace cassie {
 namespace launch {
 
-void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel, int* pending) {
+void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel) {
   dim3 grid((n_envs + 3) / 4), block(64);
   if (ctrl == 2) {
-    if (scripted) hipLaunchKernelGGL((g16::env_ctrl_step_g16_kernel<2, true>), grid, block, 0, s, p, zpos, zvel, pending);
-    else hipLaunchKernelGGL((g16::env_ctrl_step_g16_kernel<2, false>), grid, block, 0, s, p, zpos, zvel, pending);
+    if (scripted) hipLaunchKernelGGL((g16::env_ctrl_g16_kernel<2, true>), grid, block, 0, s, p, zpos, zvel);
+    else hipLaunchKernelGGL((g16::env_ctrl_g16_kernel<2, false>), grid, block, 0, s, p, zpos, zvel);
   } else {
-    if (scripted) hipLaunchKernelGGL((g16::env_ctrl_step_g16_kernel<3, true>), grid, block, 0, s, p, zpos, zvel, pending);
-    else hipLaunchKernelGGL((g16::env_ctrl_step_g16_kernel<3, false>), grid, block, 0, s, p, zpos, zvel, pending);
+    if (scripted) hipLaunchKernelGGL((g16::env_ctrl_g16_kernel<3, true>), grid, block, 0, s, p, zpos, zvel);
+    else hipLaunchKernelGGL((g16::env_ctrl_g16_kernel<3, false>), grid, block, 0, s, p, zpos, zvel);
   }
 }
 

@@ -9,7 +9,8 @@ namespace launch {
 void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending) {
   dim3 grid((n_envs + 3) / 4), block(64);
   if (mode == 0) hipLaunchKernelGGL((g16::env_step_g16_kernel<0>), grid, block, 0, s, p, pending);
-  else hipLaunchKernelGGL((g16::env_step_g16_kernel<1>), grid, block, 0, s, p, pending);
+  else if (mode == 1) hipLaunchKernelGGL((g16::env_step_g16_kernel<1>), grid, block, 0, s, p, pending);
+  else hipLaunchKernelGGL((g16::env_step_g16_kernel<2>), grid, block, 0, s, p, pending);
 }
 
 }  // namespace launch

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the OSC controller-in-the-loop kernel (not a test).  Needs a profiling build of the extension
+(-DCASSIE_PHASE_TIMING) pointed to by CASSIE2D_LIB; prints shader cycles per phase summed over wavefronts."""
+import ctypes as ct
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from cassierl_amd import rollout as R  # noqa: E402
+from cassierl_amd.vec_env import CassieVecEnv  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+scripted = len(sys.argv) > 2 and sys.argv[2] == "scripted"
+env = CassieVecEnv(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
+out = env.alloc()
+env.reset(out)
+ids = torch.arange(n, device="cuda")
+lo, hi = np.array([-2, -2, -2, 0, -2, 0, -2.0]), np.full(7, 2.0)
+zp = torch.full((n,), 0.9, dtype=torch.float64, device="cuda")
+zv = torch.zeros(n, dtype=torch.float64, device="cuda")
+buf = (ct.c_ulonglong * 16)()
+env.L.CassieVecPhaseCycles.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+for rep in range(2):
+    for t in range(10):
+        if scripted:
+            env._chk(env.L.CassieVecStandingStep(env.h, 2, zp.data_ptr(), zv.data_ptr(), 10))
+        else:
+            env.step(R.random_actions(4, ids, t + 10 * rep, lo, hi), out)
+    env._chk(env.L.CassieVecPhaseCycles(env.h, buf))
+v = np.array(list(buf), dtype=np.float64)
+names = ["0 staging/setState", "1 ctrl_dyn (FK, M, Hinv, rows, pinv4)", "2 T build (Nc, Hinv y, A x)", "3 QP data (G, c)", "4 QP iterations",
+         "5 glue", "6 physics substep"]
+tot = v[:7].sum()
+for i, nm in enumerate(names):
+    print("%-42s %6.2f %%" % (nm, 100 * v[i] / tot))
+print("QP iterations per wave-substep: %.2f" % (v[8] / (n / 4 * 10 * 10)))
