@@ -116,14 +116,21 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
       L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, pc);
     }
   } else {
-    L2::ctrl_k4(ctrl, scripted, h->n, h->stream, p, zpos, zvel);
+    // wave-per-environment kernels only (CASSIE_WAVE_PER_ENV cross-check, debug record): same split, one wavefront per environment
+    for (int sub = 0; sub < p.n_sub; sub++) {
+      cassie::VecParams ps = p;
+      ps.n_sub = 1; ps.pending = nullptr;
+      if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
+      L2::ctrl_k4(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
+      ps.debug = nullptr;
+      L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, ps);
+    }
   }
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
 
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
-  const bool shallow = h->n <= 16384;  // <= ~16 waves per SIMD queued: favour residency over spill-free code
   const bool pdtq = mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE;
   if (h->hf.h) {
     // height-field terrain: PD / torque physics only (the controllers' contact model assumes the flat floor, OSC_RBDL.cpp:41-71)
@@ -148,7 +155,7 @@ int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
     // test hook: same code with only MAXACT_DBG register-resident columns, so that the workspace path is exercised
     L2::step_k1(mode, L2::K1_DEBUG, h->n, h->stream, p);
   } else if (pdtq) {
-    L2::step_k1(mode, shallow ? L2::K1_SHALLOW : L2::K1_DEEP, h->n, h->stream, p);
+    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p);
   }
   else if (mode == CASSIE_CTRL_OSC || mode == CASSIE_CTRL_JACOBIAN) {
     return launch_ctrl_step(h, mode, p, nullptr, nullptr);

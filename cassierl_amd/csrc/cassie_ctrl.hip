@@ -559,85 +559,33 @@ __device__ __forceinline__ void scripted_targets(SM& sm, CtrlSmem& cs, const Lan
   lds_sync();
 }
 
-// ---------------------------------------------------------------- fused controller + physics kernel
+// ---------------------------------------------------------------- controller kernel, one wavefront per environment
 // CTRL: 2 = OSC (StepOsc), 3 = Jacobian (StepJacobian).  SCRIPTED: targets come from standing_controller_* instead of actions.
+// DynamicModel::setState + DynamicState + controller; the motor commands go into the state record and env_step_kernel<2, ..>
+// (cassie_kernels.hip) does the mj_step -- the same split as the packed path (cassie_ctrl_g16.hip), kept as the independent
+// cross-check of that path (CASSIE_WAVE_PER_ENV) and for the debug record of the Jacobian controller.
 template <int CTRL, bool SCRIPTED>
-__global__ void __launch_bounds__(64, 2) env_ctrl_step_kernel(VecParams p, const double* zpos, const double* zvel) {
+__global__ void __launch_bounds__(64, 1) env_ctrl_kernel(VecParams p, const double* zpos, const double* zvel) {
   __shared__ Smem sm;
   __shared__ CtrlSmem cs;
-  __shared__ double s18[18];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   if (env >= p.n_envs) return;
-  // clean-up pass of the 4-envs-per-wave kernel: only the envs it could not finish, only their remaining substeps
-  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
-  if (n_sub == 0) return;
-  if (p.pending && p.stats && lane == 0) atomicAdd(p.stats + STAT_K1_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);
-  double s1 = load_state(st, sm, lane);
-  double qstate_l = s1;
-  double time = rdlane(s1, 20);
+  load_state(st, sm, lane);
   constexpr int ADIM = CTRL == 2 ? 7 : 6;
   if (!SCRIPTED && lane < ADIM) cs.act[lane] = p.actions[(size_t)env * ADIM + lane];
-  const double zp = SCRIPTED ? zpos[env] : 0.0, zv = SCRIPTED ? zvel[env] : 0.0;
   lds_sync();
-  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
-  double* ovf = p.ovf + (size_t)env * p.ovf_stride;
-  StepOut so; so.niter = 0; so.active = 0;
-  int niter_sum = 0;
-  double ctrl = 0.0;
+  const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0, noshort = (p.flags & FLAG_NO_PINV_SHORTCUT) != 0;
   unsigned wset = (unsigned)st[ES_QPWSET];
-  const bool noshort = (p.flags & FLAG_NO_PINV_SHORTCUT) != 0;
-  for (int sub = 0; sub < n_sub; sub++) {
-    if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zp, zv);
-    if (lane < 13) { sm.kq[lane] = sm.q[lane]; sm.kv[lane] = sm.v[lane]; }  // DynamicModel::setState
-    lds_sync();
-    if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort);
-    else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr, noshort);
-    ctrl = c.act >= 0 ? cs.u[c.act] : 0.0;
-    substep<true, 32>(sm, c, lane, ctrl, so, nullptr, ovf);
-    niter_sum += so.niter;
-    time += 0.0005;
-  }
-  if (c.dvalid && c.grp == 0 && c.act >= 0) sm.ctrl[c.act] = ctrl;
+  if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zpos[env], zvel[env]);  // kinematics of the LAST setState
+  if (lane < 13) { st[ES_KQ + lane] = sm.q[lane]; st[ES_KV + lane] = sm.v[lane]; }  // DynamicModel::setState
   lds_sync();
-  if (p.obs) {
-    // Env.step with control_mode 'OSC' (cassie2d.py:97-225 walk env / cassie_stand2d.py:86-137): observation, reward, termination
-    opstate18(sm, c, lane, fix_kin, s18);
-    double sp = 0.0;
-    if (lane < 17) sp = s18[lane + 1];
-    if (lane == 5 || lane == 11) sp -= s18[0];
-    double reward = 0.0;
-    int done = 0;
-    env_outputs_wave(p, sm, s18, lane, SCRIPTED ? nullptr : p.actions + (size_t)env * ADIM, ADIM, qstate_l, time, sp, reward, done);
-    const bool bad = __ballot(lane < 26 && !in_range(lane < 13 ? sm.q[lane] : sm.v[lane - 13])) != 0 || !in_range(reward);  // failure guard
-    if (bad) {
-      sp = 0.0; reward = 0.0; done = 1;
-      if (lane == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
-      if (p.auto_reset) {
-        if (lane < 13) { sm.ws[lane] = 0.0; sm.kq[lane] = cp_env_qinit[lane]; sm.kv[lane] = 0.0; }
-        if (lane < NU) sm.ctrl[lane] = 0.0;
-      }
-    }
-    if (p.terminal_obs && lane < 26) p.terminal_obs[(size_t)env * 26 + lane] = sp;
-    if (done && p.auto_reset) {
-      if (lane < 13) { sm.q[lane] = cp_env_qinit[lane]; sm.v[lane] = 0.0; }
-      if (lane >= 1 && lane < 14) qstate_l = cp_env_qinit[lane - 1];
-      time = 0.0;
-      wset = 0u;
-      lds_sync();
-      substep<false, 32>(sm, c, lane, c.act >= 0 ? sm.ctrl[c.act] : 0.0, so, nullptr, ovf);
-      opstate18(sm, c, lane, fix_kin, s18);
-      sp = 0.0;
-      if (lane < 17) sp = s18[lane + 1];
-      if (lane == 5 || lane == 11) sp -= s18[0];
-    }
-    if (lane < 26) p.obs[(size_t)env * 26 + lane] = sp;
-    if (lane == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
-  }
-  store_state(st, sm, lane, qstate_l, time, niter_sum);
+  if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort);
+  else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr, noshort);
+  if (lane < NU) st[ES_CTRL + lane] = cs.u[lane];  // mj_data->ctrl (pre-clamp), consumed by the physics kernel
   if (CTRL == 2 && lane == 0) st[ES_QPWSET] = (double)wset;
 }
 

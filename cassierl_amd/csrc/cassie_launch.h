@@ -11,12 +11,13 @@
 namespace cassie {
 namespace launch {
 
-// K1 instantiations of env_step_kernel<MODE, WPS, MAXACT>
-enum K1Variant { K1_DEEP = 0 /* <.,3,32> */, K1_SHALLOW = 1 /* <.,4,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
+// K1 instantiations of env_step_kernel<MODE, WPS, MAXACT>.  The general kernel is sized for ONE wavefront per SIMD (312 registers,
+// no scratch): its product role is the hand-over pass, where nearly every wavefront exits at once and occupancy buys nothing,
+// while the 168-register build it replaced spilled 608 B per lane (r01/r02 PMC).
+enum K1Variant { K1_DEEP = 0 /* <.,1,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
 constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
 
-// tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque, 2 motor commands from the state record; mode 2 has the
-// K1_DEEP variant only)
+// tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque, 2 motor commands from the state record; K1_DEBUG: modes 0, 1)
 void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p);
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
 // tu_hf.hip: the same kernels with the height-field collision stage (p.hf.h != null); PD / torque modes
@@ -28,7 +29,7 @@ void init_state(int n_envs, hipStream_t s, double* state);
 void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel);
 // tu_g16.hip: four environments per wavefront
 void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
-// tu_ctrl.hip / tu_ctrl_g16.hip: controller in the loop (ctrl: 2 OSC, 3 Jacobian)
+// tu_ctrl.hip / tu_ctrl_g16.hip: controllers (ctrl: 2 OSC, 3 Jacobian): they write the motor commands into the state record
 void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
 // (the packed controller kernel only writes the motor commands; step_g16 / step_k1 with mode 2 then do the mj_step)
 void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);

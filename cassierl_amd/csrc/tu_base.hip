@@ -11,13 +11,10 @@ void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecPa
   if (variant == K1_DEBUG) {
     if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 2, K1_MAXACT_DBG>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((env_step_kernel<1, 2, K1_MAXACT_DBG>), grid, block, 0, s, p);
-  } else if (variant == K1_SHALLOW) {
-    if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 4, K1_MAXACT>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((env_step_kernel<1, 4, K1_MAXACT>), grid, block, 0, s, p);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 3, K1_MAXACT>), grid, block, 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL((env_step_kernel<1, 3, K1_MAXACT>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((env_step_kernel<2, 3, K1_MAXACT>), grid, block, 0, s, p);
+    if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 1, K1_MAXACT>), grid, block, 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL((env_step_kernel<1, 1, K1_MAXACT>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((env_step_kernel<2, 1, K1_MAXACT>), grid, block, 0, s, p);
   }
 }
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel) {

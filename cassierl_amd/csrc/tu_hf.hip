@@ -10,8 +10,8 @@ namespace launch {
 
 void step_k1_hf(int mode, int n_envs, hipStream_t s, const VecParams& p) {
   dim3 grid(n_envs), block(64);
-  if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 3, K1_MAXACT, true>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((env_step_kernel<1, 3, K1_MAXACT, true>), grid, block, 0, s, p);
+  if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 1, K1_MAXACT, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((env_step_kernel<1, 1, K1_MAXACT, true>), grid, block, 0, s, p);
 }
 void step_g16_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending) {
   dim3 grid((n_envs + 3) / 4), block(64);
