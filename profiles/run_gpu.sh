@@ -21,5 +21,10 @@ for w in $what; do
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
           python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline > "$out/stats_bench.log" 2>&1 )
       find "$out/stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
+    trpo)
+      timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
+      tail -2 "$out/trpo_65536.jsonl" | cut -c1-400 ;;
+    pmc)
+      bash profiles/collect_pmc.sh $tag | tail -12 ;;
   esac
 done
