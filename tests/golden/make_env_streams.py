@@ -87,7 +87,7 @@ def main():
         a_osc = rng.uniform(-1, 1, size=(T, 7)) * np.array([3, 3, 1, 1, 1, 1, 3.0]); a_osc[:, 3] = np.abs(a_osc[:, 3]); a_osc[:, 5] = np.abs(a_osc[:, 5])
         for tag, module, mode, acts in (("walk_pd", "cassie2d", "PD", a_pd), ("walk_torque", "cassie2d", "Torque", a_tq),
                                         ("stand_torque", "cassie_stand2d", "Torque", a_tq), ("stand_pd", "cassie_stand2d", "PD", a_pd),
-                                        ("stand_osc", "cassie_stand2d", "OSC", a_osc)):
+                                        ("stand_osc", "cassie_stand2d", "OSC", a_osc), ("walk_osc", "cassie2d", "OSC", a_osc)):
             o0, o, r, d, rs = record(module, mode, acts, T)
             out[tag + "_actions"], out[tag + "_obs0"], out[tag + "_obs"] = acts, o0, o
             out[tag + "_reward"], out[tag + "_done"], out[tag + "_reset_obs"] = r, d, rs

@@ -65,6 +65,28 @@ def test_env_step_osc_golden_stream(vec, streams, traj):
     env.close()
 
 
+@pytest.mark.parametrize("wave_per_env", [False, True])
+def test_walk_env_with_osc_control_golden_stream(vec, streams, traj, wave_per_env):
+    """cassie2d.py with control_mode = 'OSC' (the walk env accepts it, cassie2d.py:53,104-105): reference-gait reward, r < 0.6
+    termination, gait joints in obs[17:26] -- recorded from the reference's own class (tests/golden/make_env_streams.py).
+    r01 computed the stand reward here."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    n = 3
+    env = vec(n, kind="walk", control_mode="OSC", n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV if wave_per_env else 0)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    obs0 = env.reset_host()
+    np.testing.assert_allclose(obs0, np.tile(streams["walk_osc_obs0"], (n, 1)), atol=1e-12)
+    acts = streams["walk_osc_actions"]
+    for t in range(40):
+        obs, rew, done = env.step_host(np.tile(acts[t], (n, 1)))
+        assert (done == bool(streams["walk_osc_done"][t])).all()
+        np.testing.assert_allclose(rew, streams["walk_osc_reward"][t], rtol=0, atol=1e-6)
+        want = streams["walk_osc_reset_obs"][t] if streams["walk_osc_done"][t] else streams["walk_osc_obs"][t]
+        np.testing.assert_allclose(obs, np.tile(want, (n, 1)), rtol=0, atol=1e-5)
+    assert streams["walk_osc_done"].all() and abs(streams["walk_osc_reward"][0] - 0.39754008) < 1e-7  # quirk Q3 in this mode too
+    env.close()
+
+
 def _py_standing_osc(o, zpos, zvel, flags=0):
     s = o.opstate(flags)
     act = np.zeros(7)
