@@ -59,6 +59,28 @@ __device__ __forceinline__ int nth_set_bit(unsigned mask, int n) {
 
 struct G16Out { int niter; bool overflow; };
 
+#ifdef CASSIE_MFMA
+// -DCASSIE_MFMA: A = J M^-1 J' through v_mfma_f64_16x16x4 (A/B experiment asked for by the north star).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef unsigned mfma_u2 __attribute__((ext_vector_type(2)));
+// a' = [a.lanes0-31, b.lanes0-31], b' = [a.lanes32-63, b.lanes32-63]   (v_permlane32_swap, gfx950)
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  mfma_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  mfma_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]   (v_permlane16_swap, gfx950)
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  mfma_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  mfma_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// 4x4 transpose between (register index) and (16-lane row index): afterwards register k of row G holds what register G of row k held
+__device__ __forceinline__ void transpose_regs_rows(double& r0, double& r1, double& r2, double& r3) {
+  swap32(r0, r2); swap32(r1, r3); swap16(r0, r1); swap16(r2, r3);
+}
+#endif
+
 // ---------------------------------------------------------------- one mj_forward (+ optional Euler step) for 4 envs
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
 // `integrate` (wave-uniform) = false gives mj_forward only (Cassie2d::Reset); it is a run-time flag so that a kernel carries ONE
@@ -139,7 +161,9 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   }
   double b = 0.0, jar = 0.0, R = 1.0;
   const bool active = kind != RK_SKIP;
+#ifndef CASSIE_MFMA
   double X[NV];
+#endif
   int leg = 0;
   {
     const int so = opaque(slot);
@@ -211,6 +235,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     jar = jw - aref;
     static_for<0, 8>([&](auto kk) { constexpr int K = decltype(kk)::value; sm.rowJ[l][K] = active ? J[K] : 0.0; });
     sm.rowleg[l] = leg;
+#ifndef CASSIE_MFMA
     const double* mi = sm.minv;
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
@@ -218,11 +243,61 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
       static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; sx += mi[C * NV + vbase + K] * J[3 + K]; });
       X[C] = sx;
     });
+#endif
   }
   lds_sync();
   // ---- row of A = J M^-1 J' + R in registers (16 columns = the 16 row lanes of this environment)
   double Ac[MAXR];
   double Adiag = 1.0, Ant = 0.0;
+#ifdef CASSIE_MFMA
+  {
+    // Per environment gg of the wave, two 16x16x16 products on the matrix cores, K = dof index padded 13 -> 16 (4 MFMAs each):
+    //   X' = Minv J'  (M index = dof, N index = constraint row)   then   A = X J'  (M = row, N = row),
+    // all 64 lanes reading the operands of environment gg from ITS LDS.  Operand layouts of v_mfma_f64_16x16x4 (probed on
+    // gfx950): A-operand lane i = A[i % 16][i / 16], B-operand lane i = B[i / 16][i % 16], result register j of lane i =
+    // D[4 j + i / 16][i % 16].  With that layout the result of the first product IS the A-operand of the second
+    // (X[r][4 s + i/16] sits in register s of lane 16 (i/16) + r), so nothing moves in between.  The second result holds, on
+    // lane 16 k + c, A_gg[4 j + k][c] = A_gg[c][4 j + k]: row c's entries are spread over the four 16-lane rows, and one 4x4
+    // (register <-> row) transpose per j -- v_permlane32_swap + v_permlane16_swap, no LDS -- brings every environment's
+    // rows back to its own lanes.
+    SM* const base = &sm - g;
+    mfma_d4 Dres[4];
+    static_for<0, 4>([&](auto ggc) {
+      constexpr int GG = decltype(ggc)::value;
+      const SM& se = base[GG];
+      const int legr = se.rowleg[l];
+      double bop[4];
+      mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      static_for<0, 4>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        const int j = 4 * S + g;  // dof index carried by this lane in K-chunk S
+        const int idx = j < 3 ? j : (legr == 0 ? (j < 8 ? j : -1) : ((j >= 8 && j < NV) ? j - 5 : -1));
+        bop[S] = idx >= 0 ? se.rowJ[l][idx < 0 ? 0 : idx] : 0.0;
+        const double aop = (l < NV && j < NV) ? se.minv[(l < NV ? l : 0) * NV + (j < NV ? j : 0)] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[S], acc, 0, 0, 0);
+      });
+      mfma_d4 acc2 = {0.0, 0.0, 0.0, 0.0};
+      static_for<0, 4>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[S], bop[S], acc2, 0, 0, 0);
+      });
+      Dres[GG] = acc2;
+    });
+    static_for<0, 4>([&](auto jc) {
+      constexpr int Jj = decltype(jc)::value;
+      double t0 = Dres[0][Jj], t1 = Dres[1][Jj], t2 = Dres[2][Jj], t3 = Dres[3][Jj];
+      transpose_regs_rows(t0, t1, t2, t3);
+      Ac[4 * Jj + 0] = t0; Ac[4 * Jj + 1] = t1; Ac[4 * Jj + 2] = t2; Ac[4 * Jj + 3] = t3;
+    });
+    static_for<0, MAXR>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      double a = active ? Ac[K] : 0.0;
+      if (l == K && active) { a += R; Adiag = a; }
+      if (l + 1 == K && kind == RK_CN) Ant = a;
+      Ac[K] = a;
+    });
+  }
+#else
   static_for<0, MAXR>([&](auto kk) {
     constexpr int K = decltype(kk)::value;
     const double* js = sm.rowJ[K];
@@ -236,6 +311,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     if (l + 1 == K && kind == RK_CN) Ant = a;
     Ac[K] = a;
   });
+#endif
   const double Ainv = 1.0 / Adiag;
   const double Apart = swap1(Adiag);
   // ---- warm start (mj_constraintUpdate) kept only if its dual cost beats zero force

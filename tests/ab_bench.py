@@ -1,34 +1,50 @@
 #!/usr/bin/env python3
-"""A/B timing of kernel variants (not a test).  python tests/ab_bench.py [lib.so ...]; runs each with CASSIE2D_G16=1 and 0."""
+"""A/B of two builds of the extension on the bench workload (not a test): for each library given on the command line, the median
+kernel time of one 65 536-env Env.step (PD and torque) by HIP events, plus a spot check that the builds agree.
+usage: python tests/ab_bench.py libA.so libB.so"""
+import json
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CODE = r'''
-import sys, os, numpy as np, torch
+CHILD = r'''
+import os, sys, json, numpy as np
 sys.path.insert(0, %r)
+import torch
+from cassierl_amd import rollout as R
+from cassierl_amd.trajectory import default_gait
 from cassierl_amd.vec_env import CassieVecEnv
-d = np.load(os.path.join(%r, "tests", "golden", "traj2d.npz"))
-rng = np.random.default_rng(0)
-lo, hi = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
-for kind, mode, n in (("walk", "PD", 4096), ("walk", "PD", 65536), ("stand", "Torque", 4096), ("stand", "Torque", 65536)):
+g = default_gait()
+out = {}
+for kind, mode in (("walk", "PD"), ("stand", "Torque")):
+    n = 65536
     env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
-    env.set_trajectory(d["time"], d["qpos"])
-    out = env.alloc(); env.reset(out)
-    if mode == "PD":
-        a = torch.as_tensor(rng.uniform(lo, hi, size=(n, 6)), device="cuda")
-    else:
-        a = torch.as_tensor(rng.uniform(-1, 1, size=(n, 6)) * np.array([12, 12, .9] * 2), device="cuda")
-    env.time_steps(a, 30 if mode == "Torque" else 5, out)
-    ms = min(env.time_steps(a, 20, out) for _ in range(3))
+    env.set_trajectory(g.time, g.qpos)
+    bufs = env.alloc(); env.reset(bufs)
+    ids = torch.arange(n, device="cuda")
+    lo, hi = env.action_space.low, env.action_space.high
+    for t in range(20):
+        env.step(R.random_actions(1, ids, t, lo, hi), bufs)
     q, v = env.get_state_host()
-    print("  %%-5s %%-6s n=%%6d  %%.3f ms/step  %%.3f M env-steps/s  finite=%%s  zmean=%%.3f" %% (kind, mode, n, ms, n / ms / 1e3, np.isfinite(q).all(), q[:, 1].mean()))
+    ms = [env.time_steps(R.random_actions(1, ids, 20 + t, lo, hi), 20, bufs) for t in range(7)]
+    out[mode] = dict(ms_per_step=float(np.median(ms)), ms_all=[float(x) for x in ms], q0=q[:8].tolist())
     env.close()
-''' % (ROOT, ROOT)
-libs = sys.argv[1:] or [os.path.join(ROOT, "cassierl_amd", "lib", "libcassie2d.so")]
-for lib in libs:
-    for g16 in ("1", "0"):
-        print(lib, "CASSIE2D_G16=" + g16, flush=True)
-        env = dict(os.environ, CASSIE2D_LIB=os.path.abspath(lib), CASSIE2D_G16=g16)
-        subprocess.run([sys.executable, "-c", CODE], env=env)
+print("AB " + json.dumps(out))
+''' % ROOT
+res = []
+for lib in sys.argv[1:]:
+    env = dict(os.environ, CASSIE2D_LIB=os.path.abspath(lib))
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+    line = [l for l in p.stdout.splitlines() if l.startswith("AB ")]
+    if not line:
+        print(lib, "FAILED", p.stderr[-800:])
+        continue
+    r = json.loads(line[0][3:])
+    res.append(r)
+    print(json.dumps(dict(lib=lib, **{k: dict(ms_per_step=v["ms_per_step"], ms_all=v["ms_all"]) for k, v in r.items()})))
+if len(res) == 2:
+    import numpy as np
+    for k in res[0]:
+        d = np.abs(np.array(res[0][k]["q0"]) - np.array(res[1][k]["q0"])).max()
+        print(json.dumps(dict(mode=k, B_over_A_time=res[1][k]["ms_per_step"] / res[0][k]["ms_per_step"], max_dq_8_envs_after_20_steps=float(d))))
