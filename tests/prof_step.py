@@ -10,7 +10,9 @@ from cassierl_amd import rollout as R
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 mode = sys.argv[3] if len(sys.argv) > 3 else "PD"
-d = np.load(os.path.join(ROOT, "tests", "golden", "traj2d.npz"))
+from cassierl_amd.trajectory import default_gait
+g = default_gait()
+d = dict(time=g.time, qpos=g.qpos)
 env = CassieVecEnv(n, kind="walk" if mode == "PD" else "stand", control_mode=mode, n_substeps=10, auto_reset=True)
 env.set_trajectory(d["time"], d["qpos"])
 out = env.alloc(); env.reset(out)
