@@ -825,13 +825,20 @@ template <int MODE, int WPS, int MAXACT, bool HF = false>
 __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   __shared__ Smem sm;
   __shared__ double s18[18];
-  const int env = blockIdx.x;
   const int lane = threadIdx.x;
-  if (env >= p.n_envs) return;
-  // clean-up pass of the 4-envs-per-wave kernel: only envs it could not finish, only their remaining substeps.  Checked before
-  // anything else so that the (usual) no-op wave touches neither the state nor its scratch.
-  const int n_sub = p.pending ? p.pending[env] : p.n_sub;
-  if (n_sub == 0) return;
+  // Two launch shapes, one body.  Direct: one workgroup per environment (grid = n_envs).  Hand-over pass of the packed kernels
+  // (p.pending != null): one workgroup per 64 environments (grid = n_envs / 64) that reads their `pending` counts with one
+  // coalesced load and walks the non-zero ones -- nearly always none, so the pass costs ~4 us instead of the ~22 us of 65 536
+  // workgroups that exit at once (r02 kernel trace), and touches neither state nor scratch.
+  const int env0 = p.pending ? blockIdx.x * 64 : blockIdx.x;
+  int mine = p.n_sub;
+  if (p.pending) mine = (env0 + lane < p.n_envs) ? p.pending[env0 + lane] : 0;
+  unsigned long long todo = p.pending ? __ballot(mine != 0) : (env0 < p.n_envs ? 1ull : 0ull);
+  while (todo) {
+  const int bit = __ffsll((long long)todo) - 1;
+  todo &= todo - 1;
+  const int env = env0 + bit;
+  const int n_sub = p.pending ? __builtin_amdgcn_readlane(mine, bit) : p.n_sub;
   if (p.pending && p.stats && lane == 0) atomicAdd(p.stats + STAT_K1_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
@@ -909,6 +916,8 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   // ---- coalesced state write-back
   store_state(st, sm, lane, qstate_l, time, niter_sum);
   if (MODE == 2 && lane == 0) st[ES_QPWSET] = wset_keep;  // store_state clears the slot; the OSC hot start survives a hand-over
+  lds_sync();
+  }  // while (todo)
 }
 
 // ---------------------------------------------------------------- masked reset (Cassie2dEnv.reset / Cassie2d::Reset)
