@@ -234,7 +234,7 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 
 // ---------------------------------------------------------------- Cassie2d::StepOsc controller: cs.act[7] -> cs.u[6]
 // `wset` (uniform inside a row) carries the QP working set from one call to the next, as qpOASES' hotstart does in the reference
-// (OSC_RBDL.cpp:276-280): bits 0..13 = variable i sits on a bound, bits 14..27 = ... on its lower bound; 0 = cold start (all
+// (OSC_RBDL.cpp:276-280): bits 0..13 = variable i sits on a bound, bits 14..27 = ... on its lower bound, bit 28 = valid; 0 = cold start (all
 // friction-cone generators at 0, motors free).  The QP is strictly convex, so the warm start changes the number of active-set
 // iterations (typically 8 -> 1 or 2), not the solution.
 constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
@@ -372,11 +372,25 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
       if (full && !conv && l == rel) bound = false;
     }
     if (conv) busy = false;
+#ifdef CASSIE_PHASE_TIMING
+    if (it == 59) {  // environments that leave the loop unconverged, bucketed by the size of their last multiplier violation
+      const bool un = busy && l == 0;
+      pc->acc[9] += (unsigned)__popcll(__ballot(un));
+      pc->acc[10] += (unsigned)__popcll(__ballot(un && vmax < 1e-8));
+      pc->acc[11] += (unsigned)__popcll(__ballot(un && vmax >= 1e-8 && vmax < 1e-6));
+      pc->acc[12] += (unsigned)__popcll(__ballot(un && vmax >= 1e-6 && vmax < 1e-4));
+      pc->acc[13] += (unsigned)__popcll(__ballot(un && vmax >= 1e-4 && vmax < 1e-2));
+      pc->acc[14] += (unsigned)__popcll(__ballot(un && vmax >= 1e-2));
+      pc->acc[15] += (unsigned)__popcll(__ballot(un && blocked));
+    }
+#endif
   }
   {
     const unsigned bm = (unsigned)(__ballot(bound && isvar) >> (16 * rowid)) & 0x3FFFu;
     const unsigned am = (unsigned)(__ballot(bound && isvar && atlo) >> (16 * rowid)) & 0x3FFFu;
-    if (rowok) wset = bm | (am << 14);
+    if (rowok) wset = bm | (am << 14) | (1u << 28);  // bit 28: "a working set is stored" -- an EMPTY set (nothing on a bound) is a
+                                                      // perfectly good hot start and must not read as 0 = cold (r02: it did, and
+                                                      // every call with all feet loaded re-freed the 8 generators one by one)
   }
   if (lane < 6) cs.u[lane] = z;
   lds_sync();
