@@ -51,7 +51,7 @@ def spawn_ranks(args):
     """Start one child process per GPU with the torchrun environment; the parent never initialises the GPU."""
     import torch  # device_count() does not initialise the runtime on this image
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("CASSIE_DEVICE_MAP"):
         sys.stderr.write("bench.py: --gpus %d requested but only %d device(s) visible\n" % (args.gpus, have))
         return 2
     s = socket.socket()
@@ -214,7 +214,7 @@ def worker(args):
     if world != max(1, args.gpus):
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE); refusing to report a mislabelled number\n" % (args.gpus, world))
         return 3
-    dev = local_rank if world > 1 else 0
+    dev = R.local_device(local_rank) if world > 1 else 0
     torch.cuda.set_device(dev)
     device = "cuda:%d" % dev
     n_local = args.envs_per_gpu

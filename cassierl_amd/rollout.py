@@ -45,6 +45,16 @@ def random_actions(seed, env_ids, step, low, high, device=None):
     return low + (high - low) * u
 
 
+def local_device(local_rank):
+    """HIP device of a local rank: the rank itself, unless CASSIE_DEVICE_MAP ("0,0,1,...") overrides it (test hook: several ranks
+    on one GPU to exercise the N > 1 launch path on a 1-GPU box)."""
+    m = os.environ.get("CASSIE_DEVICE_MAP", "")
+    if m:
+        ids = [int(x) for x in m.split(",")]
+        return ids[local_rank % len(ids)]
+    return local_rank
+
+
 def init_distributed(backend=None):
     """One process per GPU; rendezvous from the torchrun environment (MASTER_ADDR/PORT, RANK, WORLD_SIZE)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,9 +65,9 @@ def init_distributed(backend=None):
     force = os.environ.get("CASSIE_FORCE_PROCESS_GROUP", "") == "1" and "MASTER_ADDR" in os.environ
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+            backend = os.environ.get("CASSIE_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -68,6 +78,10 @@ def gather_returns(local_returns):
     if not dist.is_initialized():
         return local_returns.clone()
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and local_returns.is_cuda:  # test hook (CASSIE_BACKEND=gloo): stage through the host
+        parts = [torch.empty(local_returns.numel(), dtype=local_returns.dtype) for _ in range(world)]
+        dist.all_gather(parts, local_returns.detach().cpu().contiguous())
+        return torch.cat(parts).to(local_returns.device)
     out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
     dist.all_gather_into_tensor(out, local_returns.contiguous())
     return out
@@ -76,7 +90,7 @@ def gather_returns(local_returns):
 def max_over_ranks(value, device=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

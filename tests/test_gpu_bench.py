@@ -71,6 +71,23 @@ def test_gpus_n_spawns_n_ranks_or_fails_loudly():
         assert rc != 0 and "only 1 device" in err
 
 
+def test_two_ranks_sharing_one_gpu_exercise_the_n_rank_path():
+    """A 1-GPU box cannot host two RCCL ranks (RCCL refuses duplicate devices), but everything else of the N > 1 path can run
+    there: the self-spawning launcher, the rendezvous, global env ids per shard, the gather and the max-over-ranks timing --
+    with both ranks mapped to device 0 and gloo carrying the two collectives (test hooks CASSIE_DEVICE_MAP / CASSIE_BACKEND)."""
+    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo")
+    rc, out, err = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline"], env)
+    assert rc == 0, err[-2000:]
+    line = _line(out)
+    assert line["n_gpus"] == 2 and line["config"]["envs_total"] == 4096 and line["finite"] and "extra" not in line
+    # weak scaling bookkeeping: value counts the envs of BOTH ranks
+    assert abs(line["value"] - 4096 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    # the gathered returns cover both shards: same checksum as one rank stepping all 4096 envs (actions are keyed by global id)
+    rc1, out1, err1 = _run(["--steps", "4", "--warmup", "1", "--envs-per-gpu", "4096", "--no-cpu-baseline", "--no-extra"])
+    assert rc1 == 0, err1[-2000:]
+    assert abs(_line(out1)["returns_checksum"] - line["returns_checksum"]) < 1e-6 * abs(line["returns_checksum"])
+
+
 def test_mismatched_world_size_is_refused():
     env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     rc, out, err = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline", "--no-extra"], env)
