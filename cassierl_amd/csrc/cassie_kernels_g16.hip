@@ -425,7 +425,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   // common configuration (robot on its feet): no active joint limit and at most 4 contacts in every environment of the
   // wave => rows are exactly 4 connect rows + pairs at rows 4,6,8,10: straight-line sweep without per-step branches
   const bool simple = __ballot(go && (nlim != 0 || ncon > 4)) == 0;
-  const bool pair8 = (anyP >> 8) & 1u, pair10 = (anyP >> 10) & 1u;
+  const bool pair4 = (anyP >> 4) & 1u, pair6 = (anyP >> 6) & 1u, pair8 = (anyP >> 8) & 1u, pair10 = (anyP >> 10) & 1u;
   int niter = 0;
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
@@ -433,7 +433,8 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     sS = sweeping & isS; sN = sweeping & isN;
     if (simple) {
       single_step(IC<0>{}); single_step(IC<1>{}); single_step(IC<2>{}); single_step(IC<3>{});
-      pair_step(IC<4>{}); pair_step(IC<6>{});
+      if (pair4) pair_step(IC<4>{});
+      if (pair6) pair_step(IC<6>{});
       if (pair8) pair_step(IC<8>{});
       if (pair10) pair_step(IC<10>{});
     } else {
