@@ -137,7 +137,7 @@ __device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& 
     load_dof_const(dc, c);
     double Mr[NV], bias;
     mass_rows<1>(sm, c, dc, l, Mr, bias, false);
-    gauss_jordan_rows<NV, true>(Mr, l);
+    gauss_jordan_rows_legs<true>(Mr, l);
     if (c.dvalid && c.grp == 0 && rowok) {
       static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
       cs.bias[c.d] = bias + dc.damping * sm.v[c.d];

@@ -104,7 +104,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     load_dof_const(dc, c);
     double bias;
     mass_rows<0>(sm, c, dc, l, Mi, bias, false);
-    gauss_jordan_rows<NV, true>(Mi, l);
+    gauss_jordan_rows_legs<true>(Mi, l);
     if (c.dvalid) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mi[C]; }); }
     double v_d = sm.v[c.d < NV ? c.d : 0];
     double u = ctrl < dc.clo ? dc.clo : (ctrl > dc.chi ? dc.chi : ctrl);
@@ -493,7 +493,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     load_dof_const(dc, c);
     double bias_unused;
     mass_rows<0>(sm, c, dc, l, Mh, bias_unused, true);
-    gauss_jordan_rows<NV, true>(Mh, l);
+    gauss_jordan_rows_legs<true>(Mh, l);
   }
   {
     double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
