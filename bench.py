@@ -279,8 +279,10 @@ def worker(args):
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d parallel Cassie2d envs per GPU (BASELINE north_star target size; configs[1] workload), random-policy "
-                                   "rollout, PD mode, 10 substeps/step, walk env reward/done/auto-reset, reference semantics (flags=0)" % n_local,
+            "config": {"workload": "%d parallel Cassie2d envs per GPU (%s), random-policy rollout, PD mode, 10 substeps/step, walk env "
+                                   "reward/done/auto-reset, reference semantics (flags=0)"
+                                   % (n_local, "BASELINE north_star target size; configs[1] workload" if n_local == ENVS_PER_GPU else
+                                      ("configs[1] as written" if n_local == 4096 else "configs[1] workload at a non-default size")),
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
                        "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms},
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
