@@ -1,5 +1,5 @@
 // cassie3d_kernels.hip -- batched Cassie3d physics (model/cassie3d_stiff.xml) on MI355X: BASELINE.json configs[4],
-// SURVEY.md section 8 row N3.  Included by cassie_cabi.hip after cassie_kernels.hip (shares its small helpers).
+// SURVEY.md section 8 row N3.  Included by tu_3d.hip after cassie_kernels.hip (shares its small helpers).
 //
 // The reference has no Cassie3d class (only the MJCF and vestigial hooks: xml_parser.h:321-323, RobotInterface.h:54,
 // DynamicModel.cpp:250-265); what runs here is the same MuJoCo step the 2-D path restates -- mj_forward (kinematics, CRB mass

@@ -1,5 +1,6 @@
-// cassie_cabi.hip -- host side of libcassie2d.so: the C-ABI of include/cassie2d.h (legacy, batch-of-one)
-// and include/cassie_vec.h (batched) on top of the kernels in cassie_kernels.hip.
+// cassie_cabi.hip -- host side of libcassie2d.so: the C-ABI of include/cassie2d.h (legacy, batch-of-one),
+// include/cassie_vec.h (batched Cassie2d) and include/cassie3d_vec.h (batched Cassie3d) on top of the kernel launchers
+// declared in cassie_launch.h (one translation unit per kernel family, tu_*.hip).
 // There is no CPU code path here: every entry point launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>

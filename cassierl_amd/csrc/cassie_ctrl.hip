@@ -1,4 +1,4 @@
-// cassie_ctrl.hip -- in-loop controllers on the MI355X path (included by cassie_cabi.hip after cassie_kernels.hip).
+// cassie_ctrl.hip -- in-loop controllers on the MI355X path (included by tu_ctrl.hip / tu_ctrl_g16.hip after cassie_kernels.hip).
 //
 //   Cassie2d::StepJacobian        src/Cassie2d/Cassie2d.cpp:119-177   (Jacobian-transpose force controller)
 //   Cassie2d::StepOsc             src/Cassie2d/Cassie2d.cpp:179-209   -> OSC_RBDL::RunPTSC / SolveQP (src/OSC_RBDL.cpp:114-291)
