@@ -487,23 +487,32 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   // than next to M^-1 at the top: its 13 doubles per lane would otherwise be live across the whole constraint solve and push
   // the kernel over 256 VGPRs (r01_c: 356 B/lane of scratch = 32 MB of HBM writes per launch).  The row of M^-1 is re-read
   // from LDS.  rowJ (overlaid by mass_rows' exchange buffers) is dead from here on.
-  double Mh[NV];
+  // qacc = M^-1 g first (its row of M^-1 and partial sums are dead before the second mass pass starts: r02, this ordering is what
+  // keeps the tail of the substep under the 256-register budget), then (M + h B)^-1 g.
   {
+    double a0 = 0.0, a1 = 0.0;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      const double gc = row_bcast<C>(gg);
+      const double mi = sm.minv[(c.dvalid ? c.d : 0) * NV + C];
+      if constexpr (C & 1) a1 += mi * gc; else a0 += mi * gc;
+    });
+    qacc = a0 + a1;
+  }
+  {
+    double Mh[NV];
     DofConst dc;
     load_dof_const(dc, c);
     double bias_unused;
     mass_rows<0>(sm, c, dc, l, Mh, bias_unused, true);
     gauss_jordan_rows_legs<true>(Mh, l);
-  }
-  {
-    double a0 = 0.0, a1 = 0.0, h0 = 0.0, h1 = 0.0;
+    double h0 = 0.0, h1 = 0.0;
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
-      double gc = row_bcast<C>(gg);
-      const double mi = sm.minv[(c.dvalid ? c.d : 0) * NV + C];
-      if constexpr (C & 1) { a1 += mi * gc; h1 += Mh[C] * gc; } else { a0 += mi * gc; h0 += Mh[C] * gc; }
+      const double gc = row_bcast<C>(gg);
+      if constexpr (C & 1) h1 += Mh[C] * gc; else h0 += Mh[C] * gc;
     });
-    qacc = a0 + a1; qacch = h0 + h1;
+    qacch = h0 + h1;
   }
   lds_sync();
   if (c.dvalid && go) {
@@ -529,6 +538,13 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   EnvLds& sm = sm4[g];
   const size_t e = valid ? (size_t)env : 0;
   double* st = p.state + e * ENV_STRIDE;
+  // The output section and the write-back recompute the environment index and the record pointer instead of keeping them
+  // alive across the whole kernel: the allocator spilled exactly these kernel-lifetime values at the prologue (r02: the last
+  // 32 B/lane of scratch, i.e. the last HBM traffic of this kernel that was not algorithmic).
+  auto env_again = [&]() -> size_t {
+    const int ev = (int)blockIdx.x * 4 + (opaque((int)threadIdx.x) >> 4);
+    return ev < p.n_envs ? (size_t)ev : 0;
+  };
   LaneConst c;
   load_lane_const(c, l);  // roles are per 16-lane row
   c.grp = 0; c.dvalid = l < NV;
@@ -578,7 +594,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     double ob = l == 0 ? sm.s18[17] : 0.0;            // obs[16 + l]
     lds_sync();
     if (reset_pass) {
-      if (do_reset) { p.obs[e * 26 + l] = oa; if (l < 10) p.obs[e * 26 + 16 + l] = ob; }  // Cassie2dEnv.reset: 17 op-space values
+      if (do_reset) { const size_t e2 = env_again(); p.obs[e2 * 26 + l] = oa; if (l < 10) p.obs[e2 * 26 + 16 + l] = ob; }  // Cassie2dEnv.reset: 17 op-space values
       break;
     }
     double obs_a = oa, obs_b = ob, reward = 0.0;
@@ -586,7 +602,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     {
       const bool fixq = (p.flags & FLAG_FIX_STALE_QSTATE) != 0;
       const double qv = fixq ? sm.q[l < NV ? l : 0] : sm.qst[l];
-      env_outputs_row(p, l, p.actions ? p.actions + e * p.adim : nullptr, p.adim, sm.tim[0], bodyx, qv, obs_a, obs_b, reward, done);
+      env_outputs_row(p, l, p.actions ? p.actions + env_again() * p.adim : nullptr, p.adim, sm.tim[0], bodyx, qv, obs_a, obs_b, reward, done);
     }
     // failure guard (see env_step_kernel): non-finite / diverged state => forced termination, reset clears every NaN carrier
     const bool badl = l < NV && !(in_range(sm.q[l < NV ? l : 0]) && in_range(sm.v[l < NV ? l : 0]));
@@ -599,29 +615,34 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
         if (l < NU) sm.ctrl[l] = 0.0;
       }
     }
-    if (live && p.terminal_obs) { p.terminal_obs[e * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e * 26 + 16 + l] = obs_b; }
-    if (live) {
-      p.obs[e * 26 + l] = obs_a;
-      if (l < 10) p.obs[e * 26 + 16 + l] = obs_b;
-      if (l == 0) { p.reward[env] = reward; p.done[env] = (uint8_t)done; }
+    {
+      const size_t e2 = env_again();
+      if (live && p.terminal_obs) { p.terminal_obs[e2 * 26 + l] = obs_a; if (l < 10) p.terminal_obs[e2 * 26 + 16 + l] = obs_b; }
+      if (live) {
+        p.obs[e2 * 26 + l] = obs_a;
+        if (l < 10) p.obs[e2 * 26 + 16 + l] = obs_b;
+        if (l == 0) { p.reward[e2] = reward; p.done[e2] = (uint8_t)done; }
+      }
     }
     do_reset = live && done && p.auto_reset;
     if (__ballot(do_reset) == 0) break;
     // Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
     if (do_reset && l < NV) { sm.q[l] = cp_env_qinit[l]; sm.v[l] = 0.0; sm.qst[l] = cp_env_qinit[l]; }
-    if (do_reset && l == 0) { sm.tim[0] = 0.0; st[ES_QPWSET] = 0.0; }  // new episode: cold start of the OSC QP too
+    if (do_reset && l == 0) { sm.tim[0] = 0.0; p.state[env_again() * ENV_STRIDE + ES_QPWSET] = 0.0; }  // new episode: cold start of the OSC QP too
     lds_sync();
     reset_pass = true;
   }
   // ---- state write-back
   if (valid) {
+    const size_t e2 = env_again();
+    double* const st2 = p.state + e2 * ENV_STRIDE;
     if (l < NV) {
-      st[ES_Q + l] = sm.q[l]; st[ES_V + l] = sm.v[l]; st[ES_WS + l] = sm.ws[l];
-      st[ES_KQ + l] = sm.kq2[l]; st[ES_KV + l] = sm.kv2[l]; st[ES_QSTATE + l] = sm.qst[l];
+      st2[ES_Q + l] = sm.q[l]; st2[ES_V + l] = sm.v[l]; st2[ES_WS + l] = sm.ws[l];
+      st2[ES_KQ + l] = sm.kq2[l]; st2[ES_KV + l] = sm.kv2[l]; st2[ES_QSTATE + l] = sm.qst[l];
     }
-    if (l < NU) st[ES_CTRL + l] = sm.ctrl[l];
+    if (l < NU) st2[ES_CTRL + l] = sm.ctrl[l];
     if (l == 0) {
-      st[ES_TIME] = sm.tim[0]; st[ES_NITER] = (double)niter_sum; pending[env] = pend;
+      st2[ES_TIME] = sm.tim[0]; st2[ES_NITER] = (double)niter_sum; pending[e2] = pend;
       if (pend > 0 && p.stats) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
     }
   }
