@@ -25,6 +25,8 @@ for w in $what; do
       timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
       tail -2 "$out/trpo_65536.jsonl" | cut -c1-400 ;;
     pmc)
-      bash profiles/collect_pmc.sh $tag | tail -12 ;;
+      bash profiles/collect_pmc.sh $tag | tail -12
+      # refresh profiles/pmc_traffic.json on the box so that a `bench` listed AFTER `pmc` reports this build's own counters
+      python3 profiles/summarize_pmc.py $tag > /dev/null ;;
   esac
 done
