@@ -48,10 +48,10 @@ __device__ __forceinline__ double rdlane(double x, int l) {
 }
 // broadcast lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
 // (mov_dpp: no "old" operand to materialise -- every lane of a row_newbcast / quad_perm / row_ror has a valid source)
+// One v_mov_b64_dpp: row_newbcast is the DPP control the 64-bit data path supports.  Must be executed by the source lane too
+// (never inside a lane-dependent branch or the lazily evaluated arm of a ?:): a source lane switched off by EXEC yields 0.
 template <int K> __device__ __forceinline__ double row_bcast(double x) {
-  int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + K, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + K, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xF, 0xF, true);
 }
 // exchange with lane^1 (DPP quad_perm [1,0,3,2])
 __device__ __forceinline__ double swap1(double x) {
@@ -377,6 +377,31 @@ __device__ __forceinline__ void gauss_jordan_rows(double (&Mr)[N], int lane) {
 // base dofs 0..2.  Pivoting on the leg dofs FIRST keeps the cross-leg blocks exactly zero (no fill-in before a base pivot), so
 // a leg pivot has nothing to do in the five columns of the other leg: 10 pivots x 5 columns x (2 DPP moves + 1 FMA) less per
 // inversion.  (Any pivot order is stable for an SPD matrix; the order only changes the rounding, at 1e-16.)
+// The column updates Mr[C] -= t * (lane K of Mr[C]) as v_fmac_f64_dpp: the broadcast rides on the multiply-add's DPP source
+// operand (the one FP64 arithmetic instruction with a DPP encoding on gfx950, row_newbcast the one control it takes) -- one
+// instruction per column instead of a DPP move plus an FMA.  The compiler's DPP combiner does not form it, hence the assembly;
+// it cannot see the "VALU write -> DPP read: 2 wait states" hazard across an assembly statement either, so each block opens
+// and closes with its own s_nop 1 (the columns inside a block are independent of each other).
+#define GJ_FMAC(i) "v_fmac_f64_dpp %" #i ", %" #i ", -%[t] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+template <int K> __device__ __forceinline__ void gj_elim7(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double t) {
+  asm("s_nop 1\n\t" GJ_FMAC(0) GJ_FMAC(1) GJ_FMAC(2) GJ_FMAC(3) GJ_FMAC(4) GJ_FMAC(5) GJ_FMAC(6) "s_nop 1"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6) : [t] "v"(t), [k] "n"(K));
+}
+template <int K> __device__ __forceinline__ void gj_elim12(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7,
+                                                           double& a8, double& a9, double& a10, double& a11, double t) {
+  asm("s_nop 1\n\t" GJ_FMAC(0) GJ_FMAC(1) GJ_FMAC(2) GJ_FMAC(3) GJ_FMAC(4) GJ_FMAC(5) GJ_FMAC(6) GJ_FMAC(7) GJ_FMAC(8) GJ_FMAC(9) GJ_FMAC(10) GJ_FMAC(11) "s_nop 1"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11) : [t] "v"(t), [k] "n"(K));
+}
+#undef GJ_FMAC
+// j-th column a pivot on dof K touches: every column but its own and, for a leg pivot, the five of the other leg
+constexpr int gj_col(int K, int j) {
+  int n = 0;
+  for (int C = 0; C < NV; C++) {
+    const bool other_leg = (K >= 3 && K <= 7 && C >= 8) || (K >= 8 && C >= 3 && C <= 7);
+    if (C != K && !other_leg) { if (n == j) return C; n++; }
+  }
+  return -1;
+}
 template <bool FAST = false>
 __device__ __forceinline__ void gauss_jordan_rows_legs(double (&Mr)[NV], int lane) {
   constexpr int ORDER[NV] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 0, 1, 2};
@@ -386,14 +411,11 @@ __device__ __forceinline__ void gauss_jordan_rows_legs(double (&Mr)[NV], int lan
     double inv = FAST ? fast_rcp(piv) : 1.0 / piv;
     bool isk = (lane & 15) == K;
     double t = isk ? 1.0 - inv : Mr[K] * inv;  // pivot row: pk - (1 - inv) pk = pk * inv
-    static_for<0, NV>([&](auto cc) {
-      constexpr int C = decltype(cc)::value;
-      constexpr bool other_leg = (K >= 3 && K <= 7 && C >= 8) || (K >= 8 && C >= 3 && C <= 7);
-      if constexpr (C != K && !other_leg) {
-        double pk = row_bcast<K>(Mr[C]);
-        Mr[C] = __builtin_fma(-t, pk, Mr[C]);
-      }
-    });
+    if constexpr (K >= 3)
+      gj_elim7<K>(Mr[gj_col(K, 0)], Mr[gj_col(K, 1)], Mr[gj_col(K, 2)], Mr[gj_col(K, 3)], Mr[gj_col(K, 4)], Mr[gj_col(K, 5)], Mr[gj_col(K, 6)], t);
+    else
+      gj_elim12<K>(Mr[gj_col(K, 0)], Mr[gj_col(K, 1)], Mr[gj_col(K, 2)], Mr[gj_col(K, 3)], Mr[gj_col(K, 4)], Mr[gj_col(K, 5)], Mr[gj_col(K, 6)],
+                   Mr[gj_col(K, 7)], Mr[gj_col(K, 8)], Mr[gj_col(K, 9)], Mr[gj_col(K, 10)], Mr[gj_col(K, 11)], t);
     Mr[K] = isk ? inv : -t;
   });
 }

@@ -85,6 +85,12 @@ __device__ __forceinline__ void transpose_regs_rows(double& r0, double& r1, doub
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
 // `integrate` (wave-uniform) = false gives mj_forward only (Cassie2d::Reset); it is a run-time flag so that a kernel carries ONE
 // copy of this code (two copies doubled the code size and the register spills around the second one).
+// acc += y * (lane K of x's 16-lane row).  (The fused v_fmac_f64_dpp form used by the Gauss-Jordan was tried here too: 4 % fewer
+// instructions, no time -- a sweep is one dependent chain, not issue-bound.)
+template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double x, double y) {
+#pragma clang fp contract(off)
+  acc = __builtin_fma(row_bcast<K>(x), y, acc);
+}
 template <class SM, bool HF = false>
 __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, int g, double ctrl, bool live, bool integrate, G16Out& out,
                                         const Terrain* terrain = nullptr) {
@@ -363,53 +369,52 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     anyS = (unsigned)((ms | (ms >> 16) | (ms >> 32) | (ms >> 48)) & 0xFFFFull);
     anyP = (unsigned)((mp | (mp >> 16) | (mp >> 32) | (mp >> 48)) & 0xFFFFull);
   }
-  double acc = 0.0;  // cost changes of the rows owned by this lane in the current sweep (summed over the row once per sweep)
-  // Every lane runs the update of ITS OWN row kind on its own (f, residual); only the result of the lane that owns row K is
-  // used at step K (row_bcast<K> / l == K), so the step functions need the lane's own kind, not the kind of row K.
-  const bool isS = (kind == RK_EQ) | (kind == RK_LIM), isLim = kind == RK_LIM, isN = kind == RK_CN;
+  double acc = 0.0;  // cost change of the current sweep, summed over the environment's rows (the same value on all 16 lanes)
+  // Every lane runs the update of ITS OWN row on its own (f, residual); at step K only lane K of a row owns a live result, and
+  // its deltas are zeroed everywhere else (`mine`), so `f += d` needs no further selection and the deltas / the cost change
+  // reach the other lanes by one 64-bit row_newbcast each.
+  const bool isE = kind == RK_EQ, isLim = kind == RK_LIM, isN = kind == RK_CN;
   const double hAdiag = 0.5 * Adiag, hApart = 0.5 * Apart;
-  bool sS = false, sN = false;  // this sweep: my environment still iterates and my row is a single row / a contact normal
-  // The two step functions are inlined at two call sites each (the straight-line sweep and the general sweep below).  Which of
+  bool sE = false, sL = false, sN = false;  // this sweep: my environment still iterates and my row is a connect row / limit / contact normal
+  // The step functions are inlined at two call sites each (the straight-line sweep and the general sweep below).  Which of
   // the two a wavefront runs depends on ALL four of its environments, so their roundings must be identical or an environment's
   // result would depend on its neighbours (measured in r02: 1e-13 after two substeps).  Contraction is therefore off inside
   // them and every fused multiply-add is written out.
-  // one single-row step (connect or joint limit) at row K of every environment
-  auto single_step = [&](auto kk) {
-#pragma clang fp contract(off)
-    constexpr int K = decltype(kk)::value;
-    double cand = __builtin_fma(-res, Ainv, f);
-    cand = isLim ? fmax(cand, 0.0) : cand;
-    double d = cand - f;
-    double chg = d * __builtin_fma(hAdiag, d, res);
-    const bool keep = (chg <= 1e-10) & sS;
-    d = keep ? d : 0.0;
-    acc += (keep & (l == K)) ? chg : 0.0;
-    double Dd = row_bcast<K>(d);
-    f += (l == K) ? d : 0.0;
-    res = __builtin_fma(Ac[K], Dd, res);
-  };
-  // Rows 0..3 are the connect (equality) rows in EVERY environment, so the straight-line sweep uses a reduced form for them: no
-  // clamp, and no cost-increase revert -- for an unclamped row d = -res / A exactly minimises its own quadratic, the change is
-  // -res^2 / (2 A) <= 0 with A = J M^-1 J' + R > 0, so mj_solPGS's `if (change > 1e-10) revert` can never fire there.  Same
-  // values as single_step, four instructions less per row.
+  // Rows 0..3 are the connect (equality) rows in EVERY environment.  Reduced form: no clamp, and no cost-increase revert -- for
+  // an unclamped row d = -res / A exactly minimises its own quadratic, the change is -res^2 / (2 A) <= 0 with
+  // A = J M^-1 J' + R > 0, so mj_solPGS's `if (change > 1e-10) revert` can never fire there.  `force -= res * ARinv` as written
+  // in mj_solPGS (product rounded, then subtracted).
   auto eq_step = [&](auto kk) {
 #pragma clang fp contract(off)
     constexpr int K = decltype(kk)::value;
-    double d = __builtin_fma(-res, Ainv, f) - f;
+    const bool mine = (l == K) & sE;
+    const double d = mine ? -(res * Ainv) : 0.0;
+    const double chg = d * __builtin_fma(hAdiag, d, res);
+    if constexpr (K == 0) acc = row_bcast<K>(chg); else fmac_bcast<K>(acc, chg, 1.0);   // step 0 opens every sweep
+    f += d;
+    fmac_bcast<K>(res, d, Ac[K]);
+  };
+  // one joint-limit row at row K (single rows beyond row 3 are limits)
+  auto single_step = [&](auto kk) {
+#pragma clang fp contract(off)
+    constexpr int K = decltype(kk)::value;
+    const double cand = fmax(__builtin_fma(-res, Ainv, f), 0.0);
+    double d = cand - f;
     double chg = d * __builtin_fma(hAdiag, d, res);
-    d = sS ? d : 0.0;
-    acc += (sS & (l == K)) ? chg : 0.0;
-    double Dd = row_bcast<K>(d);
-    f += (l == K) ? d : 0.0;
-    res = __builtin_fma(Ac[K], Dd, res);
+    const bool keep = (chg <= 1e-10) & (l == K) & sL;
+    d = keep ? d : 0.0;
+    chg = keep ? chg : 0.0;
+    fmac_bcast<K>(acc, chg, 1.0);
+    f += d;
+    fmac_bcast<K>(res, d, Ac[K]);
   };
   // one elliptic contact pair at rows (K, K+1), K even; branch-free so that steps can be scheduled across each other
   auto pair_step = [&](auto kk) {
 #pragma clang fp contract(off)
     constexpr int K = decltype(kk)::value;
-    double rt = swap1(res), ot = swap1(f);
-    double rn = res, on = f;
-    double Ann = Adiag, Att = Apart;
+    const double rt = row_bcast<K + 1>(res), ot = row_bcast<K + 1>(f);   // the tangent row's values (live on lane K)
+    const double rn = res, on = f;
+    const double Ann = Adiag, Att = Apart;
     // normal-only update (taken when the normal force is ~0)
     double fn_n = fmax(__builtin_fma(-rn, Ainv, on), 0.0);
     // ray update
@@ -430,12 +435,14 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     ft = fn >= MINVAL ? ftc : ft;
     double dn = fn - on, dt = ft - ot;
     double chg = __builtin_fma(dn, __builtin_fma(hAdiag, dn, __builtin_fma(Ant, dt, rn)), dt * __builtin_fma(hApart, dt, rt));
-    const bool keep = (chg <= 1e-10) & sN;
+    const bool keep = (chg <= 1e-10) & (l == K) & sN;
     dn = keep ? dn : 0.0; dt = keep ? dt : 0.0;
-    acc += (keep & (l == K)) ? chg : 0.0;
-    double Dn = row_bcast<K>(dn), Dt = row_bcast<K>(dt);
-    f += (l == K) ? dn : ((l == K + 1) ? Dt : 0.0);
-    res = __builtin_fma(Ac[K], Dn, __builtin_fma(Ac[K + 1], Dt, res));
+    chg = keep ? chg : 0.0;
+    fmac_bcast<K>(acc, chg, 1.0);
+    const double Dt = row_bcast<K>(dt);   // evaluated by every lane, BEFORE the selection (a DPP read needs its source lane active)
+    f += (l == K + 1) ? Dt : dn;
+    fmac_bcast<K>(res, dt, Ac[K + 1]);
+    fmac_bcast<K>(res, dn, Ac[K]);
   };
   // common configuration (robot on its feet): no active joint limit and at most 4 contacts in every environment of the
   // wave => rows are exactly 4 connect rows + pairs at rows 4,6,8,10: straight-line sweep without per-step branches
@@ -445,7 +452,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
     acc = 0.0;
-    sS = sweeping & isS; sN = sweeping & isN;
+    sE = sweeping & isE; sL = sweeping & isLim; sN = sweeping & isN;
     if (simple) {
       eq_step(IC<0>{}); eq_step(IC<1>{}); eq_step(IC<2>{}); eq_step(IC<3>{});
       if (pair4) pair_step(IC<4>{});
@@ -461,7 +468,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
         }
       });
     }
-    const double improvement = -row_sum(acc);
+    const double improvement = -acc;
     if (sweeping) {
       niter = iter + 1;
       if (improvement * scale < CP_TOLERANCE) sweeping = false;

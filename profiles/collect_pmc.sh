@@ -2,7 +2,7 @@
 # Hardware counters behind the roofline / issue-rate statements (MI355X box).   usage: bash profiles/collect_pmc.sh <tag>
 # One rocprofv3 run per counter group, --pmc only (no tracing domains); FETCH_SIZE and WRITE_SIZE in separate passes as
 # MI355X_MICROARCH.md prescribes.  Workloads: the bench workload at 65 536 envs (PD), configs[2] (OSC in the loop) at 65 536,
-# configs[4] (Cassie3d) at 16 384.  Raw CSVs land in gpurun_out/<tag>/pmc_*; profiles/summarize_pmc.py condenses them.
+# configs[4] (Cassie3d) at 16 384 (PMC_WORKLOADS / PMC_GROUPS select a subset).  Raw CSVs land in gpurun_out/<tag>/pmc_*; profiles/summarize_pmc.py condenses them.
 set -u
 tag=${1:-r02_x}
 root=$(pwd)
@@ -16,14 +16,18 @@ run() {  # name, counters, program args...
   rocprofv3 --pmc $ctrs --output-format csv -d "$out/pmc_$name" -o pmc -- python3 "$@" > "$out/pmc_$name.log" 2>&1
   echo "$name rc=$? $(find "$out/pmc_$name" -name '*counter_collection.csv' | head -1 | xargs -r wc -l)"
 }
-for wl in pd osc c3; do
+for wl in ${PMC_WORKLOADS:-pd osc c3}; do
   case $wl in
     pd)  prog="$root/tests/prof_step.py 65536 4 PD" ;;
     osc) prog="$root/tests/prof_step.py 65536 4 OSC" ;;
     c3)  prog="$root/tests/bench_cassie3d.py --envs 16384 --steps 4" ;;
   esac
-  run ${wl}_sq1 "$G1" $prog
-  run ${wl}_sq2 "$G2" $prog
-  run ${wl}_fetch "FETCH_SIZE" $prog
-  run ${wl}_write "WRITE_SIZE" $prog
+  for grp in ${PMC_GROUPS:-sq1 sq2 fetch write}; do
+    case $grp in
+      sq1) run ${wl}_sq1 "$G1" $prog ;;
+      sq2) run ${wl}_sq2 "$G2" $prog ;;
+      fetch) run ${wl}_fetch "FETCH_SIZE" $prog ;;
+      write) run ${wl}_write "WRITE_SIZE" $prog ;;
+    esac
+  done
 done
