@@ -85,6 +85,18 @@ __device__ __forceinline__ void transpose_regs_rows(double& r0, double& r1, doub
 // l = lane & 15, g = lane >> 4.  `live` (uniform inside a row) masks environments that must not be touched.
 // `integrate` (wave-uniform) = false gives mj_forward only (Cassie2d::Reset); it is a run-time flag so that a kernel carries ONE
 // copy of this code (two copies doubled the code size and the register spills around the second one).
+// (s0, s1) -= E x for the ten damped dofs 3..12: s -= me[j] * (lane 3+j of x's row), alternating between two accumulators.
+// Assembly for the reason given at gj_elim7 (cassie_kernels.hip); x may have been written by the instruction before, hence
+// the leading s_nop; s0/s1 are consumed by an ordinary add.
+constexpr int IMPLICIT_DAMPING_SWEEPS = 12;
+#define DM_FMAC(acc, j, lane) "v_fmac_f64_dpp %" #acc ", %[x], -%" #j " row_newbcast:" #lane " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void damping_matvec(double& s0, double& s1, double x, const double (&me)[10]) {
+  asm("s_nop 1\n\t" DM_FMAC(0, 2, 3) DM_FMAC(1, 3, 4) DM_FMAC(0, 4, 5) DM_FMAC(1, 5, 6) DM_FMAC(0, 6, 7) DM_FMAC(1, 7, 8) DM_FMAC(0, 8, 9)
+      DM_FMAC(1, 9, 10) DM_FMAC(0, 10, 11) DM_FMAC(1, 11, 12)
+      : "+v"(s0), "+v"(s1)
+      : "v"(me[0]), "v"(me[1]), "v"(me[2]), "v"(me[3]), "v"(me[4]), "v"(me[5]), "v"(me[6]), "v"(me[7]), "v"(me[8]), "v"(me[9]), [x] "v"(x));
+}
+#undef DM_FMAC
 // acc += y * (lane K of x's 16-lane row).  (The fused v_fmac_f64_dpp form used by the Gauss-Jordan was tried here too: 4 % fewer
 // instructions, no time -- a sweep is one dependent chain, not issue-bound.)
 template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double x, double y) {
@@ -490,36 +502,36 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     gg += g0 + g1;
   }
   double qacc = 0.0, qacch = 0.0;
-  // (M + h B)^-1 for the implicit-damping Euler step is built HERE, from a second pass over the (still valid) link sums, rather
-  // than next to M^-1 at the top: its 13 doubles per lane would otherwise be live across the whole constraint solve and push
-  // the kernel over 256 VGPRs (r01_c: 356 B/lane of scratch = 32 MB of HBM writes per launch).  The row of M^-1 is re-read
-  // from LDS.  rowJ (overlaid by mass_rows' exchange buffers) is dead from here on.
-  // qacc = M^-1 g first (its row of M^-1 and partial sums are dead before the second mass pass starts: r02, this ordering is what
-  // keeps the tail of the substep under the 256-register budget), then (M + h B)^-1 g.
+  // qacc = M^-1 g, with this lane's row of M^-1 re-read from LDS (rowJ, overlaid by mass_rows' exchange buffers, is dead here)
+  const int mrow = (c.dvalid ? c.d : 0) * NV;
   {
     double a0 = 0.0, a1 = 0.0;
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
       const double gc = row_bcast<C>(gg);
-      const double mi = sm.minv[(c.dvalid ? c.d : 0) * NV + C];
+      const double mi = sm.minv[mrow + C];
       if constexpr (C & 1) a1 += mi * gc; else a0 += mi * gc;
     });
     qacc = a0 + a1;
   }
+  // Implicit joint damping of mj_Euler: qacch = (M + h B)^-1 g.  Up to r02_f this was a second mass-matrix pass and a second
+  // Gauss-Jordan inversion per substep (~1000 instructions).  With E = M^-1 h B the same vector is (I + E)^-1 qacc, and E is a
+  // contraction whatever the pose: its eigenvalues are those of h B^1/2 M^-1 B^1/2, bounded by h B_d / (armature_d + joint
+  // inertia), 0.0393 for this model (knee spring dofs 6 and 11; tests/test_model_tables.py samples poses through the oracle).
+  // So the fixed-point iteration x <- qacc - E x from x = qacc converges to the solution with error 0.0393^n:
+  // IMPLICIT_DAMPING_SWEEPS = 12 leaves 1e-17, below the rounding of any direct solve.  One iteration = ten v_fmac_f64_dpp
+  // (the base dofs 0..2 are undamped, their columns of E are zero).
   {
-    double Mh[NV];
-    DofConst dc;
-    load_dof_const(dc, c);
-    double bias_unused;
-    mass_rows<0>(sm, c, dc, l, Mh, bias_unused, true);
-    gauss_jordan_rows_legs<true>(Mh, l);
-    double h0 = 0.0, h1 = 0.0;
-    static_for<0, NV>([&](auto cc) {
-      constexpr int C = decltype(cc)::value;
-      const double gc = row_bcast<C>(gg);
-      if constexpr (C & 1) h1 += Mh[C] * gc; else h0 += Mh[C] * gc;
-    });
-    qacch = h0 + h1;
+    double me[10];
+    static_for<0, 10>([&](auto jj) { constexpr int J = decltype(jj)::value; me[J] = sm.minv[mrow + 3 + J] * (H * cp_dof_damping[3 + J]); });
+    double x = qacc;
+#pragma unroll
+    for (int it = 0; it < IMPLICIT_DAMPING_SWEEPS; it++) {
+      double s0 = qacc, s1 = 0.0;
+      damping_matvec(s0, s1, x, me);
+      x = s0 + s1;
+    }
+    qacch = x;
   }
   lds_sync();
   if (c.dvalid && go) {

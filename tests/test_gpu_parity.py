@@ -181,29 +181,39 @@ def test_pd_1000_substeps_shadowing_bound(vec, oracle_mod):
     env.close()
 
 
+TWIN_EPS = 3e-14     # measured per-substep deviation of the HIP path from the oracle (tests/teacher_forced_error.py: max 3.2e-14)
+TWIN_C = 20.0
+
+
 def test_pd_env_streams_agree_until_the_oracle_itself_flips(vec, oracle_mod, traj):
     """Same idea one level up: Cassie2dEnv.step (walk env, PD, robots free to fall, CASSIE_FIX_STALE_QSTATE so the episode is
     not cut at the first step) over 100 Env.steps = 1000 substeps.  Reward and done from the HIP path must follow the
-    oracle env until the oracle's own 1-ulp-perturbed twins stop following it."""
+    oracle env as closely as the oracle's own twins do when their state is disturbed, at every Env.step, by the relative
+    amount the HIP path is measured to differ from the oracle in ONE substep (TWIN_EPS; the HIP path injects that ten times
+    per Env.step, hence a constant of order 10; measured worst ratio 1.6-1.9, TWIN_C = 20)."""
     rng = np.random.default_rng(11)
     n, T = 6, 100
     FIXQ = 2
     acts = rng.uniform(PD_LO, PD_HI, (T, n, 6))
     base = [oracle_mod.OracleEnv("walk", "PD", flags=FIXQ, traj=traj) for _ in range(n)]
-    twins = [[oracle_mod.OracleEnv("walk", "PD", flags=FIXQ, traj=traj) for _ in range(n)] for _ in range(3)]
+    twins = [[oracle_mod.OracleEnv("walk", "PD", flags=FIXQ, traj=traj) for _ in range(n)] for _ in range(4)]
     env = vec(n, kind="walk", control_mode="PD", n_substeps=10, flags=FIXQ, auto_reset=False)
     env.set_trajectory(traj["time"], traj["qpos"])
     obs = env.reset_host()
     for i, e in enumerate(base):
         assert np.abs(e.reset() - obs[i]).max() < 1e-12
-    for k, grp in enumerate(twins):
-        prng = np.random.default_rng(200 + k)
+    prng = np.random.default_rng(200)
+
+    def disturb(e):
+        q, v = e.oracle.state()
+        e.oracle.set_state_raw(q * (1.0 + TWIN_EPS * prng.uniform(-1, 1, 13)), v * (1.0 + TWIN_EPS * prng.uniform(-1, 1, 13)), e.oracle.warmstart())
+
+    for grp in twins:
         for e in grp:
             e.reset()
-            q, v = e.oracle.state()
-            e.oracle.set_state_raw(np.nextafter(q, q + prng.choice([-1.0, 1.0], 13)), v, e.oracle.warmstart())
+            disturb(e)
     Er = np.zeros(n)
-    checked_done = 0
+    checked_done, worst_ratio = 0, 0.0
     for t in range(T):
         o_g, r_g, d_g = env.step_host(acts[t])
         for i in range(n):
@@ -211,10 +221,13 @@ def test_pd_env_streams_agree_until_the_oracle_itself_flips(vec, oracle_mod, tra
             for grp in twins:
                 _, rp, dp = grp[i].step(acts[t, i])
                 Er[i] = max(Er[i], abs(rp - r), 1.0 if dp != d else 0.0)
-            assert abs(r_g[i] - r) <= SHADOW_C * Er[i] + 1e-10, (t, i, r_g[i], r, Er[i])
-            if SHADOW_C * Er[i] < 1e-3:  # the oracle's own perturbations are still far from changing the outcome
+                disturb(grp[i])
+            assert abs(r_g[i] - r) <= TWIN_C * Er[i] + 1e-10, (t, i, r_g[i], r, Er[i])
+            worst_ratio = max(worst_ratio, abs(r_g[i] - r) / (Er[i] + 1e-12))
+            if TWIN_C * Er[i] < 1e-3:  # the oracle's own perturbations are still far from changing the outcome
                 assert bool(d_g[i]) == d, (t, i)
                 checked_done += 1
+    print("pd_env_shadowing worst |r_hip - r| / E = %.2f, done checked %d times" % (worst_ratio, checked_done))
     assert checked_done >= n * 10
     env.close()
 
