@@ -831,8 +831,9 @@ __device__ __forceinline__ void env_outputs_row(const VecParams& p, int l, const
   const double z = row_bcast<0>(obs_a), pitch = row_bcast<1>(obs_a);
   if (p.env_kind == 0) {
     double tmax = p.traj_tmax;
-    int idx = (int)(fmod(time, tmax) / tmax * p.traj_n);
-    const double* rq = p.traj_qpos + (size_t)idx * NV;
+    int idx = (int)(fmod(time, tmax) / tmax * opaque(p.traj_n));   // opaque: keeps the conversion (and `col` below) out of the
+    const double* rq = p.traj_qpos + (size_t)idx * NV;              // registers that live across the whole kernel
+    l = opaque(l);
     if (l >= 1 && l < 10) {
       int k = l - 1;
       int col = k < 5 ? k : (k == 5 ? 6 : (k == 6 ? 8 : (k == 7 ? 9 : 11)));

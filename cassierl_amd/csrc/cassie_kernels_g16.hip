@@ -387,7 +387,11 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   // reach the other lanes by one 64-bit row_newbcast each.
   const bool isE = kind == RK_EQ, isLim = kind == RK_LIM, isN = kind == RK_CN;
   const double hAdiag = 0.5 * Adiag, hApart = 0.5 * Apart;
-  bool sE = false, sL = false, sN = false;  // this sweep: my environment still iterates and my row is a connect row / limit / contact normal
+  // "my environment still iterates" folded into two per-lane constants, so that no step has to test it: a connect row of a
+  // finished environment gets a zero step (AinvE = 0), a limit / contact row never passes the cost test (threshold -inf);
+  // the thresholds are per row kind because single_step and pair_step both run on lane K when the environments of a wave differ.
+  double AinvE = (sweeping & isE) ? Ainv : 0.0;
+  double thrL = (sweeping & isLim) ? 1e-10 : -__builtin_inf(), thrN = (sweeping & isN) ? 1e-10 : -__builtin_inf();
   // The step functions are inlined at two call sites each (the straight-line sweep and the general sweep below).  Which of
   // the two a wavefront runs depends on ALL four of its environments, so their roundings must be identical or an environment's
   // result would depend on its neighbours (measured in r02: 1e-13 after two substeps).  Contraction is therefore off inside
@@ -399,11 +403,10 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   auto eq_step = [&](auto kk) {
 #pragma clang fp contract(off)
     constexpr int K = decltype(kk)::value;
-    const bool mine = (l == K) & sE;
-    const double d = mine ? -(res * Ainv) : 0.0;
+    const double d = -(res * AinvE);                        // live on lane K; the broadcasts below read only that lane
     const double chg = d * __builtin_fma(hAdiag, d, res);
     if constexpr (K == 0) acc = row_bcast<K>(chg); else fmac_bcast<K>(acc, chg, 1.0);   // step 0 opens every sweep
-    f += d;
+    f += (l == K) ? d : 0.0;
     fmac_bcast<K>(res, d, Ac[K]);
   };
   // one joint-limit row at row K (single rows beyond row 3 are limits)
@@ -413,7 +416,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     const double cand = fmax(__builtin_fma(-res, Ainv, f), 0.0);
     double d = cand - f;
     double chg = d * __builtin_fma(hAdiag, d, res);
-    const bool keep = (chg <= 1e-10) & (l == K) & sL;
+    const bool keep = (chg <= thrL) & (l == K);
     d = keep ? d : 0.0;
     chg = keep ? chg : 0.0;
     fmac_bcast<K>(acc, chg, 1.0);
@@ -446,8 +449,9 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     double ftc = on_cone ? __builtin_copysign(mu * fn, x0) : x0;
     ft = fn >= MINVAL ? ftc : ft;
     double dn = fn - on, dt = ft - ot;
-    double chg = __builtin_fma(dn, __builtin_fma(hAdiag, dn, __builtin_fma(Ant, dt, rn)), dt * __builtin_fma(hApart, dt, rt));
-    const bool keep = (chg <= 1e-10) & (l == K) & sN;
+    // 1/2 d'A d + d'res, grouped so that only two operations wait for the tangent step
+    double chg = __builtin_fma(dt, __builtin_fma(hApart, dt, __builtin_fma(Ant, dn, rt)), dn * __builtin_fma(hAdiag, dn, rn));
+    const bool keep = (chg <= thrN) & (l == K);
     dn = keep ? dn : 0.0; dt = keep ? dt : 0.0;
     chg = keep ? chg : 0.0;
     fmac_bcast<K>(acc, chg, 1.0);
@@ -464,7 +468,6 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   for (int iter = 0; iter < CP_ITERATIONS; iter++) {
     if (__ballot(sweeping) == 0) break;
     acc = 0.0;
-    sE = sweeping & isE; sL = sweeping & isLim; sN = sweeping & isN;
     if (simple) {
       eq_step(IC<0>{}); eq_step(IC<1>{}); eq_step(IC<2>{}); eq_step(IC<3>{});
       if (pair4) pair_step(IC<4>{});
@@ -483,7 +486,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     const double improvement = -acc;
     if (sweeping) {
       niter = iter + 1;
-      if (improvement * scale < CP_TOLERANCE) sweeping = false;
+      if (improvement * scale < CP_TOLERANCE) { sweeping = false; AinvE = 0.0; thrL = thrN = -__builtin_inf(); }
     }
   }
   out.niter = niter;
