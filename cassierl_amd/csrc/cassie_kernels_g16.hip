@@ -105,7 +105,7 @@ template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double 
 }
 template <class SM, bool HF = false>
 __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, int g, double ctrl, bool live, bool integrate, G16Out& out,
-                                        const Terrain* terrain = nullptr) {
+                                        const Terrain* terrain = nullptr, PhaseClock* pc = nullptr) {
   // Per-lane model constants are re-read from constant memory in every substep (K$/L1 hits).  Without these barriers the
   // compiler hoists ~50 loop-invariant table loads out of the substep loop and then spills them to scratch, which costs
   // HBM write traffic at every kernel boundary (profiles/r01_c_pmc: 32 MB per launch against 3.7 MB algorithmic).
@@ -114,7 +114,9 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   c.ancmask = opaque(c.ancmask); c.d = opaque(c.d); c.dlink = opaque(c.dlink); c.submask = opaque(c.submask);
   c.rel = opaque(c.rel); c.act = opaque(c.act); c.kL = opaque(c.kL); c.kR = opaque(c.kR);
   // ---- kinematics, mass matrix, both inverses
+  PHASE_MARK(*pc, 0);
   planar_fk<0>(sm, sm.q, sm.v, c, l);
+  PHASE_MARK(*pc, 1);
   double tau, qs;
   {
     double Mi[NV];
@@ -133,6 +135,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   }
   if (c.dvalid) sm.qs[c.d] = qs;
   lds_sync();
+  PHASE_MARK(*pc, 2);
   // ---- which constraints are active: limits on lanes 0..7, collision spheres on lanes 0..15 (+ sphere 16 on lane 0)
   const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
   bool lim_act = false;
@@ -177,6 +180,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
       slot = SLOT_CON + 2 * nth_set_bit(con_mask, j) + odd;
     }
   }
+  PHASE_MARK(*pc, 3);
   double b = 0.0, jar = 0.0, R = 1.0;
   const bool active = kind != RK_SKIP;
 #ifndef CASSIE_MFMA
@@ -316,6 +320,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     });
   }
 #else
+  PHASE_MARK(*pc, 4);
   static_for<0, MAXR>([&](auto kk) {
     constexpr int K = decltype(kk)::value;
     const double* js = sm.rowJ[K];
@@ -330,6 +335,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     Ac[K] = a;
   });
 #endif
+  PHASE_MARK(*pc, 5);
   const double Ainv = 1.0 / Adiag;
   const double Apart = swap1(Adiag);
   // ---- warm start (mj_constraintUpdate) kept only if its dual cost beats zero force
@@ -369,6 +375,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     if (cost > 0) { f = 0.0; res = 0.0; }
   }
   res += b;
+  PHASE_MARK(*pc, 6);
   // ---- PGS sweeps; step K updates row K of every environment of the wave
   const double scale = 1.0 / (CP_MEANINERTIA * NV);
   const double AttInv = 1.0 / Apart;
@@ -489,6 +496,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
       if (improvement * scale < CP_TOLERANCE) { sweeping = false; AinvE = 0.0; thrL = thrN = -__builtin_inf(); }
     }
   }
+  PHASE_MARK(*pc, 7);
   out.niter = niter;
   // ---- g = tau + J' f on the dof lanes, both accelerations, integration
   double gg = tau;
@@ -536,6 +544,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
     }
     qacch = x;
   }
+  PHASE_MARK(*pc, 8);
   lds_sync();
   if (c.dvalid && go) {
     sm.ws[c.d] = qacc;
@@ -567,6 +576,8 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     const int ev = (int)blockIdx.x * 4 + (opaque((int)threadIdx.x) >> 4);
     return ev < p.n_envs ? (size_t)ev : 0;
   };
+  PhaseClock pc;   // profiling builds only (-DCASSIE_PHASE_TIMING, tests/phase_profile.py physics)
+  pc.start();
   LaneConst c;
   load_lane_const(c, l);  // roles are per 16-lane row
   c.grp = 0; c.dvalid = l < NV;
@@ -596,7 +607,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     double cnew;
     if (reset_pass || MODE == 2) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
     else { const double act_l = sm.actl[l]; cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l; }
-    substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf);  // reset pose on the flat floor: 12 active rows
+    substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf, &pc);  // reset pose on the flat floor: 12 active rows
     if (!reset_pass) {
       if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
       if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; }  // setState of this substep
@@ -668,6 +679,8 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       if (pend > 0 && p.stats) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
     }
   }
+  PHASE_MARK(pc, 0);
+  pc.flush(p.phase, (int)threadIdx.x);
 }
 
 }  // namespace g16

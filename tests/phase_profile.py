@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Phase breakdown of the OSC controller-in-the-loop kernel (not a test).  Needs a profiling build of the extension
-(-DCASSIE_PHASE_TIMING) pointed to by CASSIE2D_LIB; prints shader cycles per phase summed over wavefronts."""
+"""Phase breakdown of the OSC controller-in-the-loop kernels, or (third argument "physics") of the packed physics kernel on the
+bench workload (not a test).  Needs a profiling build of the extension (-DCASSIE_PHASE_TIMING on cassie_cabi, tu_g16 and
+tu_ctrl_g16) pointed to by CASSIE2D_LIB; prints shader cycles per phase summed over wavefronts.
+usage: phase_profile.py [n_envs] [scripted|random] [physics]"""
 import ctypes as ct
 import os
 import sys
@@ -15,6 +17,33 @@ from cassierl_amd.vec_env import CassieVecEnv  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 scripted = len(sys.argv) > 2 and sys.argv[2] == "scripted"
+if len(sys.argv) > 3 and sys.argv[3] == "physics":
+    from cassierl_amd.trajectory import default_gait
+    gait = default_gait()
+    for kind, mode in (("walk", "PD"), ("stand", "Torque")):
+        env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+        env.set_trajectory(gait.time, gait.qpos)
+        out = env.alloc()
+        env.reset(out)
+        ids = torch.arange(n, device="cuda")
+        buf = (ct.c_ulonglong * 16)()
+        env.L.CassieVecPhaseCycles.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        for t in range(10):
+            env.step(R.random_actions(1, ids, t, env.action_space.low, env.action_space.high), out)
+        env._chk(env.L.CassieVecPhaseCycles(env.h, buf))   # reads and clears
+        for t in range(20):
+            env.step(R.random_actions(1, ids, 10 + t, env.action_space.low, env.action_space.high), out)
+        env._chk(env.L.CassieVecPhaseCycles(env.h, buf))
+        v = np.array(list(buf), dtype=np.float64)
+        names = ["0 outside the substep (load, glue, integrate, outputs, write-back)", "1 kinematics (FK, sincos)", "2 mass matrix, M^-1 (Gauss-Jordan), smooth accel.",
+                 "3 active limits / contacts, row kinds", "4 constraint rows (J, aref, M^-1 J')", "5 A = J M^-1 J' + R", "6 warm start, initial residual",
+                 "7 PGS sweeps", "8 J'f, qacc, implicit damping"]
+        tot = v[:9].sum()
+        print("%s env, %s mode, %d envs: %.0f cycles per wavefront per Env.step" % (kind, mode, n, tot / (n / 4) / 20))
+        for i, nm in enumerate(names):
+            print("  %-72s %6.2f %%" % (nm, 100 * v[i] / tot))
+        env.close()
+    sys.exit(0)
 env = CassieVecEnv(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
 out = env.alloc()
 env.reset(out)
