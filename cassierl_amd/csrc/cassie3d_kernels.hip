@@ -39,7 +39,7 @@ using cassie::wave_sum;
 template <int MR>
 struct Smem3 {
   double q[22], v[NV], ws[NV], qs[NV];
-  double minv[NV][NV], mhinv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion), (M + h B)^-1
+  double minv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion)
   double rowJ[MR][NV];                 // constraint Jacobian rows
   union {
     struct {
@@ -92,12 +92,14 @@ __device__ __forceinline__ double rdlane_dyn(double x, int l) {  // l wave-unifo
   return __hiloint2double(hi, lo);
 }
 
+constexpr int IMPLICIT_DAMPING_SWEEPS3 = 12;
+
 // In-register Gauss-Jordan inverse of the SPD matrix whose row d lives on lane d < NV (other lanes: zero rows).
 __device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
   static_for<0, NV>([&](auto kk) {
     constexpr int K = decltype(kk)::value;
     double piv = rdlane(Mr[K], K);
-    double inv = 1.0 / piv;
+    double inv = cassie::fast_rcp(piv);
     bool isk = lane == K;
     double t = isk ? 1.0 - inv : Mr[K] * inv;
     static_for<0, NV>([&](auto cc) {
@@ -276,12 +278,6 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
   }
   const double damping = c3_dof_damping[d];
   if (dbg && dvalid) { for (int J = 0; J < NV; J++) dbg[D3_M + d * NV + J] = sm.minv[d][J]; dbg[D3_BIAS + d] = bias; }
-  {
-    double Mh[NV];  // (M + h B)^-1 for the implicit-damping Euler step, parked in LDS until then
-    static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mh[J] = dvalid ? sm.minv[d][J] + (J == d ? H * damping : 0.0) : 0.0; });
-    gauss_jordan20(Mh, lane);
-    if (dvalid) { static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; sm.mhinv[d][J] = Mh[J]; }); }
-  }
   double Mr[NV];
   static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mr[J] = dvalid ? sm.minv[d][J] : 0.0; });
   gauss_jordan20(Mr, lane);
@@ -579,12 +575,36 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     g += dvalid ? sm.rowJ[r][d] * fr : 0.0;
   }
   double qacc = 0.0, qacch = 0.0;
-  static_for<0, NV>([&](auto cc) {
-    constexpr int C = decltype(cc)::value;
-    const double gc = rdlane(g, C);
-    qacc += sm.minv[d][C] * gc;
-    qacch += sm.mhinv[d][C] * gc;
-  });
+  {
+    double a0 = 0.0, a1 = 0.0;
+    static_for<0, NV>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      const double t = sm.minv[d][C] * rdlane(g, C);
+      if constexpr (C & 1) a1 += t; else a0 += t;
+    });
+    qacc = a0 + a1;
+  }
+  // Implicit joint damping of mj_Euler, qacch = (M + h B)^-1 g = (I + E)^-1 qacc with E = M^-1 h B, by the fixed-point iteration
+  // x <- qacc - E x (see the planar kernel, cassie_kernels_g16.hip): the eigenvalues of E are those of h B^1/2 M^-1 B^1/2, at most
+  // 0.0393 for this model too (the knee-spring dofs; tests/test_implicit_damping_bound.py samples poses through the oracle), so
+  // IMPLICIT_DAMPING_SWEEPS3 = 12 sweeps leave 1e-17.  Replaces a second 20 x 20 Gauss-Jordan per substep and its 3.2 KB of LDS.
+  // The six base dofs are undamped: their columns of E are zero.
+  {
+    double me[NV - 6];
+    static_for<6, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; me[C - 6] = sm.minv[d][C] * (H * c3_dof_damping[C]); });
+    double x = qacc;
+#pragma unroll
+    for (int it = 0; it < IMPLICIT_DAMPING_SWEEPS3; it++) {
+      double s0 = qacc, s1 = 0.0;
+      static_for<6, NV>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        const double xc = rdlane(x, C);
+        if constexpr (C & 1) s1 = __builtin_fma(-me[C - 6], xc, s1); else s0 = __builtin_fma(-me[C - 6], xc, s0);
+      });
+      x = s0 + s1;
+    }
+    qacch = x;
+  }
   if (dbg && dvalid) { dbg[D3_QACC + d] = qacc; if (d == 0) dbg[D3_NEFC] = nrows; }
   lds_sync();
   if (dvalid) {

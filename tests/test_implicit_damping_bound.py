@@ -1,4 +1,4 @@
-"""The packed physics kernel solves mj_Euler's implicit-damping system (M + h B) x = g by the fixed-point iteration
+"""The packed physics kernel (and the Cassie3d kernel) solves mj_Euler's implicit-damping system (M + h B) x = g by the fixed-point iteration
 x <- M^-1 g - M^-1 h B x (csrc/cassie_kernels_g16.hip, IMPLICIT_DAMPING_SWEEPS).  That is exact to rounding only if
 E = M^-1 h B is a strong contraction for EVERY pose; this test pins the bound the kernel's comment states, with the oracle's
 mass matrix (oracle/cassie_oracle.c, orc_mass_matrix) over random poses, and the three facts the code relies on."""
@@ -55,3 +55,27 @@ def test_contraction_bound_and_truncation_error():
     assert worst_rho < 0.0395, worst_rho          # DESIGN.md / kernel comment: 0.0393
     assert worst_rho ** n < 1e-16, (worst_rho, n)  # truncation below double rounding
     assert worst_err < 5e-15, worst_err            # what remains is the rounding of the two direct solves being compared
+
+
+def test_cassie3d_contraction_bound():
+    """Same bound for model/cassie3d_stiff.xml (csrc/cassie3d_kernels.hip, IMPLICIT_DAMPING_SWEEPS3): floating base, 20 dofs."""
+    txt = open(os.path.join(ROOT, "cassierl_amd", "csrc", "cassie3d_tables.h")).read()
+    m = re.search(r"c3_dof_damping\[20\] = \{([^}]*)\}", txt)
+    damp = np.array([float(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()])
+    assert (damp[:6] == 0).all()   # the kernel's matvec visits columns 6..19 only
+    src = open(os.path.join(ROOT, "cassierl_amd", "csrc", "cassie3d_kernels.hip")).read()
+    n = int(re.search(r"constexpr int IMPLICIT_DAMPING_SWEEPS3 = (\d+);", src).group(1))
+    o = O.Oracle3D()
+    q0, _ = o.state()
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _ in range(300):
+        q = q0.copy()
+        q[:3] += rng.uniform(-1, 1, 3) * 0.3
+        quat = q[3:7] + rng.normal(size=4) * 0.5
+        q[3:7] = quat / np.linalg.norm(quat)
+        q[7:] += rng.uniform(-1, 1, len(q) - 7)
+        M = np.array(o.mass_matrix(q))
+        worst = max(worst, np.abs(np.linalg.eigvals(np.linalg.solve(M, np.diag(H * damp)))).max())
+    assert worst < 0.0395, worst
+    assert worst ** n < 1e-16, (worst, n)
