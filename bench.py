@@ -39,7 +39,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -241,11 +241,18 @@ def worker(args):
     torch.cuda.synchronize()
     R.barrier()
     torch.cuda.synchronize()
+    # Two HIP events bracket the timed region on the stream its kernels are launched on (use_torch_stream above): GPU time per
+    # Env.step = the dominant kernel + its ~5 us hand-over pass + the three elementwise kernels of the return accumulation
+    # (~10 us).  (Events around every single step would agree with rocprofv3's per-kernel average even more directly, but their
+    # barrier packets cost 0.15 ms per step -- they would change the number being reported.)
+    kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    kev0.record()
     for t in range(args.warmup, total):
         _, rew, dn = env.step(actions[t], out)
         returns += rew
         dones += dn.sum()
+    kev1.record()
     ev0.record()
     all_returns = R.gather_returns(returns)  # the single collective of the rollout batch (RCCL over xGMI)
     ev1.record()
@@ -257,8 +264,7 @@ def worker(args):
     ranks_joined = int(R.max_over_ranks(world, device=device))
     counters = env.counters()
 
-    # kernel-only time of the dominant kernel pair, HIP events on the stream it is launched on
-    kernel_ms = env.time_steps(actions[-1], args.steps, out)
+    kernel_ms = kev0.elapsed_time(kev1) / args.steps
     q, v = env.get_state_host()
     finite = bool(np.isfinite(q).all() and np.isfinite(v).all())
     env.close()

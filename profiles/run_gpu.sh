@@ -19,7 +19,7 @@ for w in $what; do
       tail -c 3000 "$out/bench.json" ;;
     prof)
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
-          python3 "$root/bench.py" --steps 60 --warmup 10 --no-cpu-baseline > "$out/stats_bench.log" 2>&1 )
+          python3 "$root/bench.py" --no-extra --no-cpu-baseline > "$out/stats_bench.log" 2>&1 )
       find "$out/stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     trpo)
       timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
