@@ -164,7 +164,13 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   const unsigned lim_mask = (unsigned)(bl >> (16 * g)) & 0xFFu;
   const unsigned con_mask = ((unsigned)(b0 >> (16 * g)) & 0xFFFFu) | ((((unsigned)(b1 >> (16 * g))) & 1u) << 16);
   const int nlim = __popc(lim_mask), ncon = __popc(con_mask);
-  const int cbase = (4 + nlim + 1) & ~1;  // contact pairs start on an even row
+  // Contact pairs start on an even row behind the limits.  When the environments of a wave differ in their limits, their pairs
+  // would sit on different rows and a sweep would run a pair step for every row ANY of them uses; if all of them fit
+  // "<= 4 limits, <= 4 contacts", the pairs of the whole wave start at row 8 instead (pad rows in between; the row ORDER, hence
+  // the Gauss-Seidel result, is the same).
+  const bool fits8 = !live || (nlim <= 4 && ncon <= 4);
+  const bool align8 = __ballot(!fits8) == 0 && __ballot(live && nlim != 0) != 0;
+  const int cbase = align8 ? 8 : ((4 + nlim + 1) & ~1);
   const int nrows = cbase + 2 * ncon;
   const bool ovf_here = live && nrows > MAXR;
   out.overflow = ovf_here;
