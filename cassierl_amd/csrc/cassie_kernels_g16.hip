@@ -164,13 +164,15 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   const unsigned lim_mask = (unsigned)(bl >> (16 * g)) & 0xFFu;
   const unsigned con_mask = ((unsigned)(b0 >> (16 * g)) & 0xFFFFu) | ((((unsigned)(b1 >> (16 * g))) & 1u) << 16);
   const int nlim = __popc(lim_mask), ncon = __popc(con_mask);
-  // Contact pairs start on an even row behind the limits.  When the environments of a wave differ in their limits, their pairs
-  // would sit on different rows and a sweep would run a pair step for every row ANY of them uses; if all of them fit
-  // "<= 4 limits, <= 4 contacts", the pairs of the whole wave start at row 8 instead (pad rows in between; the row ORDER, hence
-  // the Gauss-Seidel result, is the same).
-  const bool fits8 = !live || (nlim <= 4 && ncon <= 4);
-  const bool align8 = __ballot(!fits8) == 0 && __ballot(live && nlim != 0) != 0;
-  const int cbase = align8 ? 8 : ((4 + nlim + 1) & ~1);
+  // Contact pairs start on an even row behind the limits.  If the environments of a wave had their pairs on different rows, a
+  // sweep would run a pair step for every row ANY of them uses, so pairs are put on row 8 wherever that is possible: an
+  // environment with 1..4 limits and <= 4 contacts always uses row 8 (pad rows behind its limits) -- its layout, and with it the
+  // grouping of its partial sums, depends on nothing but its own state; an environment without limits moves from row 4 to row 8
+  // when a neighbour needs it, which changes no bit of its result (the pad rows add exact zeros to the same partial sums, the
+  // Gauss-Seidel order is the same).  Everything else is compacted.
+  const bool own8 = live && nlim >= 1 && nlim <= 4 && ncon <= 4;
+  const bool shift8 = live && nlim == 0 && ncon <= 4 && __ballot(own8) != 0;
+  const int cbase = (own8 || shift8) ? 8 : ((4 + nlim + 1) & ~1);
   const int nrows = cbase + 2 * ncon;
   const bool ovf_here = live && nrows > MAXR;
   out.overflow = ovf_here;
