@@ -592,14 +592,14 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   // ---- state load (strided inside the 704-byte record; the four records of a wave are adjacent)
   if (l < NV) {
     sm.q[l] = st[ES_Q + l]; sm.v[l] = st[ES_V + l]; sm.ws[l] = st[ES_WS + l];
-    sm.kq2[l] = st[ES_KQ + l]; sm.kv2[l] = st[ES_KV + l];
-    sm.qst[l] = st[ES_QSTATE + l];
+    sm.qst[l] = st[ES_QSTATE + l];   // ES_KQ / ES_KV are not read: the first setState of this step overwrites them (set_state below)
   }
   if (l < NU) sm.ctrl[l] = st[ES_CTRL + l];
   if (l == 0) sm.tim[0] = st[ES_TIME];
   sm.actl[l] = (MODE != 2 && p.actions && c.act >= 0 && c.dvalid) ? p.actions[e * p.adim + c.act] : 0.0;
   lds_sync();
   bool live = valid;
+  bool set_state = false;  // this environment did a setState in this launch: kq2 / kv2 are defined and go back to the record
   int pend = 0, niter_sum = 0;
   sm.ctl[l] = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf, &pc);  // reset pose on the flat floor: 12 active rows
     if (!reset_pass) {
       if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
-      if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; }  // setState of this substep
+      if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; set_state = true; }  // setState of this substep
       sub++;
       if (sub < p.n_sub && __ballot(live) != 0) continue;
       if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = sm.ctl[l];
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
       obs_a = 0.0; obs_b = 0.0; reward = 0.0; done = 1;
       if (l == 0 && p.stats) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
       if (p.auto_reset) {
-        sm.ws[l] = 0.0; sm.kq2[l] = l < NV ? cp_env_qinit[l] : 0.0; sm.kv2[l] = 0.0;
+        sm.ws[l] = 0.0; sm.kq2[l] = l < NV ? cp_env_qinit[l] : 0.0; sm.kv2[l] = 0.0; set_state = true;
         if (l < NU) sm.ctrl[l] = 0.0;
       }
     }
@@ -679,7 +679,8 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     double* const st2 = p.state + e2 * ENV_STRIDE;
     if (l < NV) {
       st2[ES_Q + l] = sm.q[l]; st2[ES_V + l] = sm.v[l]; st2[ES_WS + l] = sm.ws[l];
-      st2[ES_KQ + l] = sm.kq2[l]; st2[ES_KV + l] = sm.kv2[l]; st2[ES_QSTATE + l] = sm.qst[l];
+      if (set_state) { st2[ES_KQ + l] = sm.kq2[l]; st2[ES_KV + l] = sm.kv2[l]; }
+      st2[ES_QSTATE + l] = sm.qst[l];
     }
     if (l < NU) st2[ES_CTRL + l] = sm.ctrl[l];
     if (l == 0) {
