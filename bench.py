@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
+DOMINANT_KERNEL = "cassie::g16::env_step_g16_kernel<0>"  # the kernel one bench step launches (PD mode, flat floor)
+PREROLL_SECONDS = 0.4                # untimed Env.steps before the timed region, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -47,10 +49,25 @@ def parse_args():
 
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU call)
-def spawn_ranks(args):
-    """Start one child process per GPU with the torchrun environment; the parent never initialises the GPU."""
-    import torch  # device_count() does not initialise the runtime on this image
-    have = torch.cuda.device_count()
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT touching torch.cuda / HIP in the launcher parent: the visibility lists if
+    set, otherwise the DRM render nodes of the box (one per GPU)."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        return len([f for f in os.listdir("/dev/dri") if f.startswith("renderD")])
+    except OSError:
+        return 0
+
+
+def spawn_ranks(args, poll_s=0.5, deadline_s=3600.0):
+    """Start one child process per GPU with the torchrun environment; the parent never initialises the GPU.  All children are
+    polled together: the first non-zero exit (or the deadline) ends the run -- the surviving ranks, which would otherwise sit in
+    a collective waiting for the dead one, are killed by their exact PIDs -- and the launcher returns non-zero (128 + signal
+    number for a rank that died from a signal, 124 for the deadline)."""
+    have = visible_gpus()
     if have < args.gpus and not os.environ.get("CASSIE_DEVICE_MAP"):
         sys.stderr.write("bench.py: --gpus %d requested but only %d device(s) visible\n" % (args.gpus, have))
         return 2
@@ -64,44 +81,138 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc, deadline = 0, time.time() + 3600
-    for p in procs:
-        try:
-            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
-        except subprocess.TimeoutExpired:
-            rc = max(rc, 124)
-    for p in procs:  # a rank that died takes the others down with it (exact PIDs only)
+    rc, deadline = 0, time.time() + deadline_s
+    live = list(range(args.gpus))
+    while live and rc == 0:
+        time.sleep(poll_s)
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.remove(r)
+            if code != 0:
+                rc = 128 - code if code < 0 else code
+                sys.stderr.write("bench.py: rank %d exited with %s; stopping the other ranks\n"
+                                 % (r, "signal %d" % -code if code < 0 else "code %d" % code))
+                break
+        if rc == 0 and live and time.time() > deadline:
+            rc = 124
+            sys.stderr.write("bench.py: deadline of %.0f s passed with rank(s) %s still running\n" % (deadline_s, live))
+    for p in procs:  # exact PIDs only
         if p.poll() is None:
             p.kill()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
     return rc
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(traj, cores, budget_s=12.0):
-    """Oracle (C restatement, OpenMP over envs, -O3 -march=native build made on this box) on the host cores of this box,
-    bounded sample of the same workload."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
+    return O
+
+
+def cpu_baseline(traj, cores, budget_s=12.0):
+    """Oracle (C restatement, -O3 -march=native build made on this box) on the host cores of this box, bounded sample of the
+    same workload: (i) ONE thread, (ii) OpenMP over envs.  The visible CPU count of a container can exceed what its quota
+    really schedules, so the OpenMP leg tries cores, cores/2, ... and reports the best, with the threads it used."""
+    O = _oracle()
     from cassierl_amd import rollout as R
     import torch
     fast = O.use_fast_build() if hasattr(O, "use_fast_build") else False
-    n = 16 * cores
-    envs = [O.OracleEnv("walk", "PD", traj=traj) for _ in range(n)]
-    for e in envs:
-        e.reset()
     low, high = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
-    ids = torch.arange(n)
-    steps, t_used = 0, 0.0
-    O.envs_step(envs, R.random_actions(1, ids, 0, low, high).numpy(), 10, True, cores)  # warm-up
-    while t_used < budget_s and steps < 400:
-        a = R.random_actions(1, ids, steps + 1, low, high).numpy()
-        t0 = time.perf_counter()
-        O.envs_step(envs, a, 10, True, cores)
-        t_used += time.perf_counter() - t0
-        steps += 1
-    return dict(value=n * steps / t_used, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs, oracle built %s"
-                       % (n, steps, t_used, "-O3 -march=native" if fast else "-O2"))
+
+    def sample(n, threads, budget):
+        envs = [O.OracleEnv("walk", "PD", traj=traj) for _ in range(n)]
+        for e in envs:
+            e.reset()
+        ids = torch.arange(n)
+        steps, t_used = 0, 0.0
+        O.envs_step(envs, R.random_actions(1, ids, 0, low, high).numpy(), 10, True, threads)  # warm-up
+        while t_used < budget and steps < 400:
+            a = R.random_actions(1, ids, steps + 1, low, high).numpy()
+            t0 = time.perf_counter()
+            O.envs_step(envs, a, 10, True, threads)
+            t_used += time.perf_counter() - t0
+            steps += 1
+        return n * steps / t_used, steps, t_used
+
+    one, s1, t1 = sample(16, 1, 2.0)
+    tries, th = [], cores
+    while th >= 1 and len(tries) < 6:
+        tries.append(th)
+        th //= 2
+    per = max(1.0, (budget_s - 2.0) / len(tries))
+    best = None
+    for th in tries:
+        v, st, tu = sample(16 * th, th, per)
+        if best is None or v > best[0]:
+            best = (v, th, st, tu)
+    return dict(value=best[0], unit="env-steps/s", cores=best[1], kind="port",
+                single_thread=dict(value=one, unit="env-steps/s", cores=1, sample="16 envs x %d Env.steps in %.1f s" % (s1, t1)),
+                cores_visible=cores, threads_tried=tries,
+                sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs on %d threads (best of %s), "
+                       "oracle built %s" % (16 * best[1], best[2], best[3], best[1], tries, "-O3 -march=native" if fast else "-O2"))
+
+
+def cpu_legs_other_configs(budget_s=4.0):
+    """CPU legs beside the other BASELINE configs (oracle, ONE thread, bounded samples):
+    configs[0] squatting.py (Jacobian standing controller, 2 kHz loop, 20 000 substeps = 10 s of robot time -- bounded by time,
+    the substeps actually run are stated), configs[2] OSC standing controller per substep, configs[4] Cassie3d torque mode."""
+    O = _oracle()
+    rows = []
+    qinit = np.array([0, 0.939, 0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407,
+                      0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407])
+
+    def jacobian_force(s, zpos, zvel):  # standing_controller_jacobian, rllab/envs/cassie2d.py:297-331
+        xt = (s[6] + s[12]) / 2.0
+        fx = 200.0 * (xt - s[0]) + 50.0 * (0.0 - s[3])
+        fz = max(0.5 * 9.806 * 31.0 + 200.0 * (zpos - s[1]) + 50.0 * (zvel - s[4]), 0.0)
+        my = 100.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+        return np.array([fx, fz, my, fx, fz, my])
+
+    o = O.Oracle()
+    o.reset(qinit, np.zeros(13))
+    n, t0 = 0, time.perf_counter()
+    while n < 20000 and time.perf_counter() - t0 < 3 * budget_s:
+        t = n * 0.0005
+        s = o.opstate()
+        o.step_jacobian(jacobian_force(s, 0.7 + 0.25 * np.sin(0.5 * 3.1415 * t), 0.25 * np.cos(0.5 * 3.1415 * t)))  # squatting.py:9-16
+        n += 1
+    dt = time.perf_counter() - t0
+    q, _ = o.state()
+    rows.append(dict(workload="configs[0]_squatting_cpu", cores=1, substeps=n, substeps_per_s=n / dt, seconds=dt, pelvis_z=float(q[1]),
+                     note="squatting.py loop on the oracle: scripted Jacobian standing controller + StepJacobian per substep (2 kHz), one thread; "
+                          "%d of the 20 000 substeps of configs[0] run within the time bound" % n))
+    o = O.Oracle()
+    o.reset(qinit, np.zeros(13))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        s = o.opstate()
+        a = np.zeros(7)   # standing_controller_osc(zpos=0.9, zvel=0), rllab/envs/cassie2d.py:263-295
+        a[3] = 100.0 * (-5e-3 - s[7]); a[5] = 100.0 * (-5e-3 - s[13])
+        a[0] = 100.0 * ((s[6] + s[12]) / 2.0 - s[0]) + 20.0 * (0.0 - s[3])
+        a[1] = 100.0 * (0.9 - s[1]) + 20.0 * (0.0 - s[4])
+        a[6] = 20.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+        o.step_osc(a)
+        n += 1
+    dt = time.perf_counter() - t0
+    rows.append(dict(workload="configs[2]_osc_standing_cpu", cores=1, substeps=n, substeps_per_s=n / dt, env_steps_equiv_per_s=n / dt / 10, seconds=dt,
+                     note="OSC QP (literal 39-variable form) + mj_step per substep on the oracle, one thread, one robot"))
+    o3 = O.Oracle3D()
+    rng = np.random.default_rng(5)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        o3.step_torque(rng.uniform(-1, 1, 10) * 4.5)
+        n += 1
+    dt = time.perf_counter() - t0
+    rows.append(dict(workload="configs[4]_cassie3d_cpu", cores=1, substeps=n, substeps_per_s=n / dt, env_steps_per_s=n / dt / 10, seconds=dt,
+                     note="cassie3d_stiff.xml physics on the oracle (-O2 parity build), random torques, one thread, one robot"))
+    return rows
 
 
 # ------------------------------------------------------------------------------------------------ extra workloads (N=1)
@@ -210,6 +321,8 @@ def worker(args):
     from cassierl_amd.trajectory import default_gait
     from cassierl_amd.vec_env import CassieVecEnv
 
+    if os.environ.get("CASSIE_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):  # test hook: this rank dies before the rendezvous
+        return 7
     rank, local_rank, world = R.init_distributed()
     if world != max(1, args.gpus):
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE); refusing to report a mislabelled number\n" % (args.gpus, world))
@@ -235,6 +348,18 @@ def worker(args):
     env.reset(out)
     for t in range(args.warmup):
         env.step(actions[t], out)
+    # Fixed pre-roll, separate from the caller's --warmup: a fresh process on a fresh box ramps its clocks over the first few
+    # hundred milliseconds (r02: the driver's `--warmup 5` left the 20 timed steps 19 % slower than steady state), so Env.steps
+    # of the same workload run for at least PREROLL_SECONDS before the timed region, whatever --warmup says.  Their actions come
+    # from a different stream (seed 9), so the timed steps consume exactly actions[warmup:total] as before.
+    preroll_steps = 0
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREROLL_SECONDS or preroll_steps < 20:
+        for _ in range(10):
+            env.step(R.random_actions(9, ids, preroll_steps, low, high), out)
+            preroll_steps += 1
+        torch.cuda.synchronize()
     R.gather_returns(returns)  # RCCL communicator set-up happens here, outside the timed region
     env.reset_counters()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -274,13 +399,19 @@ def worker(args):
         n_total = n_local * world
         value = n_total * args.steps / elapsed
         achieved_gbps = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
+        # PMC-derived figures (profiles/pmc_traffic.json, written by profiles/summarize_pmc.py from a rocprofv3 --pmc session) are
+        # only reported when they describe THIS source tree (hash of cassierl_amd/csrc) and this batch size; otherwise null.
         pmc = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except Exception:
             pmc = {}
-        traffic = pmc.get("hbm_bytes_per_launch") if pmc.get("envs") == n_local else None
-        valu = pmc.get("valu_flop_per_env_step")  # counted from SQ_INSTS_VALU_* of the same kernel, see profiles/README.md
+        from cassierl_amd.build import source_hash
+        pmc_ok = pmc.get("envs") == n_local and pmc.get("csrc_sha16") == source_hash()
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc_ok else None
+        valu = pmc.get("valu_flop_per_env_step") if pmc_ok else None  # counted from SQ_INSTS_VALU_* of the same kernel, see profiles/README.md
+        useful = pmc.get("useful_flop_per_env_step") if pmc_ok else None
+        dominant = (pmc.get("dominant_kernel") if pmc_ok else None) or DOMINANT_KERNEL
         line = {
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -290,16 +421,22 @@ def worker(args):
                                    % (n_local, "BASELINE north_star target size; configs[1] workload" if n_local == ENVS_PER_GPU else
                                       ("configs[1] as written" if n_local == 4096 else "configs[1] workload at a non-default size")),
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
-                       "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms},
+                       "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms,
+                       "preroll_steps": preroll_steps},
             "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "cassie::g16::env_step_g16_kernel<0> (+ its hand-over passes)", "kernel_ms": kernel_ms,
+                         "kernel": dominant + " (+ its hand-over passes)", "kernel_ms": kernel_ms,
+                         "pmc_source": pmc.get("source") if pmc_ok else None,
                          "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d); see fp64_valu"},
             "fp64_valu": None if not valu else {
                 "achieved_tflops": valu * n_local / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                 "frac": valu * n_local / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                "flop_model": "counted: FP64 VALU instruction counters of the dominant kernel (profiles/pmc_traffic.json)"},
+                "useful_frac": None if not useful else useful * n_local / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "useful_flop_per_env_step": useful,
+                "flop_model": "achieved = ISSUED FP64 lane-flops (VALU instruction counters of the dominant kernel x 64 lanes, "
+                              "profiles/pmc_traffic.json): an upper bound; useful = flops of the same algorithm counted by an "
+                              "op-counting run of the planar specification for this workload's row mix (tests/count_flops.py)"},
             "physics_substeps_per_s": value * 10, "returns_checksum": float(all_returns.sum().item()), "finite": finite,
             "episodes_terminated_per_env_step": float(dones.item()) / (n_local * args.steps),
             "cleanup_frac": counters["cleanup_frac"], "k1_frac": counters["k1_frac"], "nonfinite_resets": counters["nonfinite_resets"],
@@ -316,6 +453,11 @@ def worker(args):
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(traj, cores)
+            if "extra" in line:
+                try:
+                    line["extra"] += cpu_legs_other_configs()
+                except Exception as ex:
+                    line["extra"].append({"error": "cpu legs: " + repr(ex)})
         else:
             line["cpu_baseline"] = None
     if R.dist.is_initialized():

@@ -26,12 +26,37 @@ def _deps():
     return d
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel / C-ABI sources: ties PMC-derived figures (profiles/pmc_traffic.json) and
+    build stamps to the source tree they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _units():
     return [u for u in UNITS if os.path.exists(os.path.join(CSRC, u + ".hip"))]
 
 
+STAMP = os.path.join(OBJDIR, "FLAGS.stamp")
+
+
+def _stamp_matches():
+    """The objects under lib/obj were compiled with exactly the current FLAGS (an A/B or profiling build -- CASSIE_HIPCC_FLAGS --
+    leaves a different stamp, and the next plain build() then recompiles everything instead of mixing objects)."""
+    try:
+        return open(STAMP).read() == " ".join(FLAGS)
+    except OSError:
+        return False
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not _stamp_matches():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(d) > t for d in _deps())
@@ -42,6 +67,18 @@ def build(force=False, verbose=False, only=None):
     if not force and not only and not needs_build():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:  # ranks of one job may call build() at the same time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not only and not needs_build():  # another process built it while this one waited
+            return LIB
+        return _build_locked(force, verbose, only)
+
+
+def _build_locked(force, verbose, only):
+    if not _stamp_matches():
+        force = True   # objects of another flag set: recompile every unit
+        only = None
     newest = max(os.path.getmtime(d) for d in _deps())
 
     def compile_one(u):
@@ -62,6 +99,8 @@ def build(force=False, verbose=False, only=None):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(FLAGS))
     return LIB
 
 

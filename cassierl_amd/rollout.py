@@ -38,6 +38,15 @@ def counter_uniform(seed, env_ids, step, dim, device=None, dtype=torch.float64):
     return mant.to(dtype) * (1.0 / (1 << 53))
 
 
+def counter_normal(seed, env_ids, step, dim, device=None, dtype=torch.float64):
+    """N(0,1) keyed like counter_uniform (Box-Muller on two independent counter streams): the exploration noise of the TRPO
+    sampler, so that a policy rollout -- like the random-action stream -- does not depend on how the envs are sharded."""
+    u1 = counter_uniform(seed, env_ids, 2 * int(step), dim, device=device)
+    u2 = counter_uniform(seed, env_ids, 2 * int(step) + 1, dim, device=device)
+    r = torch.sqrt(-2.0 * torch.log1p(-u1))   # 1 - u1 in (0, 1]
+    return (r * torch.cos(6.283185307179586 * u2)).to(dtype)
+
+
 def random_actions(seed, env_ids, step, low, high, device=None):
     u = counter_uniform(seed, env_ids, step, len(low), device=device)
     low = torch.as_tensor(low, dtype=torch.float64, device=u.device)

@@ -61,10 +61,11 @@ class GaussianMLPPolicy(nn.Module):
         return self.mean_net(obs), self.log_std.expand(obs.shape[0], -1)
 
     @torch.no_grad()
-    def get_actions(self, obs, generator=None):
+    def get_actions(self, obs, generator=None, noise=None):
         mean, log_std = self.dist_info(obs)
-        noise = torch.randn(mean.shape, dtype=mean.dtype, device=mean.device, generator=generator)
-        return mean + noise * log_std.exp(), mean, log_std
+        if noise is None:
+            noise = torch.randn(mean.shape, dtype=mean.dtype, device=mean.device, generator=generator)
+        return mean + noise.to(mean.dtype) * log_std.exp(), mean, log_std
 
     @staticmethod
     def log_likelihood(actions, mean, log_std):
@@ -251,7 +252,7 @@ class AnalyticFisher:
 class TRPO:
     def __init__(self, env_step, env_reset, policy, baseline, n_envs, obs_dim, act_map, batch_size=15000, max_path_length=1000,
                  discount=0.99, step_size=0.005, cg_iters=10, reg_coeff=1e-5, backtrack_ratio=0.8, max_backtracks=15, seed=1,
-                 env_reset_masked=None):
+                 env_reset_masked=None, env_id0=None):
         """env_step(actions[N, adim] float64) -> (obs[N, obs_dim], reward[N], done[N] uint8/bool), auto-resetting;
         env_reset() -> obs; env_reset_masked(mask uint8[N]) -> obs with the masked envs reset (used when a path is truncated
         at max_path_length, where rllab's sampler calls env.reset()).  batch_size counts env-steps over ALL ranks, as
@@ -260,7 +261,11 @@ class TRPO:
         value of the next observation (rllab's batch sampler discards/truncates the tail instead; with 65 536 envs x few steps
         per iteration nearly every path is cut, so dropping the tail would bias every return); the policy runs in float32."""
         self.env_step, self.env_reset, self.env_reset_masked = env_step, env_reset, env_reset_masked
-        self._steps_since_start = 0  # host-side upper bound of path_t: truncation cannot happen before max_path_length steps
+        # Host-side lower bound of the Env.steps left before ANY path can reach max_path_length (path_t <= max_path_length -
+        # _steps_to_trunc holds for every env): while it is positive no truncation mask can be non-empty, so collect() launches no
+        # masked reset at all; when it reaches zero the device-side maximum of path_t re-arms it (one scalar read-back per
+        # max_path_length steps at most -- r02 launched the masked-reset kernel on EVERY step once 1000 steps had elapsed).
+        self._steps_to_trunc = max_path_length
         self.policy, self.baseline, self.act_map = policy, baseline, act_map
         self.n_envs, self.obs_dim = n_envs, obs_dim
         self.horizon = max(1, int(math.ceil(batch_size / (n_envs * _world()))))
@@ -268,9 +273,12 @@ class TRPO:
         self.cg_iters, self.reg_coeff = cg_iters, reg_coeff
         self.backtrack_ratio, self.max_backtracks = backtrack_ratio, max_backtracks
         dev = next(policy.parameters()).device
-        self.gen = torch.Generator(device=dev)
+        # Exploration noise: a counter-based stream keyed by (seed, GLOBAL env id, noise step, action component), like the
+        # random-action stream of rollout.py -- the sampled batch does not depend on the number of ranks the envs are sharded over.
         rank = dist.get_rank() if dist.is_initialized() else 0
-        self.gen.manual_seed(seed * 1000003 + rank)
+        self.seed = seed
+        self.env_ids = torch.arange(n_envs, dtype=torch.int64, device=dev) + (rank * n_envs if env_id0 is None else env_id0)
+        self.noise_step = 0
         self.obs = None
         self.path_t = torch.zeros(n_envs, dtype=torch.int64, device=dev)
         self.path_ret = torch.zeros(n_envs, dtype=torch.float64, device=dev)
@@ -279,6 +287,7 @@ class TRPO:
     # ---- sampling: T vectorised Env.steps, everything stays on the device
     @torch.no_grad()
     def collect(self):
+        from . import rollout as R
         pol_dtype = next(self.policy.parameters()).dtype
         if self.obs is None:
             self.obs = self.env_reset().clone()
@@ -294,7 +303,9 @@ class TRPO:
         ep_sum = torch.zeros((), dtype=torch.float64, device=dev) # device: boolean-mask indexing would synchronise every step
         for t in range(T):
             o = self.obs.to(pol_dtype)
-            a, mean, log_std = self.policy.get_actions(o, self.gen)
+            noise = R.counter_normal(self.seed, self.env_ids, self.noise_step, self.policy.log_std.numel())
+            self.noise_step += 1
+            a, mean, log_std = self.policy.get_actions(o, noise=noise)
             nobs, rew, done = self.env_step(self.act_map(a))
             done = done.bool().clone()
             obs_b[t], act_b[t], mean_b[t], lstd_b[t] = o, a, mean, log_std
@@ -307,10 +318,13 @@ class TRPO:
             ep_sum += torch.where(cut, self.path_ret, torch.zeros_like(self.path_ret)).sum()
             self.path_ret = torch.where(cut, torch.zeros_like(self.path_ret), self.path_ret)
             self.path_t = torch.where(cut, torch.zeros_like(self.path_t), self.path_t)
-            self._steps_since_start += 1
-            if self.env_reset_masked is not None and self._steps_since_start >= self.max_path_length:
-                # path truncated at max_path_length while the env is still alive: rllab resets the env there
-                nobs = self.env_reset_masked((cut & ~done).to(torch.uint8))
+            self._steps_to_trunc -= 1
+            if self.env_reset_masked is not None and self._steps_to_trunc <= 0:
+                # a path may have been truncated at max_path_length while its env is still alive: rllab resets the env there
+                trunc = cut & ~done
+                if bool(trunc.any()):
+                    nobs = self.env_reset_masked(trunc.to(torch.uint8))
+                self._steps_to_trunc = self.max_path_length - int(self.path_t.max())  # re-arm from the oldest live path
             self.obs = nobs.clone()
         return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
                     episode_count=ep_n, episode_return_sum=ep_sum)
@@ -409,30 +423,42 @@ class TRPO:
         return path if r == 0 else "%s.rank%d" % (path, r)
 
     def save(self, path, extra=None):
+        """Tensors and plain Python values only (loaded with weights_only=True), written to `path.tmp` and renamed into place so
+        that a crash during the write never corrupts the one snapshot_mode='last' file."""
+        import os
         env = getattr(self, "env", None)
-        ck = dict(policy=self.policy.state_dict(), baseline=self.baseline.coeffs, itr=self.itr, extra=extra,
-                  gen_state=self.gen.get_state(), obs=None if self.obs is None else self.obs.cpu(),
-                  path_t=self.path_t.cpu(), path_ret=self.path_ret.cpu(), steps_since_start=self._steps_since_start,
+        ck = dict(policy={k: v.detach().cpu() for k, v in self.policy.state_dict().items()},
+                  baseline=None if self.baseline.coeffs is None else self.baseline.coeffs.detach().cpu(), itr=int(self.itr), extra=extra,
+                  noise_step=int(self.noise_step), noise_seed=int(self.seed), obs=None if self.obs is None else self.obs.cpu(),
+                  path_t=self.path_t.cpu(), path_ret=self.path_ret.cpu(), steps_to_trunc=int(self._steps_to_trunc),
                   env_state=None if env is None or not hasattr(env, "get_full_state_host") else torch.from_numpy(env.get_full_state_host()))
-        torch.save(ck, self._rank_path(path))
+        mine = self._rank_path(path)
+        torch.save(ck, mine + ".tmp")
+        os.replace(mine + ".tmp", mine)
 
     def load(self, path, restore_sampler=True):
+        """Returns (extra, sampler_restored): policy / baseline / iteration always come back; the sampler state (env records,
+        noise counter, observation, path clocks) only from this rank's own file with a matching batch shape -- the second value
+        says whether that happened, so a run that merely LOOKS resumed can be told from the interrupted run continued."""
+        import os
         dev = next(self.policy.parameters()).device
         mine = self._rank_path(path)
-        import os
-        ck = torch.load(mine if os.path.exists(mine) else path, map_location="cpu", weights_only=False)
+        ck = torch.load(mine if os.path.exists(mine) else path, map_location="cpu", weights_only=True)
         self.policy.load_state_dict(ck["policy"])
         self.baseline.coeffs = None if ck["baseline"] is None else ck["baseline"].to(dev)
         self.itr = ck["itr"]
         env = getattr(self, "env", None)
+        restored = False
         if restore_sampler and os.path.exists(mine) and ck.get("env_state") is not None and env is not None \
                 and tuple(ck["env_state"].shape) == (self.n_envs, 88):
             env.set_full_state_host(ck["env_state"].numpy())
-            self.gen.set_state(ck["gen_state"])
+            self.noise_step, self.seed = ck["noise_step"], ck.get("noise_seed", self.seed)
             self.obs = None if ck["obs"] is None else ck["obs"].to(dev)
             self.path_t, self.path_ret = ck["path_t"].to(dev), ck["path_ret"].to(dev)
-            self._steps_since_start = ck.get("steps_since_start", 0)
-        return ck.get("extra")
+            self._steps_to_trunc = ck.get("steps_to_trunc", 0)
+            restored = True
+        self.sampler_restored = restored
+        return ck.get("extra"), restored
 
 
 def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajectory=None, seed=1, **kw):

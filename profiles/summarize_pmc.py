@@ -88,7 +88,16 @@ def main():
     with open(os.path.join(HERE, tag + "_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1)
     with open(os.path.join(HERE, "pmc_traffic.json"), "w") as f:
-        json.dump(dict(source="profiles/%s_pmc.json" % tag, envs=65536, hbm_bytes_per_launch=int(pd["hbm_bytes_per_launch"]),
+        sys.path.insert(0, ROOT)
+        from cassierl_amd.build import source_hash
+        useful = None
+        try:  # counted useful flops of the same workload (tests/count_flops.py writes it)
+            useful = json.load(open(os.path.join(HERE, "useful_flops.json")))["pd_bench"]["flop_per_env_step"]
+        except Exception:
+            pass
+        dom = pd["kernels"][0]["kernel"] if pd["kernels"] else None
+        json.dump(dict(source="profiles/%s_pmc.json" % tag, envs=65536, csrc_sha16=source_hash(), dominant_kernel=dom,
+                       useful_flop_per_env_step=useful, hbm_bytes_per_launch=int(pd["hbm_bytes_per_launch"]),
                        algorithmic_bytes_per_launch=ALGO_BYTES_PER_ENV_STEP * 65536,
                        valu_flop_per_env_step=pd["fp64_lane_flops_issued_per_env_step"],
                        note="bench workload at 65 536 envs: packed kernel + its hand-over pass per Env.step.  valu_flop_per_env_step = ISSUED FP64 lane-flops "

@@ -92,3 +92,34 @@ def test_mismatched_world_size_is_refused():
     env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     rc, out, err = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline", "--no-extra"], env)
     assert rc != 0 and "refusing" in err and out.strip() == ""
+
+
+def test_configs3_eight_ranks_of_65536_envs_on_one_gpu():
+    """configs[3] = 8 x 65 536 envs, one rank per GPU.  A 1-GPU box cannot give every rank its own device, but it can run the
+    whole configuration: the self-spawning launcher starts 8 ranks of 65 536 envs each (all mapped to device 0, gloo carrying the
+    collectives -- RCCL refuses duplicate devices), all 8 join, `envs_total` is 524 288, and the gathered returns cover all eight
+    shards: their checksum equals ONE rank stepping the same 524 288 global env ids.  What remains untested afterwards is RCCL
+    with N > 1 alone."""
+    env = dict(CASSIE_DEVICE_MAP="0,0,0,0,0,0,0,0", CASSIE_BACKEND="gloo")
+    rc, out, err = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env, timeout=2400)
+    assert rc == 0, err[-2000:]
+    line = _line(out)
+    assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 65536 and line["config"]["envs_total"] == 524288
+    assert line["finite"] and line["nonfinite_resets"] == 0 and "extra" not in line
+    assert abs(line["value"] - 524288 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    rc1, out1, err1 = _run(["--steps", "3", "--warmup", "1", "--envs-per-gpu", "524288", "--no-cpu-baseline", "--no-extra"], timeout=1200)
+    assert rc1 == 0, err1[-2000:]
+    one = _line(out1)
+    assert one["config"]["envs_total"] == 524288 and one["finite"]
+    assert abs(one["returns_checksum"] - line["returns_checksum"]) < 1e-9 * abs(one["returns_checksum"])
+
+
+def test_launcher_stops_all_ranks_when_one_dies():
+    """a rank that dies must take the run down at once (the survivors would otherwise wait in a collective until a
+    watchdog fires).  Rank 1 is made to exit before the rendezvous; the launcher must return non-zero within seconds."""
+    import time
+    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_FAIL_RANK="1")
+    t0 = time.time()
+    rc, out, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline"], env, timeout=600)
+    assert rc != 0 and "rank 1 exited" in err and time.time() - t0 < 300
+    assert not [l for l in out.strip().splitlines() if l.startswith("{")]

@@ -208,6 +208,43 @@ def test_configs4_16384_cassie3d_properties():
     e3.close()
 
 
+# ------------------------------------------------------------------------------------------------ configs[3], all 524 288 envs on one device
+def test_configs3_524288_envs_single_device_properties(vec, traj):
+    """The size of configs[3] (8 x 65 536) resident on ONE device: 131 072 workgroups of the packed kernel, 369 MB of state
+    records, record offsets beyond 2^31 bytes (size_t indexing), the hand-over pass over 8192 workgroups.  Robots move and fall
+    (stand env, random torques keyed by env id mod 97, auto-reset): replicas spread over the whole grid agree bit for bit, every
+    state stays finite, the counters add up, and the first 4096 envs equal a 4096-env batch stepped on its own."""
+    import torch
+    from cassierl_amd import rollout as R
+    n, T = 524288, 12
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    small = vec(4096, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    out, outs = env.alloc(), small.alloc()
+    env.reset(out); small.reset(outs)
+    ids = torch.arange(n, device="cuda") % 97
+    lo, hi = env.action_space.low * 1.5, env.action_space.high * 1.5
+    ndone = torch.zeros((), dtype=torch.int64, device="cuda")
+    for t in range(T):
+        a = R.random_actions(11, ids, t, lo, hi)
+        o, r, d = env.step(a, out)
+        ndone += d.sum()
+        small.step(a[:4096].contiguous(), outs)
+    env.synchronize()
+    s = env.get_full_state_host()
+    assert s.shape == (n, 88) and np.isfinite(s).all()
+    k = np.arange(n) % 97
+    for j in (0, 13, 96):
+        grp = s[k == j]
+        assert (grp[:, :39] == grp[0, :39]).all(), j
+    assert np.array_equal(s[:4096, :39], small.get_full_state_host()[:, :39])
+    assert np.array_equal(out[0][:4096].cpu().numpy(), outs[0].cpu().numpy())
+    c = env.counters()
+    assert c["substeps"] == n * T * 10 and c["nonfinite_resets"] == 0
+    assert s[:, 1].min() < 0.7   # robots did fall
+    record(test="configs3_524288_single_device", steps=T, episodes=int(ndone), **c)
+    env.close(); small.close()
+
+
 # ------------------------------------------------------------------------------------------------ configs[3], one rank's share
 def test_configs3_one_rank_trpo_iteration_65536_envs():
     """configs[3] is 8 x 65 536 envs under TRPO; this is one rank's share on one GPU: a full TRPO iteration (policy rollout of

@@ -27,19 +27,23 @@ def main():
     ap.add_argument("--snapshot", default="")
     ap.add_argument("--load-policy", default="")
     ap.add_argument("--timing", action="store_true", help="report rollout / update seconds separately (adds synchronisations)")
+    ap.add_argument("--dump-params", default="", help="rank 0 writes the flat policy parameters (.npy) after the last iteration")
     args = ap.parse_args()
     import torch
     from cassierl_amd import rollout as R
     from cassierl_amd.trajectory import default_gait
     from cassierl_amd.trpo import make_cassie_trpo
     rank, local_rank, world = R.init_distributed()
-    torch.cuda.set_device(local_rank if world > 1 else 0)
+    dev = R.local_device(local_rank) if world > 1 else 0   # CASSIE_DEVICE_MAP (test hook): several ranks on one GPU
+    torch.cuda.set_device(dev)
     traj = default_gait()
-    algo = make_cassie_trpo(args.envs_per_gpu, kind=args.kind, control_mode=args.control_mode, device=local_rank if world > 1 else 0,
+    algo = make_cassie_trpo(args.envs_per_gpu, kind=args.kind, control_mode=args.control_mode, device=dev,
                             trajectory=traj, seed=1, batch_size=args.envs_per_gpu * world * args.horizon)
     algo.timing = args.timing
     if args.load_policy:
-        algo.load(args.load_policy)
+        _, restored = algo.load(args.load_policy)
+        if rank == 0:
+            print(json.dumps(dict(loaded=args.load_policy, itr=algo.itr, sampler_restored=restored)))
     for _ in range(args.n_itr):
         t0 = time.perf_counter()
         st = algo.train_iteration()
@@ -50,6 +54,12 @@ def main():
             print(json.dumps(st))
         if args.snapshot:
             algo.save(args.snapshot)  # snapshot_mode="last"
+    if args.dump_params and rank == 0:
+        from cassierl_amd.trpo import flat_params
+        np.save(args.dump_params, flat_params(algo.policy).double().cpu().numpy())
+    if R.dist.is_initialized():
+        R.dist.barrier()
+        R.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
