@@ -536,7 +536,7 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
   // Implicit joint damping of mj_Euler: qacch = (M + h B)^-1 g.  Up to r02_f this was a second mass-matrix pass and a second
   // Gauss-Jordan inversion per substep (~1000 instructions).  With E = M^-1 h B the same vector is (I + E)^-1 qacc, and E is a
   // contraction whatever the pose: its eigenvalues are those of h B^1/2 M^-1 B^1/2, bounded by h B_d / (armature_d + joint
-  // inertia), 0.0393 for this model (knee spring dofs 6 and 11; tests/test_model_tables.py samples poses through the oracle).
+  // inertia), 0.0393 for this model (knee spring dofs 6 and 11; tests/test_implicit_damping_bound.py samples poses through the oracle).
   // So the fixed-point iteration x <- qacc - E x from x = qacc converges to the solution with error 0.0393^n:
   // IMPLICIT_DAMPING_SWEEPS = 12 leaves 1e-17, below the rounding of any direct solve.  One iteration = ten v_fmac_f64_dpp
   // (the base dofs 0..2 are undamped, their columns of E are zero).
