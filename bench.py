@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--cpu-legs-only", action="store_true", help="internal: print the CPU legs of configs[0]/[2]/[4] as JSON (no GPU) and exit")
     return ap.parse_args()
 
 
@@ -454,8 +455,12 @@ def worker(args):
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(traj, cores)
             if "extra" in line:
+                # in a child process: these legs use the oracle's -O2 parity build (the -O3 -march=native timing build bound above
+                # for the headline's CPU leg trips a GCC auto-vectorisation alignment fault in the OSC routine), and the child never
+                # touches the GPU
                 try:
-                    line["extra"] += cpu_legs_other_configs()
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-legs-only"], capture_output=True, text=True, timeout=300)
+                    line["extra"] += json.loads(cp.stdout.strip().splitlines()[-1])
                 except Exception as ex:
                     line["extra"].append({"error": "cpu legs: " + repr(ex)})
         else:
@@ -477,6 +482,9 @@ def worker(args):
 
 def main():
     args = parse_args()
+    if args.cpu_legs_only:
+        print(json.dumps(cpu_legs_other_configs()))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     sys.exit(worker(args))

@@ -237,7 +237,7 @@ def test_configs3_524288_envs_single_device_properties(vec, traj):
         grp = s[k == j]
         assert (grp[:, :39] == grp[0, :39]).all(), j
     assert np.array_equal(s[:4096, :39], small.get_full_state_host()[:, :39])
-    assert np.array_equal(out[0][:4096].cpu().numpy(), outs[0].cpu().numpy())
+    assert np.array_equal(out["obs"][:4096].cpu().numpy(), outs["obs"].cpu().numpy())
     c = env.counters()
     assert c["substeps"] == n * T * 10 and c["nonfinite_resets"] == 0
     assert s[:, 1].min() < 0.7   # robots did fall
