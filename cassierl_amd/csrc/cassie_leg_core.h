@@ -1,0 +1,963 @@
+// cassie_leg_core.h -- Cassie2d Env.step with TWO LANES PER ENVIRONMENT: one lane per leg, 32 environments per wavefront.
+//
+// Why (r02 PMC + phase profile): the 4-environments-per-wave kernel (cassie_kernels_g16.hip) is
+// VALU-issue bound, and in its PGS sweeps -- 60 % of its time -- a Gauss-Seidel step is a scalar computation replicated on the
+// 16 lanes of an environment's DPP row: 4 useful lanes of 64.  Only fewer instructions per environment help.  This file is
+// the structural answer: every phase of the substep is SCALAR-PER-LANE code over ONE LEG of the robot, so a wave instruction
+// does useful work for 64 (environment, leg) pairs; the two lanes of an environment meet only where the mechanism couples
+// its legs -- through the three base dofs (x, z, pitch).
+//
+//   * Mass matrix M = [[B, C_L', C_R'], [C_L, L_L, 0], [C_R, 0, L_R]]: each lane builds and inverts its own 5x5 leg block
+//     (hip, knee, ankle, toe, achilles rod), forms Y = L^-1 C and its share C' L^-1 C of the 3x3 Schur complement
+//     S = B - sum_k C_k' L_k^-1 C_k; the shares meet by one lane-pair exchange, both lanes factor S = F F' and keep G = F^-1.
+//     M^-1 is never formed: x_b = G'G (g_b - sum_k Y_k' g_k), x_k = L_k^-1 g_k - Y_k x_b.
+//   * Constraint rows belong to a leg (connect, joint limits, the leg's collision spheres; the pelvis sphere rides on the left
+//     lane).  With z_i = L^-1 jl_i and u~_i = G (jb_i - C' z_i):  A_ij = jl_i . z_j [same leg] + u~_i . u~_j  (+ R_i on the
+//     diagonal), so a lane keeps only its leg's symmetric block (36 doubles for 8 rows) and three numbers per row; the coupling
+//     to the other leg lives in ONE shared 3-vector a~ = sum_j u~_j f_j, updated by a lane-pair exchange per Gauss-Seidel step.
+//   * PGS runs in MuJoCo's row order (connect L, connect R, limits L, limits R, pelvis + left contacts, right contacts): a step
+//     is executed by both lanes on their own row slot, the owner leg's result is kept.  ~16 wave instructions per
+//     environment-sweep against ~46 in the 16-lanes-per-environment kernel; the setup phases are ~12x shorter.
+//   * Capacity: 8 rows per leg (2 connect + contact pairs from slot 2 upward + joint limits from slot 7 downward).  An
+//     environment that needs more is left untouched from that substep on and handed to the packed 16-row kernel and, behind
+//     it, the wave-per-environment kernel through `pending` (same mechanism as before, one tier more).
+//
+// The arithmetic is the same restatement of mj_step as in cassie_kernels.hip (reference call sites: Cassie2d::Step/StepPd,
+// src/Cassie2d/Cassie2d.cpp:86-117; mj_step of MuJoCo 1.50 configured by model/cassie2d_stiff.xml:5; Cassie2dEnv.step,
+// rllab/envs/cassie2d.py:97-225, cassie_stand2d.py:86-137); what differs is the factorisation (block elimination instead of a
+// 13x13 Gauss-Jordan) and the grouping of sums, i.e. roundings at the 1e-16 level.
+//
+// The code is written against a small "backend" B (per-lane types D/I/M, lane-pair exchange, table gathers, per-lane LDS
+// slots) so that the SAME source is compiled (a) by hipcc with B = the gfx950 backend of cassie_kernels_leg.hip -- the
+// product -- and (b) by g++ with a two-lane emulation (tests/host_emul/) that the CPU test-suite checks against the oracle.
+// (b) is test infrastructure: the library has no CPU path.
+#ifndef CASSIE_LEG_CORE_H_
+#define CASSIE_LEG_CORE_H_
+
+#include "cassie2d_planar.h"
+#include "cassie_vec_layout.h"
+
+#ifndef LEG_FN
+#define LEG_FN __device__ __forceinline__
+#endif
+
+namespace cassie {
+namespace leg {
+
+constexpr int LNV = CP_NV;
+constexpr double LH = CP_TIMESTEP;
+constexpr double LMINVAL = 1e-15;
+constexpr int CAP = 8;  // constraint rows per leg
+enum { K_NONE = 0, K_EQ = 1, K_LIM = 2, K_CN = 3, K_CT = 4 };
+
+template <int I_> struct LI { static constexpr int value = I_; };
+template <int B_, int E_, class F> LEG_FN void lfor(F&& f) {
+  if constexpr (B_ < E_) { f(LI<B_>{}); lfor<B_ + 1, E_>(f); }
+}
+// index of (i, j), i <= j, in the packed upper triangle of a symmetric N x N matrix
+constexpr int symidx(int n, int i, int j) { return i <= j ? i * n - i * (i - 1) / 2 + (j - i) : j * n - j * (j - 1) / 2 + (i - j); }
+
+// What the core reads from the launch parameters (scalars / read-only tables; no per-environment pointers).
+struct EnvCfg {
+  int n_sub, flags, env_kind, auto_reset, adim;
+  bool want_obs;
+  const double* traj_qpos;
+  double traj_tmax;
+  int traj_n;
+};
+
+template <class B> struct Core {
+  typedef typename B::D D;
+  typedef typename B::I I;
+  typedef typename B::M M;
+
+  // ------------------------------------------------------------------------------------------------ per-lane state
+  struct Lane {
+    D qb[3], ql[5], vb[3], vl[5];       // qpos / qvel: base (x, z, pitch) replicated on both lanes, own leg (hip, knee, ankle, toe, rod)
+    D wb[3], wl[5];                     // qacc_warmstart
+    D kqb[3], kql[5], kvb[3], kvl[5];   // state at the last DynamicModel::setState (quirks Q1/Q2)
+    D qst[5];                           // self.qstate of the own leg's joints (quirk Q3); the base entries are never read
+    D ctrl[3];                          // last mj_data->ctrl of the own leg's actuators (hip, knee, toe)
+    D time;
+  };
+  struct Out {
+    D body[5], foot[6], ref[9];         // obs[0..4], obs[5 + 6 leg ..], obs[17..25]
+    D reward;
+    M done, stored;                     // stored: this environment produced outputs (was live at the end of the step)
+    D rbody[5], rfoot[6];               // reset observation (valid where do_reset)
+    M do_reset, bad, set_state;
+    I pend, niter;
+  };
+
+  // kinematics of one leg (+ pelvis): index 0 pelvis, 1 thigh, 2 shin, 3 tarsus, 4 toe, 5 achilles rod
+  struct Kin {
+    D c[6], s[6], w[6], ox[6], oz[6], cx[6], cz[6], fx[6], fz[6], vx[6], vz[6];
+  };
+
+  static LEG_FN D ldc(const double* t, I i) { return B::ldc(t, i); }
+
+  // parent of leg link j (1..5) in the Kin numbering
+  static constexpr int kparent(int j) { return j == 1 ? 0 : (j == 5 ? 1 : j - 1); }
+
+  // ------------------------------------------------------------------------------------------------ planar FK of one leg
+  template <int SEM>
+  static LEG_FN void fk(const D (&qb)[3], const D (&ql)[5], const D (&vb)[3], const D (&vl)[5], I leg, Kin& k) {
+    const I lb = leg * 5 + 1;      // first link of the leg in the model tables
+    const I db = leg * 5 + 3;      // first dof of the leg
+    D th[6];
+    th[0] = cp_link_sigma[0] * (qb[2] - cp_qpos0[2]);
+    k.w[0] = cp_link_sigma[0] * vb[2];
+    lfor<1, 6>([&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      constexpr int P = kparent(J);
+      const D sg = ldc(cp_link_sigma, lb + (J - 1));
+      th[J] = th[P] + sg * (ql[J - 1] - ldc(cp_qpos0, db + (J - 1)));
+      k.w[J] = k.w[P] + sg * vl[J - 1];
+    });
+    lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; B::sincos(th[J], k.s[J], k.c[J]); });
+    k.ox[0] = 0.0; k.oz[0] = 0.0; k.vx[0] = 0.0; k.vz[0] = 0.0;
+    D ax[6], az[6];
+    ax[0] = 0.0; az[0] = CP_GRAVITY;
+    lfor<1, 6>([&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      constexpr int P = kparent(J);
+      const I li = (lb + (J - 1)) * 2 + SEM * (CP_NLINK * 2);
+      const D fx = ldc(&cp_link_off[0][0][0], li), fz = ldc(&cp_link_off[0][0][0], li + 1);
+      const D tx = k.c[P] * fx + k.s[P] * fz, tz = -k.s[P] * fx + k.c[P] * fz;
+      const D pw = k.w[P];
+      k.ox[J] = k.ox[P] + tx; k.oz[J] = k.oz[P] + tz;
+      k.vx[J] = k.vx[P] + pw * tz; k.vz[J] = k.vz[P] - pw * tx;
+      ax[J] = ax[P] - pw * pw * tx; az[J] = az[P] - pw * pw * tz;
+    });
+    lfor<0, 6>([&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      const I l = J == 0 ? I(0) : lb + (J - 1);
+      const I ci = l * 2 + SEM * (CP_NLINK * 2);
+      const D cx0 = ldc(&cp_link_com[0][0][0], ci), cz0 = ldc(&cp_link_com[0][0][0], ci + 1);
+      const D m = ldc(cp_link_mass, l);
+      const D rx = k.c[J] * cx0 + k.s[J] * cz0, rz = -k.s[J] * cx0 + k.c[J] * cz0;
+      k.cx[J] = k.ox[J] + rx; k.cz[J] = k.oz[J] + rz;
+      const D w2 = k.w[J] * k.w[J];
+      k.fx[J] = m * (ax[J] - w2 * rx); k.fz[J] = m * (az[J] - w2 * rz);
+    });
+  }
+
+  // point on Kin link J (relative to the pelvis origin)
+  template <int J> static LEG_FN void link_point(const Kin& k, D dx, D dz, D& px, D& pz) {
+    px = k.ox[J] + k.c[J] * dx + k.s[J] * dz;
+    pz = k.oz[J] - k.s[J] * dx + k.c[J] * dz;
+  }
+
+  // ------------------------------------------------------------------------------------------------ mass matrix blocks, bias
+  // Ls: own 5x5 leg block (packed symmetric, armature included); C[d][b]: coupling of leg dof d with base dof b;
+  // Bb: 3x3 base block (packed symmetric, identical on both lanes); bias: base (identical on both lanes) and leg parts.
+  struct Mass { D Ls[15], C[5][3], Bb[6], biasb[3], biasl[5]; };
+
+  // subtree of leg dof d (0 hip .. 4 rod) as a bit mask over the Kin links 1..5
+  static constexpr int submask(int d) { return d == 0 ? 0b111110 : (d == 1 ? 0b011100 : (d == 2 ? 0b011000 : (d == 3 ? 0b010000 : 0b100000))); }
+  // dof i is an ancestor-or-self of dof j (leg-local indices)
+  static constexpr bool anc(int i, int j) { return i == j || (i == 0) || (i == 1 && (j == 2 || j == 3)) || (i == 2 && j == 3); }
+
+  template <int SEM>
+  static LEG_FN void mass_bias(const Kin& k, I leg, Mass& mm) {
+    const I lb = leg * 5 + 1, db = leg * 5 + 3;
+    D mass[6], inert[6];
+    lfor<0, 6>([&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      const I l = J == 0 ? I(0) : lb + (J - 1);
+      mass[J] = ldc(cp_link_mass, l);
+      inert[J] = ldc(&cp_link_inertia[0][0], l + SEM * CP_NLINK);
+    });
+    D s1x[5], s1z[5], s2[5], sg[5];
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      const D odx = k.ox[Dd + 1], odz = k.oz[Dd + 1];
+      sg[Dd] = ldc(cp_dof_sigma, db + Dd);
+      D a1x = 0.0, a1z = 0.0, a2 = 0.0, bs = 0.0;
+      lfor<1, 6>([&](auto ll) {
+        constexpr int Lk = decltype(ll)::value;
+        if constexpr ((submask(Dd) >> Lk) & 1) {
+          const D rx = k.cx[Lk] - odx, rz = k.cz[Lk] - odz;
+          a1x += mass[Lk] * rx; a1z += mass[Lk] * rz; a2 += mass[Lk] * (rx * rx + rz * rz) + inert[Lk];
+          bs += k.fx[Lk] * rz - k.fz[Lk] * rx;
+        }
+      });
+      s1x[Dd] = a1x; s1z[Dd] = a1z; s2[Dd] = a2;
+      mm.biasl[Dd] = sg[Dd] * bs;
+    });
+    // leg block (sigma_i sigma_j = 1 inside a leg in this model, kept for generality)
+    lfor<0, 5>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      lfor<Ii, 5>([&](auto jj) {
+        constexpr int Jj = decltype(jj)::value;
+        D val = 0.0;
+        if constexpr (anc(Ii, Jj)) {  // deep = Jj
+          val = sg[Ii] * sg[Jj] * (s2[Jj] + (k.ox[Jj + 1] - k.ox[Ii + 1]) * s1x[Jj] + (k.oz[Jj + 1] - k.oz[Ii + 1]) * s1z[Jj]);
+        }
+        if constexpr (Ii == Jj) val += ldc(cp_dof_armature, db + Ii);
+        mm.Ls[symidx(5, Ii, Jj)] = val;
+      });
+    });
+    // coupling with the base: slides (x, z) and pitch (sigma = +1, anchor = pelvis origin)
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      mm.C[Dd][0] = sg[Dd] * s1z[Dd];
+      mm.C[Dd][1] = -(sg[Dd] * s1x[Dd]);
+      mm.C[Dd][2] = cp_dof_sigma[2] * sg[Dd] * (s2[Dd] + k.ox[Dd + 1] * s1x[Dd] + k.oz[Dd + 1] * s1z[Dd]);
+    });
+    // whole-body sums about the pelvis origin: own leg's share, partner's share (exchange), pelvis
+    D lm = 0.0, l1x = 0.0, l1z = 0.0, l2 = 0.0, lfx = 0.0, lfz = 0.0, lt = 0.0;
+    lfor<1, 6>([&](auto ll) {
+      constexpr int Lk = decltype(ll)::value;
+      lm += mass[Lk]; l1x += mass[Lk] * k.cx[Lk]; l1z += mass[Lk] * k.cz[Lk];
+      l2 += mass[Lk] * (k.cx[Lk] * k.cx[Lk] + k.cz[Lk] * k.cz[Lk]) + inert[Lk];
+      lfx += k.fx[Lk]; lfz += k.fz[Lk]; lt += k.fx[Lk] * k.cz[Lk] - k.fz[Lk] * k.cx[Lk];
+    });
+    const D tm = (lm + B::swap(lm)) + mass[0];
+    const D t1x = (l1x + B::swap(l1x)) + mass[0] * k.cx[0], t1z = (l1z + B::swap(l1z)) + mass[0] * k.cz[0];
+    const D t2 = (l2 + B::swap(l2)) + (mass[0] * (k.cx[0] * k.cx[0] + k.cz[0] * k.cz[0]) + inert[0]);
+    mm.Bb[symidx(3, 0, 0)] = tm; mm.Bb[symidx(3, 0, 1)] = 0.0; mm.Bb[symidx(3, 1, 1)] = tm;
+    mm.Bb[symidx(3, 0, 2)] = cp_dof_sigma[2] * t1z; mm.Bb[symidx(3, 1, 2)] = -(cp_dof_sigma[2] * t1x);
+    mm.Bb[symidx(3, 2, 2)] = t2 + cp_dof_armature[2];
+    mm.biasb[0] = (lfx + B::swap(lfx)) + k.fx[0];
+    mm.biasb[1] = (lfz + B::swap(lfz)) + k.fz[0];
+    mm.biasb[2] = cp_dof_sigma[2] * ((lt + B::swap(lt)) + (k.fx[0] * k.cz[0] - k.fz[0] * k.cx[0]));
+  }
+
+  // ------------------------------------------------------------------------------------------------ block factorisation
+  // In-place inverse of a packed symmetric positive definite N x N matrix (symmetric Gauss-Jordan, no pivoting).
+  template <int N> static LEG_FN void sym_inverse(D (&a)[N * (N + 1) / 2]) {
+    lfor<0, N>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      const D p = B::rcp(a[symidx(N, K, K)]);
+      D col[N];
+      lfor<0, N>([&](auto ii) { constexpr int Ii = decltype(ii)::value; col[Ii] = a[symidx(N, Ii, K)]; });
+      lfor<0, N>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        if constexpr (Ii != K) {
+          const D t = col[Ii] * p;
+          lfor<Ii, N>([&](auto jj) {
+            constexpr int Jj = decltype(jj)::value;
+            if constexpr (Jj != K) a[symidx(N, Ii, Jj)] = a[symidx(N, Ii, Jj)] - t * col[Jj];
+          });
+        }
+      });
+      lfor<0, N>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        if constexpr (Ii != K) a[symidx(N, Ii, K)] = -(col[Ii] * p);
+      });
+      a[symidx(N, K, K)] = -p;
+    });
+    // the sweeps leave -A^-1
+    lfor<0, N * (N + 1) / 2>([&](auto ii) { constexpr int Ii = decltype(ii)::value; a[Ii] = -a[Ii]; });
+  }
+
+  struct Fact { D Li[15], Y[5][3], G[6]; };  // L^-1 (packed symmetric), Y = L^-1 C, G = F^-1 lower triangular (row-major packed: 00,10,11,20,21,22)
+
+  static LEG_FN void factor(const Mass& mm, const D (&hdamp)[5], bool with_damping, Fact& fc) {
+    lfor<0, 15>([&](auto ii) { constexpr int Ii = decltype(ii)::value; fc.Li[Ii] = mm.Ls[Ii]; });
+    if (with_damping) lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; fc.Li[symidx(5, Dd, Dd)] = fc.Li[symidx(5, Dd, Dd)] + hdamp[Dd]; });
+    sym_inverse<5>(fc.Li);
+    lfor<0, 5>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        D a = 0.0;
+        lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * mm.C[Jj][Bc]; });
+        fc.Y[Ii][Bc] = a;
+      });
+    });
+    D S[6];
+    lfor<0, 3>([&](auto aa) {
+      constexpr int A_ = decltype(aa)::value;
+      lfor<A_, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        D a = 0.0;
+        lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += mm.C[Jj][A_] * fc.Y[Jj][Bc]; });
+        S[symidx(3, A_, Bc)] = mm.Bb[symidx(3, A_, Bc)] - (a + B::swap(a));   // own + partner: commutative, identical on both lanes
+      });
+    });
+    // Cholesky S = F F' (F lower), G = F^-1
+    const D f00 = B::sqrt(S[symidx(3, 0, 0)]);
+    const D i00 = B::rcp(f00);
+    const D f10 = S[symidx(3, 0, 1)] * i00, f20 = S[symidx(3, 0, 2)] * i00;
+    const D f11 = B::sqrt(S[symidx(3, 1, 1)] - f10 * f10);
+    const D i11 = B::rcp(f11);
+    const D f21 = (S[symidx(3, 1, 2)] - f20 * f10) * i11;
+    const D f22 = B::sqrt(S[symidx(3, 2, 2)] - f20 * f20 - f21 * f21);
+    const D i22 = B::rcp(f22);
+    fc.G[0] = i00;
+    fc.G[1] = -(f10 * i00) * i11; fc.G[2] = i11;
+    fc.G[4] = -(f21 * i11) * i22; fc.G[5] = i22;
+    fc.G[3] = -(f20 * fc.G[0] + f21 * fc.G[1]) * i22;
+  }
+  static LEG_FN void Gmul(const Fact& fc, const D (&u)[3], D (&o)[3]) {
+    o[0] = fc.G[0] * u[0];
+    o[1] = fc.G[1] * u[0] + fc.G[2] * u[1];
+    o[2] = fc.G[3] * u[0] + fc.G[4] * u[1] + fc.G[5] * u[2];
+  }
+  static LEG_FN void GTmul(const Fact& fc, const D (&t)[3], D (&o)[3]) {
+    o[0] = fc.G[0] * t[0] + fc.G[1] * t[1] + fc.G[3] * t[2];
+    o[1] = fc.G[2] * t[1] + fc.G[4] * t[2];
+    o[2] = fc.G[5] * t[2];
+  }
+  // x = M^-1 g for g = (gb identical on both lanes, gl own leg)
+  static LEG_FN void minv_apply(const Fact& fc, const D (&gb)[3], const D (&gl)[5], D (&xb)[3], D (&xl)[5]) {
+    D t[3];
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      D a = 0.0;
+      lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Y[Jj][Bc] * gl[Jj]; });
+      t[Bc] = gb[Bc] - (a + B::swap(a));
+    });
+    D gt[3];
+    Gmul(fc, t, gt);
+    GTmul(fc, gt, xb);
+    lfor<0, 5>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      D a = 0.0;
+      lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * gl[Jj]; });
+      xl[Ii] = a - (fc.Y[Ii][0] * xb[0] + fc.Y[Ii][1] * xb[1] + fc.Y[Ii][2] * xb[2]);
+    });
+  }
+
+  static LEG_FN D impedance(D d0, D d1, D width, D x) {
+    const M flat = (d0 == d1) | (width <= LMINVAL);
+    D xx = B::fabs(x / width);
+    D y = B::sel(xx <= 0.5, 2.0 * xx * xx, 1.0 - 2.0 * (1.0 - xx) * (1.0 - xx));
+    D r = d0 + y * (d1 - d0);
+    r = B::sel(xx >= 1.0, d1, r);
+    r = B::sel(xx <= 0.0, d0, r);
+    return B::sel(flat, 0.5 * (d0 + d1), r);
+  }
+
+  // ------------------------------------------------------------------------------------------------ one mj_forward (+ Euler)
+  struct SubOut { I niter; M overflow; };
+
+  // `live` masks environments that must not be touched (identical on the two lanes of an environment); `integrate` is
+  // wave-uniform (false: mj_forward only, Cassie2d::Reset).  cu: pre-clamp command of the own leg's three actuators.
+  static LEG_FN void substep(typename B::Lds& lds, Lane& st, const D (&cu)[3], M live, bool integrate, SubOut& out) {
+    const I leg = B::leg();
+    const I db = leg * 5 + 3;
+    Kin k;
+    fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+    Mass mm;
+    mass_bias<0>(k, leg, mm);
+    // smooth force: passive damping, bias, actuation (ctrl clamped to ctrlrange, times gear); actuators on hip (0), knee (1), toe (3)
+    D taub[3], taul[5], hdamp[5];
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      const D damp = ldc(cp_dof_damping, db + Dd);
+      hdamp[Dd] = LH * damp;
+      D t = -damp * st.vl[Dd] - mm.biasl[Dd];
+      if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
+        constexpr int A_ = Dd == 3 ? 2 : Dd;
+        const I ai = leg * 3 + A_;
+        const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
+        const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
+        t = t + ldc(cp_act_gear, ai) * u;
+      }
+      taul[Dd] = t;
+    });
+    Fact fc;
+    factor(mm, hdamp, false, fc);
+    D qsb[3], qsl[5];
+    minv_apply(fc, taub, taul, qsb, qsl);
+
+    // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
+    const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+    I nlim = 0, ncon = 0;
+    M ovf = (live & !live);  // false
+    lfor<0, 4>([&](auto jj) {
+      constexpr int Jj = decltype(jj)::value;
+      const D qd = st.ql[Jj];
+      const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
+      const D dlo = qd - lo, dhi = hi - qd;
+      const M act = (dlo < 0.0) | (dhi < 0.0);
+      const D pos = B::sel(dlo < 0.0, dlo, dhi);
+      const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
+      lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
+      nlim = nlim + B::toI(act);
+    });
+    lfor<0, 9>([&](auto cc) {
+      constexpr int Cc = decltype(cc)::value;
+      constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
+      const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
+      D cx, cz;
+      link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
+      const D dist = basez + cz - ldc(cp_sph_r, sph);
+      M act = dist < 0.0;
+      if constexpr (Cc == 0) act = act & (leg == 0);
+      // contact point: half-way into the penetration, on the vertical through the sphere centre
+      lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
+      ncon = ncon + B::toI(act);
+    });
+    const I nrows = nlim + ncon * 2 + 2;
+    ovf = live & (nrows > CAP);
+    ovf = ovf | B::swapm(ovf);
+    out.overflow = ovf;
+    const M go = live & !ovf;
+
+    // ---- constraint rows of the own leg: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
+    D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP];
+    D Ant[3], AttInv[3];
+    I kind[CAP];
+    {
+      D jl[CAP][5], jb[CAP][3], z[CAP][5];
+      D bvec[CAP], jar[CAP], Rr[CAP];
+      lfor<0, CAP>([&](auto ss) {
+        constexpr int S = decltype(ss)::value;
+        D pos = 0.0, invw = 0.0;
+        I kd = K_NONE;
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = 0.0; });
+        jb[S][0] = 0.0; jb[S][1] = 0.0; jb[S][2] = 0.0;
+        if constexpr (S < 2) {
+          // connect: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3); row = component S of p1 - p2
+          const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
+          D p1x, p1z, p2x, p2z;
+          link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
+          link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
+          kd = K_EQ;
+          invw = ldc(cp_eq_invweight, leg);
+          pos = S == 0 ? p1x - p2x : p1z - p2z;
+          // J = J(p1 on rod: pitch, hip, rod) - J(p2 on tarsus: pitch, hip, knee, ankle); the base slides cancel
+          auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - k.oz[Jl] : -(px - k.ox[Jl]); };  // y^ x (p - o), component S
+          jb[S][2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
+          const D sg0 = ldc(cp_dof_sigma, db + 0), sg1 = ldc(cp_dof_sigma, db + 1), sg2 = ldc(cp_dof_sigma, db + 2), sg4 = ldc(cp_dof_sigma, db + 4);
+          jl[S][0] = sg0 * ent(p1x, p1z, LI<1>{}) - sg0 * ent(p2x, p2z, LI<1>{});
+          jl[S][1] = -(sg1 * ent(p2x, p2z, LI<2>{}));
+          jl[S][2] = -(sg2 * ent(p2x, p2z, LI<3>{}));
+          jl[S][4] = sg4 * ent(p1x, p1z, LI<5>{});
+        } else {
+          constexpr int P = (S - 2) >> 1;     // contact pair that may live here
+          constexpr int ODD = (S - 2) & 1;    // 0 normal (z row), 1 tangent (x row)
+          constexpr int LJ = 7 - S;           // limit index that may live here
+          const M isc = ncon > P;
+          const M isl = nlim > LJ;
+          kd = B::seli(isc, I(ODD ? K_CT : K_CN), B::seli(isl, I(K_LIM), I(K_NONE)));
+          // contact
+          D px, pz, dist, cinvw; I depth;
+          lds.ld_pair(P, px, pz, dist, cinvw, depth);
+          D cjl[4];
+          lfor<0, 4>([&](auto dd) {
+            constexpr int Dd = decltype(dd)::value;
+            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - k.oz[Dd + 1] : -(px - k.ox[Dd + 1]));
+            cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
+          });
+          const D cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
+          // limit
+          D lpos = 0.0, lsgn = 0.0, linvw = 0.0; I lj = 0;
+          if constexpr (LJ < 4) lds.ld_lim(LJ, lpos, lsgn, linvw, lj);
+          lfor<0, 4>([&](auto dd) {
+            constexpr int Dd = decltype(dd)::value;
+            jl[S][Dd] = B::sel(isc, cjl[Dd], B::sel(isl & (lj == Dd), lsgn, D(0.0)));
+          });
+          jb[S][0] = B::sel(isc, D(ODD ? 1.0 : 0.0), D(0.0));
+          jb[S][1] = B::sel(isc, D(ODD ? 0.0 : 1.0), D(0.0));
+          jb[S][2] = B::sel(isc, cj2, D(0.0));
+          pos = B::sel(isc, dist, lpos);
+          invw = B::sel(isc, cinvw, linvw);
+        }
+        kd = B::seli(go, kd, I(K_NONE));
+        kind[S] = kd;
+        const M active = kd != K_NONE;
+        const M iseq = kd == K_EQ, islim = kd == K_LIM;
+        // solver parameters of the row's kind
+        const D solref0 = B::sel(iseq, ldc(&cp_eq_solref[0][0], leg * 2), B::sel(islim, D(cp_limit_solref[0]), D(cp_contact_solref[0])));
+        const D solref1 = B::sel(iseq, ldc(&cp_eq_solref[0][0], leg * 2 + 1), B::sel(islim, D(cp_limit_solref[1]), D(cp_contact_solref[1])));
+        const D simp0 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3), B::sel(islim, D(cp_limit_solimp[0]), D(cp_contact_solimp[0])));
+        const D simp1 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 1), B::sel(islim, D(cp_limit_solimp[1]), D(cp_contact_solimp[1])));
+        const D simp2 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 2), B::sel(islim, D(cp_limit_solimp[2]), D(cp_contact_solimp[2])));
+        D vel = jb[S][0] * st.vb[0] + jb[S][1] * st.vb[1] + jb[S][2] * st.vb[2];
+        D bq = jb[S][0] * qsb[0] + jb[S][1] * qsb[1] + jb[S][2] * qsb[2];
+        D jw = jb[S][0] * st.wb[0] + jb[S][1] * st.wb[1] + jb[S][2] * st.wb[2];
+        lfor<0, 5>([&](auto dd) {
+          constexpr int Dd = decltype(dd)::value;
+          vel += jl[S][Dd] * st.vl[Dd]; bq += jl[S][Dd] * qsl[Dd]; jw += jl[S][Dd] * st.wl[Dd];
+        });
+        const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
+        const D kk_ = 1.0 / (simp1 * simp1 * tc * tc * solref1 * solref1), bb_ = 2.0 / (simp1 * tc);
+        const D imp = impedance(simp0, simp1, simp2, pos);
+        D R = (1.0 - imp) / imp * invw;
+        R = B::sel(R > LMINVAL, R, D(LMINVAL));
+        const M ist = kd == K_CT;
+        const D own_pos = B::sel(ist, D(0.0), pos);
+        const D imp_own = B::sel(ist, impedance(simp0, simp1, simp2, D(0.0)), imp);
+        const D aref = -bb_ * vel - kk_ * imp_own * own_pos;
+        bvec[S] = B::sel(active, bq - aref, D(0.0));
+        jar[S] = jw - aref;
+        Rr[S] = B::sel(active, R, D(1.0));
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = B::sel(active, jl[S][Dd], D(0.0)); });
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[S][Bc] = B::sel(active, jb[S][Bc], D(0.0)); });
+        // z = L^-1 jl, u = jb - C' z, u~ = G u
+        lfor<0, 5>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
+          D a = 0.0;
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * jl[S][Jj]; });
+          z[S][Ii] = a;
+        });
+        D u[3];
+        lfor<0, 3>([&](auto bb) {
+          constexpr int Bc = decltype(bb)::value;
+          D a = 0.0;
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += mm.C[Jj][Bc] * z[S][Jj]; });
+          u[Bc] = jb[S][Bc] - a;
+        });
+        Gmul(fc, u, ut[S]);
+      });
+      // own-leg block of A (R on the diagonal) and the full diagonal
+      lfor<0, CAP>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        lfor<Ii, CAP>([&](auto jj) {
+          constexpr int Jj = decltype(jj)::value;
+          D a = 0.0;
+          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; a += jl[Ii][Dd] * z[Jj][Dd]; });
+          if constexpr (Ii == Jj) a += Rr[Ii];
+          Al[symidx(CAP, Ii, Jj)] = a;
+        });
+        Adiag[Ii] = Al[symidx(CAP, Ii, Ii)] + (ut[Ii][0] * ut[Ii][0] + ut[Ii][1] * ut[Ii][1] + ut[Ii][2] * ut[Ii][2]);
+        Ainv[Ii] = 1.0 / Adiag[Ii];
+      });
+      lfor<0, 3>([&](auto pp) {
+        constexpr int P = decltype(pp)::value;
+        constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+        Ant[P] = Al[symidx(CAP, N, T)] + (ut[N][0] * ut[T][0] + ut[N][1] * ut[T][1] + ut[N][2] * ut[T][2]);
+        AttInv[P] = 1.0 / Adiag[T];
+      });
+      // ---- warm start (mj_constraintUpdate from qacc_warmstart), kept only if its dual cost beats zero force
+      const D mu = CP_CONTACT_MU;
+      lfor<0, CAP>([&](auto ss) {
+        constexpr int S = decltype(ss)::value;
+        const D Dd_ = 1.0 / Rr[S];
+        D fv = 0.0;
+        fv = B::sel(kind[S] == K_EQ, -Dd_ * jar[S], fv);
+        fv = B::sel((kind[S] == K_LIM) & (jar[S] < 0.0), -Dd_ * jar[S], fv);
+        if constexpr (S >= 2) {
+          constexpr int ODD = (S - 2) & 1;
+          constexpr int NS = S - ODD, TS = NS + 1;
+          const D jn = jar[NS], jt = jar[TS];
+          const D Nn = jn * mu, U1 = jt * mu, Tt = B::fabs(U1);
+          const M top = (Nn >= mu * Tt) | ((Tt <= 0.0) & (Nn >= 0.0));
+          const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
+          const D Dm = Dd_ / (mu * mu * (1.0 + mu * mu)), NmT = Nn - mu * Tt;
+          const D fnm = -Dm * NmT * mu;
+          const D ftm = -fnm / Tt * U1 * mu;
+          const D fn = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jn, fnm));
+          const D ft = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jt, ftm));
+          fv = B::sel((kind[S] == K_CN) | (kind[S] == K_CT), ODD ? ft : fn, fv);
+        }
+        f[S] = fv;
+      });
+      D at[3] = {D(0.0), D(0.0), D(0.0)};
+      lfor<0, CAP>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
+      D cost = 0.0;
+      lfor<0, CAP>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        D a = 0.0;
+        lfor<0, CAP>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += Al[symidx(CAP, Ii, Jj)] * f[Jj]; });
+        r[Ii] = a;   // own-leg part of (A f)_i, R included
+        const D full = a + (ut[Ii][0] * at[0] + ut[Ii][1] * at[1] + ut[Ii][2] * at[2]);
+        cost += f[Ii] * (0.5 * full + bvec[Ii]);
+      });
+      cost = cost + B::swap(cost);
+      const M drop = cost > 0.0;
+      lfor<0, CAP>([&](auto ss) {
+        constexpr int S = decltype(ss)::value;
+        f[S] = B::sel(drop, D(0.0), f[S]);
+        r[S] = B::sel(drop, D(0.0), r[S]) + bvec[S];
+      });
+      // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = sum_j u~_j f_j is shared by the two lanes
+      D a0 = B::sel(drop, D(0.0), at[0]), a1 = B::sel(drop, D(0.0), at[1]), a2 = B::sel(drop, D(0.0), at[2]);
+      const D scale = 1.0 / (CP_MEANINERTIA * LNV);
+      M sweeping = go;
+      const M isL = leg == 0;
+      // wave-uniform "some environment has such a row" bits
+      bool anyLim[2][4], anyPair[2][3];
+      lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; anyLim[0][Jj] = B::any(go & isL & (nlim > Jj)); anyLim[1][Jj] = B::any(go & !isL & (nlim > Jj)); });
+      lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & isL & (ncon > P)); anyPair[1][P] = B::any(go & !isL & (ncon > P)); });
+      D acc = 0.0;
+      // exchange of the step's contribution to a~ : (d0, d1, d2) is non-zero on the owner lane only
+      auto share = [&](D d0, D d1, D d2) {
+        a0 = a0 + (d0 + B::swap(d0)); a1 = a1 + (d1 + B::swap(d1)); a2 = a2 + (d2 + B::swap(d2));
+      };
+      // a connect row (slots 0, 1).  Reduced form: no clamp and no cost-increase revert -- for an unclamped row d = -res / A exactly
+      // minimises its own quadratic, the change is -res^2 / (2 A) <= 0, so mj_solPGS's revert can never fire (see cassie_kernels_g16.hip).
+      auto eq_step = [&](auto ss, M owner) {
+        constexpr int S = decltype(ss)::value;
+        const M mine = owner & sweeping & (kind[S] == K_EQ);
+        const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
+        D d = -(res * Ainv[S]);
+        D chg = d * (0.5 * Adiag[S] * d + res);
+        d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
+        acc += chg;
+        f[S] = f[S] + d;
+        lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
+      };
+      auto lim_step = [&](auto ss, M owner) {
+        constexpr int S = decltype(ss)::value;
+        const M mine = owner & sweeping & (kind[S] == K_LIM);
+        const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
+        const D cand = B::fmax(f[S] - res * Ainv[S], D(0.0));
+        D d = cand - f[S];
+        D chg = d * (0.5 * Adiag[S] * d + res);
+        const M keep = mine & (chg <= 1e-10);
+        d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+        acc += chg;
+        f[S] = f[S] + d;
+        lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
+      };
+      auto pair_step = [&](auto pp, M owner) {
+        constexpr int P = decltype(pp)::value;
+        constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+        const M mine = owner & sweeping & (kind[N] == K_CN);
+        const D rn = r[N] + (ut[N][0] * a0 + ut[N][1] * a1 + ut[N][2] * a2);
+        const D rt = r[T] + (ut[T][0] * a0 + ut[T][1] * a1 + ut[T][2] * a2);
+        const D on = f[N], ot = f[T];
+        const D Ann = Adiag[N], Att = Adiag[T], Ant_ = Ant[P];
+        // normal-only update (taken when the normal force is ~0)
+        const D fn_n = B::fmax(on - rn * Ainv[N], D(0.0));
+        // ray update
+        const D denom = on * (Ann * on + Ant_ * ot) + ot * (Ant_ * on + Att * ot);
+        D x = -(on * rn + ot * rt) * B::rcp(denom);
+        x = B::fmax(x, D(-1.0));
+        x = B::sel(denom >= LMINVAL, x, D(0.0));
+        const M use_n = on < LMINVAL;
+        D fn = B::sel(use_n, fn_n, on + x * on);
+        D ft = B::sel(use_n, D(0.0), ot + x * ot);
+        // friction on one dimension: unconstrained minimiser unless it leaves the cone
+        const D bc = rt - Att * ot + Ant_ * (fn - on);
+        const D x0 = -bc * AttInv[P];
+        const D v1 = x0 * (1.0 / mu);
+        const D val = v1 * v1 - fn * fn;
+        const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
+        const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
+        ft = B::sel(fn >= LMINVAL, ftc, ft);
+        D dn = fn - on, dt = ft - ot;
+        D chg = 0.5 * (Ann * dn * dn + 2.0 * Ant_ * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+        const M keep = mine & (chg <= 1e-10);
+        dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+        acc += chg;
+        f[N] = f[N] + dn; f[T] = f[T] + dt;
+        lfor<0, CAP>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
+          r[Ii] = r[Ii] + Al[symidx(CAP, Ii, N)] * dn + Al[symidx(CAP, Ii, T)] * dt;
+        });
+        share(ut[N][0] * dn + ut[T][0] * dt, ut[N][1] * dn + ut[T][1] * dt, ut[N][2] * dn + ut[T][2] * dt);
+      };
+      I niter = 0;
+      for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+        if (!B::any(sweeping)) break;
+        acc = 0.0;
+        eq_step(LI<0>{}, isL); eq_step(LI<1>{}, isL);
+        eq_step(LI<0>{}, !isL); eq_step(LI<1>{}, !isL);
+        lfor<0, 2>([&](auto ww) {
+          constexpr int W = decltype(ww)::value;
+          lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[W][Jj]) lim_step(LI<7 - Jj>{}, W == 0 ? isL : !isL); });
+        });
+        lfor<0, 2>([&](auto ww) {
+          constexpr int W = decltype(ww)::value;
+          lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[W][P]) pair_step(LI<P>{}, W == 0 ? isL : !isL); });
+        });
+        const D improvement = -(acc + B::swap(acc));
+        niter = niter + B::toI(sweeping);
+        sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
+      }
+      out.niter = niter;
+      // ---- total generalised force g = tau + J' f
+      D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = taul[Dd]; });
+      lfor<0, CAP>([&](auto ss) {
+        constexpr int S = decltype(ss)::value;
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] += jl[S][Dd] * f[S]; });
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; sb[Bc] += jb[S][Bc] * f[S]; });
+      });
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = taub[Bc] + (sb[Bc] + B::swap(sb[Bc])); });
+      // qacc = M^-1 g (next warm start); mj_Euler's implicit joint damping: (M + h B) qacc' = g by a second block factorisation
+      // (only the leg blocks change: the base dofs are undamped)
+      D xb[3], xl[5];
+      minv_apply(fc, gb, gl, xb, xl);
+      D hb[3], hl[5];
+      if (integrate) {
+        Fact fh;
+        factor(mm, hdamp, true, fh);
+        minv_apply(fh, gb, gl, hb, hl);
+      }
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        st.wb[Bc] = B::sel(go, xb[Bc], st.wb[Bc]);
+        if (integrate) {
+          const D vn = st.vb[Bc] + LH * hb[Bc];
+          st.vb[Bc] = B::sel(go, vn, st.vb[Bc]);
+          st.qb[Bc] = B::sel(go, st.qb[Bc] + LH * vn, st.qb[Bc]);
+        }
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        st.wl[Dd] = B::sel(go, xl[Dd], st.wl[Dd]);
+        if (integrate) {
+          const D vn = st.vl[Dd] + LH * hl[Dd];
+          st.vl[Dd] = B::sel(go, vn, st.vl[Dd]);
+          st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
+        }
+      });
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------ operational-space state
+  // Cassie2d::GetOperationalSpaceState (Cassie2d.cpp:218-237) with the RBDL-semantics tables from the kinematics of the last
+  // setState (quirks Q1/Q2): body site on both lanes, the own foot (mean of the two toe sites) per lane.
+  static LEG_FN void opstate(const D (&kqb)[3], const D (&kql)[5], const D (&kvb)[3], const D (&kvl)[5], D (&body)[4], D (&foot)[4]) {
+    const I leg = B::leg();
+    Kin k;
+    fk<1>(kqb, kql, kvb, kvl, leg, k);
+    const D bx = kqb[0] - cp_qpos0[0] + cp_link_off[1][0][0], bz = kqb[1] - cp_qpos0[1] + cp_link_off[1][0][1];
+    auto site = [&](auto jj, I sid, D (&o)[4]) {
+      constexpr int J = decltype(jj)::value;
+      const D dx = ldc(&cp_site_d[0][0][0], sid * 2 + CP_NSITE * 2), dz = ldc(&cp_site_d[0][0][0], sid * 2 + 1 + CP_NSITE * 2);
+      const D rx = k.c[J] * dx + k.s[J] * dz, rz = -k.s[J] * dx + k.c[J] * dz;
+      o[0] = bx + k.ox[J] + rx; o[1] = bz + k.oz[J] + rz;
+      o[2] = kvb[0] + k.vx[J] + k.w[J] * rz; o[3] = kvb[1] + k.vz[J] - k.w[J] * rx;
+    };
+    site(LI<0>{}, I(1), body);
+    D sa[4], sbv[4];
+    site(LI<4>{}, leg * 2 + 2, sa);
+    site(LI<4>{}, leg * 2 + 3, sbv);
+    lfor<0, 4>([&](auto ii) { constexpr int Ii = decltype(ii)::value; foot[Ii] = (sa[Ii] + sbv[Ii]) / 2.0; });
+  }
+
+  static LEG_FN M in_range(D x) { return B::fabs(x) <= FINITE_BOUND; }  // false for NaN and +-inf
+
+  // ------------------------------------------------------------------------------------------------ fused Env.step
+  // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (StepOsc / StepJacobian:
+  // the controller kernel wrote them).  act3: the own leg's action components (hip, knee, toe); a2own: this lane's share of
+  // sum(action^2) (cassie_stand2d.py reward).  valid: the lane's environment exists.
+  template <int MODE>
+  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, Lane& st, const D (&act3)[3], D a2own, M valid, Out& o) {
+    const I leg = B::leg();
+    const I db = leg * 5 + 3;
+    M live = valid;
+    o.set_state = (valid & !valid);
+    o.pend = 0; o.niter = 0;
+    o.do_reset = o.set_state; o.bad = o.set_state; o.done = o.set_state; o.stored = o.set_state;
+    o.reward = 0.0;
+    D ctl[3] = {D(0.0), D(0.0), D(0.0)};
+    SubOut so;
+    for (int sub = 0; sub < cfg.n_sub; sub++) {
+      D qb0[3], ql0[5], vb0[3], vl0[5];
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; qb0[Bc] = st.qb[Bc]; vb0[Bc] = st.vb[Bc]; });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ql0[Dd] = st.ql[Dd]; vl0[Dd] = st.vl[Dd]; });
+      D cnew[3];
+      lfor<0, 3>([&](auto aa) {
+        constexpr int A_ = decltype(aa)::value;
+        constexpr int Dd = A_ == 2 ? 3 : A_;
+        if constexpr (MODE == 2) cnew[A_] = st.ctrl[A_];
+        else if constexpr (MODE == 0) cnew[A_] = 10.0 * (act3[A_] - ql0[Dd]) + 5.0 * (0.0 - vl0[Dd]);
+        else cnew[A_] = act3[A_];
+      });
+      substep(lds, st, cnew, live, true, so);
+      const M ovf = live & so.overflow;
+      o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);
+      live = live & !ovf;
+      // DynamicModel::setState of this substep (the pre-step state), ctrl, clock
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.kqb[Bc] = B::sel(live, qb0[Bc], st.kqb[Bc]); st.kvb[Bc] = B::sel(live, vb0[Bc], st.kvb[Bc]); });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; st.kql[Dd] = B::sel(live, ql0[Dd], st.kql[Dd]); st.kvl[Dd] = B::sel(live, vl0[Dd], st.kvl[Dd]); });
+      lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; ctl[A_] = B::sel(live, cnew[A_], ctl[A_]); });
+      o.niter = o.niter + B::seli(live, so.niter, I(0));
+      st.time = B::sel(live, st.time + 0.0005, st.time);
+      o.set_state = o.set_state | live;
+      if (!B::any(live)) break;
+    }
+    lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; st.ctrl[A_] = B::sel(live, ctl[A_], st.ctrl[A_]); });
+    if (!cfg.want_obs) return;
+    // ---- end-of-step section
+    const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
+    D body[4], foot[4];
+    if (fix_kin) opstate(st.qb, st.ql, st.vb, st.vl, body, foot);
+    else opstate(st.kqb, st.kql, st.kvb, st.kvl, body, foot);
+    const D bodyx = body[0], zz = body[1], pitch = st.qb[2];
+    // obs[0..4] = z, pitch, xd, zd, pitchd ; own foot: x - bodyx, z, 0 (Q4), xd, zd, 0 (Q4)
+    auto fill_obs = [&](D (&ob)[5], D (&of)[6]) {
+      ob[0] = zz; ob[1] = pitch; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
+      of[0] = foot[0] - bodyx; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
+    };
+    fill_obs(o.body, o.foot);
+    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = 0.0; });
+    D reward = 0.0;
+    M done;
+    if (cfg.env_kind == 0) {
+      // reference-gait lookup (cassie2d_trajectory.py:16-19), reward (cassie2d.py:197-218); qstate is the reset pose unless
+      // FLAG_FIX_STALE_QSTATE (quirk Q3)
+      const double tmax = cfg.traj_tmax;
+      const I idx = B::toint(B::fmod(st.time, tmax) / tmax * (double)cfg.traj_n);
+      constexpr int COLS[9] = {0, 1, 2, 3, 4, 6, 8, 9, 11};
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = B::ldg(cfg.traj_qpos, idx * LNV + COLS[Ii]); });
+      const bool fixq = (cfg.flags & FLAG_FIX_STALE_QSTATE) != 0;
+      // joints 3,4,6 (left) and 8,9,11 (right): own hip + knee + toe, partner's by exchange; left first as in the reference
+      const D mine3 = fixq ? st.ql[0] + st.ql[1] + st.ql[3] : st.qst[0] + st.qst[1] + st.qst[3];
+      const D other3 = B::swap(mine3);
+      D j = B::sel(leg == 0, mine3, other3);
+      j = j + B::sel(leg == 0, other3, mine3);
+      D sum = 0.0;
+      lfor<3, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; sum += o.ref[Ii]; });
+      j = j - sum; j = B::exp(-(j * j));
+      D pp = bodyx + zz;
+      pp = pp - (o.ref[0] + o.ref[1]); pp = B::exp(-(pp * pp));
+      D oo = pitch;
+      oo = oo - o.ref[2]; oo = B::exp(-(oo * oo));
+      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+      done = (zz < 0.6) | (zz > 1.2) | (reward < 0.6);
+    } else {
+      const D a2 = a2own + B::swap(a2own);
+      // m = (left foot x - bodyx + right foot x - bodyx) / 2, left first
+      const D fo = B::swap(o.foot[0]);
+      const D m = (B::sel(leg == 0, o.foot[0], fo) + B::sel(leg == 0, fo, o.foot[0])) / 2.0;
+      reward = 0.0;
+      reward = reward - 2.0 * (0.9 - zz) * (0.9 - zz);
+      reward = reward - 2.0 * m * m;
+      reward = reward + 1.0;
+      reward = reward - 0.001 * a2;
+      done = zz < 0.5;
+    }
+    // failure guard (MuJoCo's mj_checkPos / mj_checkVel): a state outside the finite range terminates the episode
+    M okl = in_range(st.qb[0]) & in_range(st.qb[1]) & in_range(st.qb[2]) & in_range(st.vb[0]) & in_range(st.vb[1]) & in_range(st.vb[2]);
+    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; okl = okl & in_range(st.ql[Dd]) & in_range(st.vl[Dd]); });
+    okl = okl & B::swapm(okl);
+    const M bad = live & ((!okl) | (!in_range(reward)));
+    o.bad = bad;
+    lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.body[Ii] = B::sel(bad, D(0.0), o.body[Ii]); });
+    lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.foot[Ii] = B::sel(bad, D(0.0), o.foot[Ii]); });
+    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = B::sel(bad, D(0.0), o.ref[Ii]); });
+    reward = B::sel(bad, D(0.0), reward);
+    done = done | bad;
+    if (cfg.auto_reset) {
+      // the reset below also clears every NaN carrier (warm start, ctrl, setState copies)
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        st.wb[Bc] = B::sel(bad, D(0.0), st.wb[Bc]); st.kqb[Bc] = B::sel(bad, D(cp_env_qinit[Bc]), st.kqb[Bc]); st.kvb[Bc] = B::sel(bad, D(0.0), st.kvb[Bc]);
+        st.ctrl[Bc] = B::sel(bad, D(0.0), st.ctrl[Bc]);
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        st.wl[Dd] = B::sel(bad, D(0.0), st.wl[Dd]); st.kql[Dd] = B::sel(bad, ldc(cp_env_qinit, db + Dd), st.kql[Dd]); st.kvl[Dd] = B::sel(bad, D(0.0), st.kvl[Dd]);
+      });
+      o.set_state = o.set_state | bad;
+    }
+    o.reward = reward; o.done = done; o.stored = live;
+    o.do_reset = live & done & (cfg.auto_reset != 0);
+    if (!B::any(o.do_reset)) return;
+    // ---- Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.qb[Bc] = B::sel(o.do_reset, D(cp_env_qinit[Bc]), st.qb[Bc]); st.vb[Bc] = B::sel(o.do_reset, D(0.0), st.vb[Bc]); });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      const D qi = ldc(cp_env_qinit, db + Dd);
+      st.ql[Dd] = B::sel(o.do_reset, qi, st.ql[Dd]); st.vl[Dd] = B::sel(o.do_reset, D(0.0), st.vl[Dd]); st.qst[Dd] = B::sel(o.do_reset, qi, st.qst[Dd]);
+    });
+    st.time = B::sel(o.do_reset, D(0.0), st.time);
+    substep(lds, st, st.ctrl, o.do_reset, false, so);   // the reset pose on the flat floor has 12 rows: never an overflow
+    // reset observation: 17 op-space values from the kinematics of the last setState (quirk Q2), pitch from the reset pose
+    if (fix_kin) opstate(st.qb, st.ql, st.vb, st.vl, body, foot);
+    else opstate(st.kqb, st.kql, st.kvb, st.kvl, body, foot);
+    {
+      const D bx2 = body[0];
+      o.rbody[0] = body[1]; o.rbody[1] = st.qb[2]; o.rbody[2] = body[2]; o.rbody[3] = body[3]; o.rbody[4] = st.vb[2];
+      o.rfoot[0] = foot[0] - bx2; o.rfoot[1] = foot[1]; o.rfoot[2] = 0.0; o.rfoot[3] = foot[2]; o.rfoot[4] = foot[3]; o.rfoot[5] = 0.0;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------ HBM <-> lane
+  // Per-lane "pointers" (B::P: the lane's state record / action row / observation row ...); base-dof fields are read by both
+  // lanes of an environment and written by the left lane only.
+  struct Io {
+    typename B::P rec, act, obs, tobs, rew;
+    typename B::P8 done;
+    bool has_act, has_tobs;
+  };
+
+  static LEG_FN void load_lane(typename B::P rec, Lane& st) {
+    const I leg = B::leg();
+    const I lo = leg * 5 + 3, ao = leg * 3;
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      st.qb[Bc] = B::pld(rec, I(ES_Q + Bc)); st.vb[Bc] = B::pld(rec, I(ES_V + Bc)); st.wb[Bc] = B::pld(rec, I(ES_WS + Bc));
+      st.kqb[Bc] = 0.0; st.kvb[Bc] = 0.0;   // ES_KQ / ES_KV are not read: the first setState of the step overwrites them
+      st.ctrl[Bc] = B::pld(rec, ao + (ES_CTRL + Bc));
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      st.ql[Dd] = B::pld(rec, lo + (ES_Q + Dd)); st.vl[Dd] = B::pld(rec, lo + (ES_V + Dd)); st.wl[Dd] = B::pld(rec, lo + (ES_WS + Dd));
+      st.kql[Dd] = 0.0; st.kvl[Dd] = 0.0;
+      st.qst[Dd] = B::pld(rec, lo + (ES_QSTATE + Dd));
+    });
+    st.time = B::pld(rec, I(ES_TIME));
+  }
+
+  static LEG_FN void store_lane(typename B::P rec, const Lane& st, const Out& o, M valid) {
+    const I leg = B::leg();
+    const I lo = leg * 5 + 3, ao = leg * 3;
+    const M left = valid & (leg == 0);
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      B::pst(rec, I(ES_Q + Bc), st.qb[Bc], left); B::pst(rec, I(ES_V + Bc), st.vb[Bc], left); B::pst(rec, I(ES_WS + Bc), st.wb[Bc], left);
+      B::pst(rec, I(ES_KQ + Bc), st.kqb[Bc], left & o.set_state); B::pst(rec, I(ES_KV + Bc), st.kvb[Bc], left & o.set_state);
+      B::pst(rec, ao + (ES_CTRL + Bc), st.ctrl[Bc], valid);
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      B::pst(rec, lo + (ES_Q + Dd), st.ql[Dd], valid); B::pst(rec, lo + (ES_V + Dd), st.vl[Dd], valid); B::pst(rec, lo + (ES_WS + Dd), st.wl[Dd], valid);
+      B::pst(rec, lo + (ES_KQ + Dd), st.kql[Dd], valid & o.set_state); B::pst(rec, lo + (ES_KV + Dd), st.kvl[Dd], valid & o.set_state);
+      B::pst(rec, lo + (ES_QSTATE + Dd), st.qst[Dd], valid & o.do_reset);
+    });
+    // qstate of the base dofs: reset writes qinit there too (only ever read back by the general kernels' record copy)
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; B::pst(rec, I(ES_QSTATE + Bc), D(cp_env_qinit[Bc]), left & o.do_reset); });
+    B::pst(rec, I(ES_TIME), st.time, left);
+    B::pst(rec, I(ES_NITER), B::toD(o.niter), left);
+    B::pst(rec, I(ES_QPWSET), D(0.0), left & o.do_reset);   // new episode: cold start of the OSC QP too
+  }
+
+  // one Env.step of the lane's environment: load, step, outputs, write-back.  Returns through `o` what the caller still has to do
+  // (pending count, failure-guard counter).
+  template <int MODE>
+  static LEG_FN void env_step_io(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o) {
+    const I leg = B::leg();
+    Lane st;
+    load_lane(io.rec, st);
+    D act3[3] = {D(0.0), D(0.0), D(0.0)};
+    D a2own = 0.0;
+    if (io.has_act) {
+      if constexpr (MODE != 2) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; act3[A_] = B::pld(io.act, leg * 3 + A_); });
+      // sum(action^2) of cassie_stand2d.py's reward: the own leg's three components; component 6 (OSC) rides on the left lane
+      if (cfg.env_kind != 0) {
+        lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; const D a = B::pld(io.act, leg * 3 + A_); a2own += a * a; });
+        if (cfg.adim == 7) { const D a = B::pld(io.act, I(6)); a2own += B::sel(leg == 0, a * a, D(0.0)); }
+      }
+    }
+    env_step<MODE>(cfg, lds, st, act3, a2own, valid, o);
+    if (cfg.want_obs) {
+      const M left = leg == 0;
+      auto put = [&](typename B::P row, const D (&ob)[5], const D (&of)[6], M m) {
+        lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, I(Ii), ob[Ii], m & left); });
+        lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, leg * 6 + (5 + Ii), of[Ii], m); });
+      };
+      if (io.has_tobs) {
+        put(io.tobs, o.body, o.foot, o.stored);
+        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.tobs, I(17 + Ii), o.ref[Ii], o.stored & !left); });
+      }
+      put(io.obs, o.body, o.foot, o.stored);
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), o.ref[Ii], o.stored & !left); });
+      B::pst(io.rew, I(0), o.reward, o.stored & left);
+      B::pst8(io.done, o.done, o.stored & left);
+      // Cassie2dEnv.reset returns the 17 op-space values; the trajectory slots of the observation are zero there
+      put(io.obs, o.rbody, o.rfoot, o.do_reset);
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), o.do_reset & !left); });
+    }
+    store_lane(io.rec, st, o, valid);
+  }
+};
+
+}  // namespace leg
+}  // namespace cassie
+#endif

@@ -1,0 +1,133 @@
+// leg_host.cpp -- TEST INFRASTRUCTURE: compiles cassierl_amd/csrc/cassie_leg_core.h (the two-lanes-per-environment Env.step of
+// the HIP kernel cassie_kernels_leg.hip) for the CPU with a two-lane emulation backend, one environment at a time, so that the
+// CPU test-suite can check the kernel's source against the oracle before anything runs on a GPU (tests/test_leg_host.py).
+// Only tests/ build and load this; the product (cassierl_amd/) has no CPU path.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __device__
+#define __constant__
+#define __forceinline__ inline
+#define LEG_FN inline
+#include "../../cassierl_amd/csrc/cassie_leg_core.h"
+
+namespace {
+
+struct VM {
+  bool v[2];
+  VM() {}
+  VM(bool b) { v[0] = v[1] = b; }
+};
+struct VI {
+  int v[2];
+  VI() {}
+  VI(int a) { v[0] = v[1] = a; }
+};
+struct VD {
+  double v[2];
+  VD() {}
+  VD(double a) { v[0] = v[1] = a; }
+};
+#define VD_BIN(op) inline VD operator op(const VD& a, const VD& b) { VD r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
+VD_BIN(+) VD_BIN(-) VD_BIN(*) VD_BIN(/)
+inline VD operator-(const VD& a) { VD r; r.v[0] = -a.v[0]; r.v[1] = -a.v[1]; return r; }
+inline VD& operator+=(VD& a, const VD& b) { a = a + b; return a; }
+#define VD_CMP(op) inline VM operator op(const VD& a, const VD& b) { VM r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
+VD_CMP(<) VD_CMP(>) VD_CMP(<=) VD_CMP(>=) VD_CMP(==)
+#define VI_BIN(op) inline VI operator op(const VI& a, const VI& b) { VI r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
+VI_BIN(+) VI_BIN(-) VI_BIN(*)
+#define VI_CMP(op) inline VM operator op(const VI& a, const VI& b) { VM r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
+VI_CMP(<) VI_CMP(>) VI_CMP(<=) VI_CMP(>=) VI_CMP(==) VI_CMP(!=)
+inline VM operator&(const VM& a, const VM& b) { VM r; r.v[0] = a.v[0] && b.v[0]; r.v[1] = a.v[1] && b.v[1]; return r; }
+inline VM operator|(const VM& a, const VM& b) { VM r; r.v[0] = a.v[0] || b.v[0]; r.v[1] = a.v[1] || b.v[1]; return r; }
+inline VM operator!(const VM& a) { VM r; r.v[0] = !a.v[0]; r.v[1] = !a.v[1]; return r; }
+
+struct HostB {
+  typedef VD D;
+  typedef VI I;
+  typedef VM M;
+  struct P { double* p[2]; };
+  struct P8 { uint8_t* p[2]; };
+  struct Lds {
+    double pr[3][4][2]; int pdepth[3][2];
+    double lm[4][3][2]; int lmj[4][2];
+    void st_pair(VI slot, VD px, VD pz, VD dist, VD invw, VI depth, VM m) {
+      for (int l = 0; l < 2; l++) if (m.v[l]) { int s = slot.v[l]; pr[s][0][l] = px.v[l]; pr[s][1][l] = pz.v[l]; pr[s][2][l] = dist.v[l]; pr[s][3][l] = invw.v[l]; pdepth[s][l] = depth.v[l]; }
+    }
+    void ld_pair(int s, VD& px, VD& pz, VD& dist, VD& invw, VI& depth) {
+      for (int l = 0; l < 2; l++) { px.v[l] = pr[s][0][l]; pz.v[l] = pr[s][1][l]; dist.v[l] = pr[s][2][l]; invw.v[l] = pr[s][3][l]; depth.v[l] = pdepth[s][l]; }
+    }
+    void st_lim(VI slot, VD pos, VD sgn, VD invw, VI j, VM m) {
+      for (int l = 0; l < 2; l++) if (m.v[l]) { int s = slot.v[l]; lm[s][0][l] = pos.v[l]; lm[s][1][l] = sgn.v[l]; lm[s][2][l] = invw.v[l]; lmj[s][l] = j.v[l]; }
+    }
+    void ld_lim(int s, VD& pos, VD& sgn, VD& invw, VI& j) {
+      for (int l = 0; l < 2; l++) { pos.v[l] = lm[s][0][l]; sgn.v[l] = lm[s][1][l]; invw.v[l] = lm[s][2][l]; j.v[l] = lmj[s][l]; }
+    }
+  };
+  static VI leg() { VI r; r.v[0] = 0; r.v[1] = 1; return r; }
+  static VD sel(VM m, VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VI seli(VM m, VI a, VI b) { VI r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
+  static VD swap(VD x) { VD r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
+  static VM swapm(VM x) { VM r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
+  static bool any(VM m) { return m.v[0] || m.v[1]; }
+  static VD ldc(const double* t, VI i) { VD r; r.v[0] = t[i.v[0]]; r.v[1] = t[i.v[1]]; return r; }
+  static VD ldg(const double* t, VI i) { return ldc(t, i); }
+  static VI toI(VM m) { VI r; r.v[0] = m.v[0]; r.v[1] = m.v[1]; return r; }
+  static VD toD(VI i) { VD r; r.v[0] = i.v[0]; r.v[1] = i.v[1]; return r; }
+  static VI toint(VD x) { VI r; r.v[0] = (int)x.v[0]; r.v[1] = (int)x.v[1]; return r; }
+  static void sincos(VD x, VD& s, VD& c) { for (int l = 0; l < 2; l++) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
+  static VD sqrt(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::sqrt(x.v[l]); return r; }
+  static VD rcp(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = 1.0 / x.v[l]; return r; }
+  static VD fabs(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fabs(x.v[l]); return r; }
+  static VD fmax(VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fmax(a.v[l], b.v[l]); return r; }
+  static VD exp(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::exp(x.v[l]); return r; }
+  static VD fmod(VD a, double b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fmod(a.v[l], b); return r; }
+  static VD copysign(VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::copysign(a.v[l], b.v[l]); return r; }
+  static VD pld(P p, VI off) { VD r; for (int l = 0; l < 2; l++) r.v[l] = p.p[l][off.v[l]]; return r; }
+  static void pst(P p, VI off, VD v, VM m) { for (int l = 0; l < 2; l++) if (m.v[l]) p.p[l][off.v[l]] = v.v[l]; }
+  static void pst8(P8 p, VM v, VM m) { for (int l = 0; l < 2; l++) if (m.v[l]) *p.p[l] = (uint8_t)v.v[l]; }
+};
+
+typedef cassie::leg::Core<HostB> HCore;
+
+HostB::P both(double* p) { HostB::P r; r.p[0] = r.p[1] = p; return r; }
+
+}  // namespace
+
+extern "C" {
+
+// One Env.step (or n_sub bare substeps when obs == null) of n environments on host arrays laid out like the device ones.
+// pending[e] = substeps NOT done because the environment left the 8-rows-per-leg capacity (its state is untouched from there on).
+int leg_host_step(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
+                  const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
+                  int* pending, int* nonfinite) {
+  cassie::leg::EnvCfg cfg;
+  cfg.n_sub = n_sub; cfg.flags = flags; cfg.env_kind = env_kind; cfg.auto_reset = auto_reset; cfg.adim = adim;
+  cfg.want_obs = obs != nullptr; cfg.traj_qpos = traj_qpos; cfg.traj_tmax = traj_tmax; cfg.traj_n = traj_n;
+  double dummy[32] = {0};
+  uint8_t dummy8 = 0;
+  for (int e = 0; e < n; e++) {
+    HostB::Lds lds;
+    std::memset(&lds, 0, sizeof lds);
+    HCore::Io io;
+    io.rec = both(state + (size_t)e * cassie::ENV_STRIDE);
+    io.has_act = actions != nullptr;
+    io.act = both(actions ? const_cast<double*>(actions) + (size_t)e * adim : dummy);
+    io.obs = both(obs ? obs + (size_t)e * 26 : dummy);
+    io.has_tobs = terminal_obs != nullptr;
+    io.tobs = both(terminal_obs ? terminal_obs + (size_t)e * 26 : dummy);
+    io.rew = both(reward ? reward + e : dummy);
+    io.done.p[0] = io.done.p[1] = done ? done + e : &dummy8;
+    VM valid; valid.v[0] = valid.v[1] = true;
+    HCore::Out o;
+    if (mode == 0) HCore::env_step_io<0>(cfg, lds, io, valid, o);
+    else if (mode == 1) HCore::env_step_io<1>(cfg, lds, io, valid, o);
+    else HCore::env_step_io<2>(cfg, lds, io, valid, o);
+    if (pending) pending[e] = o.pend.v[0];
+    if (nonfinite && o.bad.v[0]) (*nonfinite)++;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""TEST INFRASTRUCTURE: ctypes view of tests/host_emul/leg_host.cpp -- the source of the two-lanes-per-environment HIP kernel
+(cassierl_amd/csrc/cassie_leg_core.h) compiled for the CPU with a lane-pair emulation -- behind the subset of the
+CassieVecEnv interface the parity tests use, so that the same test bodies run against it without a GPU."""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BUILD = os.path.join(HERE, "_build")
+MODES = {"PD": 0, "Torque": 1, "Record": 2}
+_LIB = None
+dp = ct.POINTER(ct.c_double)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        os.makedirs(BUILD, exist_ok=True)
+        so = os.path.join(BUILD, "libleg_host.so")
+        srcs = [os.path.join(HERE, "host_emul", "leg_host.cpp")] + [os.path.join(ROOT, "cassierl_amd", "csrc", f)
+                                                                    for f in ("cassie_leg_core.h", "cassie2d_planar.h", "cassie_vec_layout.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
+        _LIB = ct.CDLL(so)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(dp) if a is not None else None
+
+
+class LegHostEnv:
+    def __init__(self, n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True, flags=0):
+        self.n, self.kind, self.mode, self.n_sub, self.auto_reset, self.flags = n, kind, control_mode, n_substeps, auto_reset, flags
+        self.adim = 6
+        self.state = np.zeros((n, 88))
+        self.traj_q, self.traj_tmax, self.traj_n = None, 0.0, 0
+        self.pending = np.zeros(n, dtype=np.int32)
+        self.nonfinite = 0
+
+    def set_trajectory(self, time, qpos):
+        self.traj_q = np.ascontiguousarray(qpos, dtype=np.float64)
+        self.traj_tmax, self.traj_n = float(time[-1]), len(time)
+
+    def set_full_state_host(self, s):
+        self.state = np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(self.n, 88)).copy()
+
+    def get_full_state_host(self):
+        return self.state.copy()
+
+    def _call(self, mode, acts, n_sub, want_obs):
+        acts = None if acts is None else np.ascontiguousarray(acts, dtype=np.float64)
+        obs = np.zeros((self.n, 26)) if want_obs else None
+        rew = np.zeros(self.n) if want_obs else None
+        done = np.zeros(self.n, dtype=np.uint8)
+        bad = ct.c_int(0)
+        lib().leg_host_step(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
+                            0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
+                            _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,
+                            self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad))
+        self.nonfinite += bad.value
+        return obs, rew, done.astype(bool)
+
+    def substep_host(self, mode, acts, n_sub):
+        self._call(mode, acts, n_sub, False)
+
+    def step_host(self, acts):
+        return self._call(self.mode, acts, self.n_sub, True)
+
+    def close(self):
+        pass

@@ -1,0 +1,116 @@
+"""The two-lanes-per-environment kernel source (cassierl_amd/csrc/cassie_leg_core.h), compiled for the CPU by
+tests/host_emul/leg_host.cpp, against the oracle: the same checks tests/test_gpu_parity.py runs on the GPU through the C-ABI,
+here without one -- so that a formulation error (block factorisation, factored A, row slots, sweep order) is found on the CPU."""
+import numpy as np
+import pytest
+
+from conftest import state_vec
+from leg_host import LegHostEnv
+
+PD_LO, PD_HI = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+TQ = np.array([12.0, 12.0, 0.9] * 2)
+
+
+def rel_err(sg, q1, v1):
+    return max(np.abs(sg[:13] - q1).max() / np.abs(q1).max(), np.abs(sg[13:26] - v1).max() / (1e-3 + np.abs(v1).max()))
+
+
+@pytest.mark.parametrize("mode", ["Torque", "PD"])
+def test_teacher_forced_1000_substeps(oracle_mod, mode):
+    rng = np.random.default_rng(1)
+    env = LegHostEnv(1, n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    worst, maxrows, worst_ws = 0.0, 0, 0.0
+    for i in range(1000):
+        if i % 10 == 0:
+            a = rng.uniform(-1, 1, 6) * TQ if mode == "Torque" else rng.uniform(PD_LO, PD_HI)
+        qo, vo = o.state()
+        env.set_full_state_host(state_vec(qo, vo, o.warmstart())[None])
+        env.substep_host(mode, a[None], 1)
+        assert env.pending[0] == 0
+        (o.step_torque if mode == "Torque" else o.step_pd)(a)
+        sg = env.get_full_state_host()[0]
+        q1, v1 = o.state()
+        worst = max(worst, np.abs(sg[:13] - q1).max(), np.abs(sg[13:26] - v1).max() / (1 + np.abs(v1).max()))
+        worst_ws = max(worst_ws, np.abs(sg[26:39] - o.warmstart()).max() / (1 + np.abs(o.warmstart()).max()))
+        maxrows = max(maxrows, o.nefc)
+    assert worst < 1e-9 and worst_ws < 1e-6, (worst, worst_ws)
+    assert maxrows >= 18
+
+
+def test_free_running_torque_1000_substeps(oracle_mod):
+    rng = np.random.default_rng(2)
+    n = 4
+    env = LegHostEnv(n, n_substeps=1, auto_reset=False)
+    oracles = [oracle_mod.Oracle() for _ in range(n)]
+    env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in oracles]))
+    worst = 0.0
+    for t in range(100):
+        acts = rng.uniform(-1, 1, (n, 6)) * TQ
+        env.substep_host("Torque", acts, 10)
+        assert (env.pending == 0).all()
+        for i, o in enumerate(oracles):
+            for _ in range(10):
+                o.step_torque(acts[i])
+        sg = env.get_full_state_host()
+        for i, o in enumerate(oracles):
+            worst = max(worst, rel_err(sg[i], *o.state()))
+    assert worst < 1e-5, worst   # north_star tolerance
+
+
+@pytest.mark.parametrize("tag,kind,mode", [("walk_pd", "walk", "PD"), ("walk_torque", "walk", "Torque"),
+                                          ("stand_torque", "stand", "Torque"), ("stand_pd", "stand", "PD")])
+def test_env_step_against_golden_streams(streams, traj, oracle_mod, tag, kind, mode):
+    env = LegHostEnv(2, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    # Cassie2dEnv.reset through the oracle env (the emulation has no reset entry of its own: the kernel resets inside Env.step)
+    oe = oracle_mod.OracleEnv(kind, mode, traj=dict(time=traj["time"], qpos=traj["qpos"]))
+    oe.reset()
+    o = oe.oracle
+    q, v = o.state()
+    ctor = oracle_mod.Oracle()
+    s0 = state_vec(q, v, o.warmstart(), kq=ctor.state()[0], kv=ctor.state()[1], qstate=q)   # stale kinematics of the ctor (quirk Q2)
+    env.set_full_state_host(np.tile(s0, (2, 1)))
+    acts = streams[tag + "_actions"]
+    horizon = 40 if mode == "Torque" or kind == "walk" else 8
+    for t in range(horizon):
+        obs, rew, done = env.step_host(np.tile(acts[t], (2, 1)))
+        assert (env.pending == 0).all()
+        d = bool(streams[tag + "_done"][t])
+        exp_obs = streams[tag + "_reset_obs"][t] if d else streams[tag + "_obs"][t]
+        assert (done == d).all()
+        np.testing.assert_allclose(rew, streams[tag + "_reward"][t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(obs, np.tile(exp_obs, (2, 1)), rtol=0, atol=2e-7)
+        assert np.array_equal(env.state[0], env.state[1])
+
+
+def test_limits_contacts_and_the_capacity_hand_over(oracle_mod):
+    """A robot driven into its joint limits and collapsing: wherever a leg needs at most 8 rows the step agrees with the oracle;
+    beyond that the environment is handed over untouched (pending = substeps left)."""
+    env = LegHostEnv(1, n_substeps=1, auto_reset=False)
+    o = oracle_mod.Oracle()
+    push = np.array([12.2, -12.2, 0.9, 12.2, -12.2, 0.9])
+    done_in, handed, maxlim, maxcon = 0, 0, 0, 0
+    for i in range(5000):
+        a = push if i < 800 else np.zeros(6)
+        if i == 1200:
+            o = oracle_mod.Oracle()
+        if i % 10 == 0:
+            q, v = o.state()
+            s0 = state_vec(q, v, o.warmstart())
+            env.set_full_state_host(s0[None])
+            env.substep_host("Torque", a[None], 1)
+            o.step_torque(a)
+            sg = env.get_full_state_host()[0]
+            if env.pending[0]:
+                handed += 1
+                assert env.pending[0] == 1 and np.array_equal(sg[:39], s0[:39])
+            else:
+                done_in += 1
+                q1, v1 = o.state()
+                assert np.abs(sg[:13] - q1).max() < 1e-10 and np.abs(sg[13:26] - v1).max() < 1e-8 * (1 + np.abs(v1).max()), i
+                e = o.efc()
+                maxcon = max(maxcon, o.ncon); maxlim = max(maxlim, int((e["type"] == 1).sum()))
+        else:
+            o.step_torque(a)
+    assert done_in > 100 and handed > 0 and maxlim >= 2 and maxcon >= 4, (done_in, handed, maxlim, maxcon)
