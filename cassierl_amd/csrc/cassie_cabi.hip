@@ -41,6 +41,8 @@ struct CassieVec {
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
   int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
+  int* pending_leg = nullptr;                // substeps left per env after the two-lanes-per-env kernel (input of the 4-envs-per-wave kernel)
+  bool leg = true;                           // first tier = the two-lanes-per-environment kernel (CASSIE2D_LEG=0/1 overrides the size rule)
   unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
   unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
   unsigned long long substeps_requested = 0; // host: env-substeps asked for since the counters were last cleared
@@ -70,6 +72,7 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
+constexpr int LEG_MIN_ENVS = 16384;
 constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
 constexpr int MAXACT_DBG = L2::K1_MAXACT_DBG;           // debug build of the substep: forces the overflow path in tests
@@ -95,6 +98,24 @@ cassie::VecParams make_params(CassieVec* h) {
   return p;
 }
 
+// Physics tiers on the flat floor (mode 0 PD, 1 torque, 2 commands from the record).  Each tier leaves an environment it cannot
+// hold untouched from that substep on and says how many substeps are left; the next tier finishes it (results are what that
+// tier alone would give: an environment's arithmetic is a function of its own state in every kernel).
+//   tier 1  two lanes per environment (<= 8 rows per leg)        cassie_kernels_leg.hip   [h->leg]
+//   tier 2  four environments per wavefront (<= 16 rows)          cassie_kernels_g16.hip
+//   tier 3  one wavefront per environment (any number of rows)    cassie_kernels.hip
+void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& p) {
+  cassie::VecParams p2 = p;
+  if (h->leg) {
+    L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    p2.pending = h->pending_leg;
+  }
+  L2::step_g16(mode, h->n, h->stream, p2, h->pending);
+  cassie::VecParams p3 = p;
+  p3.pending = h->pending;
+  L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3);
+}
+
 // controller-in-the-loop modes; zpos/zvel != null selects the scripted standing controllers
 int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const double* zpos, const double* zvel) {
   const bool scripted = zpos != nullptr;
@@ -111,10 +132,7 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
       ps.n_sub = 1;
       if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
       L2::ctrl_g16(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
-      L2::step_g16(2, h->n, h->stream, ps, h->pending);
-      cassie::VecParams pc = ps;
-      pc.pending = h->pending;
-      L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, pc);
+      launch_physics_tiers(h, 2, ps);
     }
   } else {
     // wave-per-environment kernels only (CASSIE_WAVE_PER_ENV cross-check, debug record): same split, one wavefront per environment
@@ -148,10 +166,7 @@ int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   } else if (h->g16 && !p.debug && pdtq) {
     // fast path: 4 environments per wavefront; environments with more than 16 active constraint rows are finished
     // by the wave-per-environment kernel, which returns immediately for every other environment
-    L2::step_g16(mode, h->n, h->stream, p, h->pending);
-    cassie::VecParams pc = p;
-    pc.pending = h->pending;
-    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, pc);
+    launch_physics_tiers(h, mode, p);
   } else if (p.debug && pdtq) {
     // test hook: same code with only MAXACT_DBG register-resident columns, so that the workspace path is exercised
     L2::step_k1(mode, L2::K1_DEBUG, h->n, h->stream, p);
@@ -212,6 +227,8 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMalloc(&h->ovf, n * OVF_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->pending, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->pending_leg, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMemset(h->pending_leg, 0, n * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
 #ifdef CASSIE_PHASE_TIMING
   if (hipMalloc(&h->phase, 16 * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->phase, 0, 16 * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
@@ -220,6 +237,10 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMemset(h->stats, 0, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
   if (h->cfg.flags & CASSIE_WAVE_PER_ENV) h->g16 = false;
+  // Two lanes per environment = 32 environments per wavefront, one wavefront per SIMD: 1024 SIMDs want >= 32 768 environments.
+  // Below LEG_MIN_ENVS the 4-environments-per-wavefront kernel (8x more wavefronts, two per SIMD) has the shorter critical path.
+  h->leg = h->g16 && n_envs >= LEG_MIN_ENVS;
+  { const char* e = getenv("CASSIE2D_LEG"); if (e && (e[0] == '0' || e[0] == '1')) h->leg = h->g16 && e[0] == '1'; }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   L2::init_state(n_envs, h->stream, h->state);
@@ -233,7 +254,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->stats); hipFree(h->phase);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->stats); hipFree(h->phase);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   delete h;

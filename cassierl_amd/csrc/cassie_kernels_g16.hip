@@ -568,12 +568,27 @@ __device__ __forceinline__ void substep(SM& sm, const LaneConst& c_in, int l, in
 // ---------------------------------------------------------------- fused Env.step, 4 envs per wave
 // MODE: 0 PD, 1 torque, 2 motor commands from the state record (the controller kernel of cassie_ctrl_g16.hip wrote them: StepOsc /
 // StepJacobian = controller launch + this kernel with n_sub = 1).  pending[env] = substeps this kernel did NOT do (0 normally).
+// Two roles: the first tier (p.pending == null: every environment, all n_sub substeps) and the hand-over tier behind the
+// two-lanes-per-environment kernel (p.pending = that kernel's per-environment count of substeps left): an environment with a
+// count c > 0 joins at substep n_sub - c -- so that all environments of a wave reach the end-of-step section together --
+// and a wave whose four counts are zero returns at once.
 template <int MODE, bool HF = false>
 __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* pending) {
   __shared__ EnvLds sm4[4];
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   const int env = blockIdx.x * 4 + g;
-  const bool valid = env < p.n_envs;
+  bool valid = env < p.n_envs;
+  int first = 0;   // substep at which this environment joins
+  if (p.pending) {
+    const int left = valid ? p.pending[env] : 0;
+    if (__ballot(left > 0) == 0) {
+      if (valid && l == 0) pending[env] = 0;
+      return;
+    }
+    if (valid && left == 0 && l == 0) pending[env] = 0;
+    valid = valid && left > 0;
+    first = p.n_sub - left;
+  }
   EnvLds& sm = sm4[g];
   const size_t e = valid ? (size_t)env : 0;
   double* st = p.state + e * ENV_STRIDE;
@@ -600,7 +615,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   lds_sync();
   bool live = valid;
   bool set_state = false;  // this environment did a setState in this launch: kq2 / kv2 are defined and go back to the record
-  int pend = 0, niter_sum = 0;
+  int pend = 0, niter_sum = (p.pending && valid) ? (int)st[ES_NITER] : 0;
   sm.ctl[l] = 0.0;
   G16Out so; so.niter = 0; so.overflow = false;
   const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0;
@@ -609,16 +624,23 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   // reset pose, for those environments) produces the reset observation.
   bool do_reset = false, reset_pass = false;
   int sub = 0;
+  if (p.pending) {   // start at the first substep any environment of the wave takes part in
+    int fmin = valid ? first : p.n_sub;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fmin = min(fmin, __shfl_xor(fmin, off));
+    sub = fmin;
+  }
   while (true) {
+    const bool joined = sub >= first;
     const int dd = c.d < NV ? c.d : 0;
     const double q_d = sm.q[dd], v_d = sm.v[dd];
     double cnew;
     if (reset_pass || MODE == 2) cnew = c.act >= 0 ? sm.ctrl[c.act] : 0.0;  // Cassie2d::Reset: mj_forward with the stale ctrl
     else { const double act_l = sm.actl[l]; cnew = MODE == 0 ? 10.0 * (act_l - q_d) + 5.0 * (0.0 - v_d) : act_l; }
-    substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : live, !reset_pass, so, &p.hf, &pc);  // reset pose on the flat floor: 12 active rows
+    substep<EnvLds, HF>(sm, c, l, g, cnew, reset_pass ? do_reset : (live && joined), !reset_pass, so, &p.hf, &pc);  // reset pose on the flat floor: 12 active rows
     if (!reset_pass) {
-      if (live && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
-      if (live) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; set_state = true; }  // setState of this substep
+      if (live && joined && so.overflow) { live = false; pend = p.n_sub - sub; }  // hand the rest of this env to the clean-up pass
+      if (live && joined) { sm.kq2[l] = q_d; sm.kv2[l] = v_d; sm.ctl[l] = cnew; niter_sum += so.niter; if (l == 0) sm.tim[0] += 0.0005; set_state = true; }  // setState of this substep
       sub++;
       if (sub < p.n_sub && __ballot(live) != 0) continue;
       if (live && c.dvalid && c.act >= 0) sm.ctrl[c.act] = sm.ctl[l];

@@ -29,6 +29,9 @@ void init_state(int n_envs, hipStream_t s, double* state);
 void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel);
 // tu_g16.hip: four environments per wavefront
 void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
+// tu_leg.hip: two lanes per environment (one per leg), 32 environments per wavefront; environments that need more than 8 rows on
+// a leg are handed on through `pending` (step_g16 with p.pending = that array, then step_k1)
+void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tu_ctrl.hip / tu_ctrl_g16.hip: controllers (ctrl: 2 OSC, 3 Jacobian): they write the motor commands into the state record
 void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
 // (the packed controller kernel only writes the motor commands; step_g16 / step_k1 with mode 2 then do the mj_step)

@@ -72,19 +72,25 @@ template <class B> struct Core {
   typedef typename B::M M;
 
   // ------------------------------------------------------------------------------------------------ per-lane state
+  // Hot part (registers): what every phase of a substep touches.  qpos / qvel / qacc_warmstart: base (x, z, pitch) replicated on
+  // both lanes of an environment, own leg (hip, knee, ankle, toe, rod).
   struct Lane {
-    D qb[3], ql[5], vb[3], vl[5];       // qpos / qvel: base (x, z, pitch) replicated on both lanes, own leg (hip, knee, ankle, toe, rod)
-    D wb[3], wl[5];                     // qacc_warmstart
-    D kqb[3], kql[5], kvb[3], kvl[5];   // state at the last DynamicModel::setState (quirks Q1/Q2)
-    D qst[5];                           // self.qstate of the own leg's joints (quirk Q3); the base entries are never read
-    D ctrl[3];                          // last mj_data->ctrl of the own leg's actuators (hip, knee, toe)
-    D time;
+    D qb[3], ql[5], vb[3], vl[5];
+    D wb[3], wl[5];
+  };
+  // Cold part (per-lane LDS slots, B::Lds::cld / cst): values that live across all substeps of an Env.step but are touched
+  // once per substep or once per step -- in registers they would be the allocator's first spills (cf. EnvLds of the g16 kernel).
+  enum {
+    C_KQ = 0,     // 8: qpos at the last DynamicModel::setState (base 3 + leg 5; quirks Q1/Q2)
+    C_KV = 8,     // 8: qvel at the last setState
+    C_QST = 16,   // 5: self.qstate of the own leg's joints (quirk Q3); the base entries are never read
+    C_CTRL = 21,  // 3: last mj_data->ctrl of the own leg's actuators (hip, knee, toe)
+    C_TIME = 24,  // env clock
+    C_ACT = 25,   // 3: this step's action components of the own leg's actuators
+    C_A2 = 28,    // this lane's share of sum(action^2) (cassie_stand2d.py reward)
+    C_N = 29
   };
   struct Out {
-    D body[5], foot[6], ref[9];         // obs[0..4], obs[5 + 6 leg ..], obs[17..25]
-    D reward;
-    M done, stored;                     // stored: this environment produced outputs (was live at the end of the step)
-    D rbody[5], rfoot[6];               // reset observation (valid where do_reset)
     M do_reset, bad, set_state;
     I pend, niter;
   };
@@ -254,9 +260,8 @@ template <class B> struct Core {
 
   struct Fact { D Li[15], Y[5][3], G[6]; };  // L^-1 (packed symmetric), Y = L^-1 C, G = F^-1 lower triangular (row-major packed: 00,10,11,20,21,22)
 
-  static LEG_FN void factor(const Mass& mm, const D (&hdamp)[5], bool with_damping, Fact& fc) {
+  static LEG_FN void factor(const Mass& mm, Fact& fc) {
     lfor<0, 15>([&](auto ii) { constexpr int Ii = decltype(ii)::value; fc.Li[Ii] = mm.Ls[Ii]; });
-    if (with_damping) lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; fc.Li[symidx(5, Dd, Dd)] = fc.Li[symidx(5, Dd, Dd)] + hdamp[Dd]; });
     sym_inverse<5>(fc.Li);
     lfor<0, 5>([&](auto ii) {
       constexpr int Ii = decltype(ii)::value;
@@ -332,98 +337,129 @@ template <class B> struct Core {
   }
 
   // ------------------------------------------------------------------------------------------------ one mj_forward (+ Euler)
-  struct SubOut { I niter; M overflow; };
+  struct SubOut { I niter; M overflow, go; };
+  constexpr static int DAMPING_SWEEPS = 12;
 
-  // `live` masks environments that must not be touched (identical on the two lanes of an environment); `integrate` is
-  // wave-uniform (false: mj_forward only, Cassie2d::Reset).  cu: pre-clamp command of the own leg's three actuators.
-  static LEG_FN void substep(typename B::Lds& lds, Lane& st, const D (&cu)[3], M live, bool integrate, SubOut& out) {
-    const I leg = B::leg();
+  // `live` masks environments that must not be touched (identical on the two lanes of an environment).  `integrate` (wave-uniform)
+  // = false gives mj_forward only (Cassie2d::Reset) and none of the per-substep bookkeeping.  `from_rec` (wave-uniform): the motor
+  // commands are the record's ctrl (MODE 2, and Reset's mj_forward with the stale ctrl); otherwise MODE 0 = PD law on the step's
+  // action, MODE 1 = the action itself.  Bookkeeping of a substep that is carried out (cold LDS slots): setState snapshot of the
+  // pre-step state, mj_data->ctrl, env clock.
+  template <int MODE>
+  static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out) {
+    // Model constants are re-read from the constant tables in every substep through indices the optimiser cannot see through
+    // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
+    // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
+    const I leg = B::opq(B::leg());
     const I db = leg * 5 + 3;
-    Kin k;
-    fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
-    Mass mm;
-    mass_bias<0>(k, leg, mm);
-    // smooth force: passive damping, bias, actuation (ctrl clamped to ctrlrange, times gear); actuators on hip (0), knee (1), toe (3)
     D taub[3], taul[5], hdamp[5];
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; });
-    lfor<0, 5>([&](auto dd) {
-      constexpr int Dd = decltype(dd)::value;
-      const D damp = ldc(cp_dof_damping, db + Dd);
-      hdamp[Dd] = LH * damp;
-      D t = -damp * st.vl[Dd] - mm.biasl[Dd];
-      if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
-        constexpr int A_ = Dd == 3 ? 2 : Dd;
-        const I ai = leg * 3 + A_;
-        const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
-        const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
-        t = t + ldc(cp_act_gear, ai) * u;
-      }
-      taul[Dd] = t;
-    });
     Fact fc;
-    factor(mm, hdamp, false, fc);
     D qsb[3], qsl[5];
-    minv_apply(fc, taub, taul, qsb, qsl);
-
-    // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
-    const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+    D oxk[6], ozk[6];           // link origins (kept for the generalised-force accumulation after the solve)
+    D p1x, p1z, p2x, p2z;       // connect anchors
     I nlim = 0, ncon = 0;
-    M ovf = (live & !live);  // false
-    lfor<0, 4>([&](auto jj) {
-      constexpr int Jj = decltype(jj)::value;
-      const D qd = st.ql[Jj];
-      const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
-      const D dlo = qd - lo, dhi = hi - qd;
-      const M act = (dlo < 0.0) | (dhi < 0.0);
-      const D pos = B::sel(dlo < 0.0, dlo, dhi);
-      const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
-      lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
-      nlim = nlim + B::toI(act);
-    });
-    lfor<0, 9>([&](auto cc) {
-      constexpr int Cc = decltype(cc)::value;
-      constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
-      const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
-      D cx, cz;
-      link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
-      const D dist = basez + cz - ldc(cp_sph_r, sph);
-      M act = dist < 0.0;
-      if constexpr (Cc == 0) act = act & (leg == 0);
-      // contact point: half-way into the penetration, on the vertical through the sphere centre
-      lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
-      ncon = ncon + B::toI(act);
-    });
-    const I nrows = nlim + ncon * 2 + 2;
-    ovf = live & (nrows > CAP);
-    ovf = ovf | B::swapm(ovf);
-    out.overflow = ovf;
-    const M go = live & !ovf;
-
-    // ---- constraint rows of the own leg: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
+    M go;
+    // ---- rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
     D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP];
     D Ant[3], AttInv[3];
     I kind[CAP];
+    D a0, a1, a2;
     {
-      D jl[CAP][5], jb[CAP][3], z[CAP][5];
+      Kin k;
+      fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+      Mass mm;
+      mass_bias<0>(k, leg, mm);
+      lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; oxk[J] = k.ox[J]; ozk[J] = k.oz[J]; });
+      // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
+      D cu[3];
+      lfor<0, 3>([&](auto aa) {
+        constexpr int A_ = decltype(aa)::value;
+        constexpr int Dd = A_ == 2 ? 3 : A_;
+        if (from_rec) cu[A_] = lds.cld(C_CTRL + A_);
+        else if constexpr (MODE == 0) cu[A_] = 10.0 * (lds.cld(C_ACT + A_) - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
+        else cu[A_] = lds.cld(C_ACT + A_);
+      });
+      // smooth force: passive damping, bias, actuation (ctrl clamped to ctrlrange, times gear)
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        const D damp = ldc(cp_dof_damping, db + Dd);
+        hdamp[Dd] = LH * damp;
+        D t = -damp * st.vl[Dd] - mm.biasl[Dd];
+        if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
+          constexpr int A_ = Dd == 3 ? 2 : Dd;
+          const I ai = leg * 3 + A_;
+          const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
+          const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
+          t = t + ldc(cp_act_gear, ai) * u;
+        }
+        taul[Dd] = t;
+      });
+      factor(mm, fc);
+      minv_apply(fc, taub, taul, qsb, qsl);
+
+      // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
+      const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+      lfor<0, 4>([&](auto jj) {
+        constexpr int Jj = decltype(jj)::value;
+        const D qd = st.ql[Jj];
+        const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
+        const D dlo = qd - lo, dhi = hi - qd;
+        const M act = (dlo < 0.0) | (dhi < 0.0);
+        const D pos = B::sel(dlo < 0.0, dlo, dhi);
+        const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
+        lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
+        nlim = nlim + B::toI(act);
+      });
+      lfor<0, 9>([&](auto cc) {
+        constexpr int Cc = decltype(cc)::value;
+        constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
+        const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
+        D cx, cz;
+        link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
+        const D dist = basez + cz - ldc(cp_sph_r, sph);
+        M act = dist < 0.0;
+        if constexpr (Cc == 0) act = act & (leg == 0);
+        // contact point: half-way into the penetration, on the vertical through the sphere centre
+        lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
+        ncon = ncon + B::toI(act);
+      });
+      const I nrows = nlim + ncon * 2 + 2;
+      M ovf = live & (nrows > CAP);
+      ovf = ovf | B::swapm(ovf);
+      out.overflow = ovf;
+      go = live & !ovf;
+      out.go = go;
+      if (integrate) {
+        // DynamicModel::setState of this substep (pre-step state), mj_data->ctrl, env clock -- for environments that carry it out
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.cst(C_KQ + Bc, st.qb[Bc], go); lds.cst(C_KV + Bc, st.vb[Bc], go); });
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.cst(C_KQ + 3 + Dd, st.ql[Dd], go); lds.cst(C_KV + 3 + Dd, st.vl[Dd], go); });
+        if (!from_rec) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; lds.cst(C_CTRL + A_, cu[A_], go); });
+        lds.cst(C_TIME, lds.cld(C_TIME) + 0.0005, go);
+      }
+
+      // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
+      {
+        const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
+        link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
+        link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
+      }
       D bvec[CAP], jar[CAP], Rr[CAP];
+      D jl[CAP][5], z[CAP][5];
       lfor<0, CAP>([&](auto ss) {
         constexpr int S = decltype(ss)::value;
         D pos = 0.0, invw = 0.0;
+        D jb[3];
         I kd = K_NONE;
         lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = 0.0; });
-        jb[S][0] = 0.0; jb[S][1] = 0.0; jb[S][2] = 0.0;
+        jb[0] = 0.0; jb[1] = 0.0; jb[2] = 0.0;
         if constexpr (S < 2) {
-          // connect: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3); row = component S of p1 - p2
-          const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
-          D p1x, p1z, p2x, p2z;
-          link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
-          link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
           kd = K_EQ;
           invw = ldc(cp_eq_invweight, leg);
           pos = S == 0 ? p1x - p2x : p1z - p2z;
           // J = J(p1 on rod: pitch, hip, rod) - J(p2 on tarsus: pitch, hip, knee, ankle); the base slides cancel
-          auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - k.oz[Jl] : -(px - k.ox[Jl]); };  // y^ x (p - o), component S
-          jb[S][2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
+          auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - ozk[Jl] : -(px - oxk[Jl]); };  // y^ x (p - o), component S
+          jb[2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
           const D sg0 = ldc(cp_dof_sigma, db + 0), sg1 = ldc(cp_dof_sigma, db + 1), sg2 = ldc(cp_dof_sigma, db + 2), sg4 = ldc(cp_dof_sigma, db + 4);
           jl[S][0] = sg0 * ent(p1x, p1z, LI<1>{}) - sg0 * ent(p2x, p2z, LI<1>{});
           jl[S][1] = -(sg1 * ent(p2x, p2z, LI<2>{}));
@@ -442,7 +478,7 @@ template <class B> struct Core {
           D cjl[4];
           lfor<0, 4>([&](auto dd) {
             constexpr int Dd = decltype(dd)::value;
-            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - k.oz[Dd + 1] : -(px - k.ox[Dd + 1]));
+            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - ozk[Dd + 1] : -(px - oxk[Dd + 1]));
             cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
           });
           const D cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
@@ -453,9 +489,9 @@ template <class B> struct Core {
             constexpr int Dd = decltype(dd)::value;
             jl[S][Dd] = B::sel(isc, cjl[Dd], B::sel(isl & (lj == Dd), lsgn, D(0.0)));
           });
-          jb[S][0] = B::sel(isc, D(ODD ? 1.0 : 0.0), D(0.0));
-          jb[S][1] = B::sel(isc, D(ODD ? 0.0 : 1.0), D(0.0));
-          jb[S][2] = B::sel(isc, cj2, D(0.0));
+          jb[0] = B::sel(isc, D(ODD ? 1.0 : 0.0), D(0.0));
+          jb[1] = B::sel(isc, D(ODD ? 0.0 : 1.0), D(0.0));
+          jb[2] = B::sel(isc, cj2, D(0.0));
           pos = B::sel(isc, dist, lpos);
           invw = B::sel(isc, cinvw, linvw);
         }
@@ -469,9 +505,9 @@ template <class B> struct Core {
         const D simp0 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3), B::sel(islim, D(cp_limit_solimp[0]), D(cp_contact_solimp[0])));
         const D simp1 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 1), B::sel(islim, D(cp_limit_solimp[1]), D(cp_contact_solimp[1])));
         const D simp2 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 2), B::sel(islim, D(cp_limit_solimp[2]), D(cp_contact_solimp[2])));
-        D vel = jb[S][0] * st.vb[0] + jb[S][1] * st.vb[1] + jb[S][2] * st.vb[2];
-        D bq = jb[S][0] * qsb[0] + jb[S][1] * qsb[1] + jb[S][2] * qsb[2];
-        D jw = jb[S][0] * st.wb[0] + jb[S][1] * st.wb[1] + jb[S][2] * st.wb[2];
+        D vel = jb[0] * st.vb[0] + jb[1] * st.vb[1] + jb[2] * st.vb[2];
+        D bq = jb[0] * qsb[0] + jb[1] * qsb[1] + jb[2] * qsb[2];
+        D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
         lfor<0, 5>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
           vel += jl[S][Dd] * st.vl[Dd]; bq += jl[S][Dd] * qsl[Dd]; jw += jl[S][Dd] * st.wl[Dd];
@@ -489,7 +525,7 @@ template <class B> struct Core {
         jar[S] = jw - aref;
         Rr[S] = B::sel(active, R, D(1.0));
         lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = B::sel(active, jl[S][Dd], D(0.0)); });
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[S][Bc] = B::sel(active, jb[S][Bc], D(0.0)); });
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = B::sel(active, jb[Bc], D(0.0)); });
         // z = L^-1 jl, u = jb - C' z, u~ = G u
         lfor<0, 5>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
@@ -502,7 +538,7 @@ template <class B> struct Core {
           constexpr int Bc = decltype(bb)::value;
           D a = 0.0;
           lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += mm.C[Jj][Bc] * z[S][Jj]; });
-          u[Bc] = jb[S][Bc] - a;
+          u[Bc] = jb[Bc] - a;
         });
         Gmul(fc, u, ut[S]);
       });
@@ -568,15 +604,18 @@ template <class B> struct Core {
         f[S] = B::sel(drop, D(0.0), f[S]);
         r[S] = B::sel(drop, D(0.0), r[S]) + bvec[S];
       });
-      // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = sum_j u~_j f_j is shared by the two lanes
-      D a0 = B::sel(drop, D(0.0), at[0]), a1 = B::sel(drop, D(0.0), at[1]), a2 = B::sel(drop, D(0.0), at[2]);
+      a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
+    }
+    // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = (a0, a1, a2) = sum_j u~_j f_j is shared by the two lanes
+    {
+      const D mu = CP_CONTACT_MU;
       const D scale = 1.0 / (CP_MEANINERTIA * LNV);
       M sweeping = go;
       const M isL = leg == 0;
       // wave-uniform "some environment has such a row" bits
       bool anyLim[2][4], anyPair[2][3];
-      lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; anyLim[0][Jj] = B::any(go & isL & (nlim > Jj)); anyLim[1][Jj] = B::any(go & !isL & (nlim > Jj)); });
-      lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & isL & (ncon > P)); anyPair[1][P] = B::any(go & !isL & (ncon > P)); });
+      lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; anyLim[0][Jj] = B::any(go & isL & (nlim > Jj)); anyLim[1][Jj] = B::any(go & (!isL) & (nlim > Jj)); });
+      lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & isL & (ncon > P)); anyPair[1][P] = B::any(go & (!isL) & (ncon > P)); });
       D acc = 0.0;
       // exchange of the step's contribution to a~ : (d0, d1, d2) is non-zero on the owner lane only
       auto share = [&](D d0, D d1, D d2) {
@@ -667,51 +706,96 @@ template <class B> struct Core {
         sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
       }
       out.niter = niter;
-      // ---- total generalised force g = tau + J' f
-      D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = taul[Dd]; });
-      lfor<0, CAP>([&](auto ss) {
-        constexpr int S = decltype(ss)::value;
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] += jl[S][Dd] * f[S]; });
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; sb[Bc] += jb[S][Bc] * f[S]; });
+    }
+    // ---- total generalised force g = tau + J' f, accumulated from the rows' geometry (no Jacobian rows kept across the solve):
+    // a force (Fx, Fz) at point p moves dof d (origin o_d, sign sigma_d) by sigma_d (Fx (pz - oz_d) - Fz (px - ox_d))
+    D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
+    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = taul[Dd]; });
+    {
+      D sg[5];
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sg[Dd] = ldc(cp_dof_sigma, db + Dd); });
+      auto push = [&](D Fx, D Fz, D px, D pz, auto jl_) {   // generalised force of (Fx, Fz) at p on the dof whose link is Kin link Jl
+        constexpr int Jl = decltype(jl_)::value;
+        return Fx * (pz - ozk[Jl]) - Fz * (px - oxk[Jl]);
+      };
+      // connect: +F at p1 on the rod (hip, rod), -F at p2 on the tarsus (hip, knee, ankle); F = (f[0], f[1])
+      const D Fx = f[0], Fz = f[1];
+      gl[0] += sg[0] * (push(Fx, Fz, p1x, p1z, LI<1>{}) - push(Fx, Fz, p2x, p2z, LI<1>{}));
+      gl[1] += -(sg[1] * push(Fx, Fz, p2x, p2z, LI<2>{}));
+      gl[2] += -(sg[2] * push(Fx, Fz, p2x, p2z, LI<3>{}));
+      gl[4] += sg[4] * push(Fx, Fz, p1x, p1z, LI<5>{});
+      sb[2] += cp_dof_sigma[2] * (push(Fx, Fz, p1x, p1z, LI<0>{}) - push(Fx, Fz, p2x, p2z, LI<0>{}));
+      // contact pairs: (x, z) force = (tangent row, normal row) at the contact point
+      lfor<0, 3>([&](auto pp) {
+        constexpr int P = decltype(pp)::value;
+        constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+        D px, pz, dist, cinvw; I depth;
+        lds.ld_pair(P, px, pz, dist, cinvw, depth);
+        const M isc = kind[N] == K_CN;
+        const D cfx = B::sel(isc, f[T], D(0.0)), cfz = B::sel(isc, f[N], D(0.0));
+        px = B::sel(isc, px, D(0.0)); pz = B::sel(isc, pz, D(0.0));
+        lfor<0, 4>([&](auto dd) {
+          constexpr int Dd = decltype(dd)::value;
+          gl[Dd] += B::sel(isc & (depth > Dd), sg[Dd] * push(cfx, cfz, px, pz, LI<Dd + 1>{}), D(0.0));
+        });
+        sb[0] += cfx; sb[1] += cfz;
+        sb[2] += cp_dof_sigma[2] * push(cfx, cfz, px, pz, LI<0>{});
       });
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = taub[Bc] + (sb[Bc] + B::swap(sb[Bc])); });
-      // qacc = M^-1 g (next warm start); mj_Euler's implicit joint damping: (M + h B) qacc' = g by a second block factorisation
-      // (only the leg blocks change: the base dofs are undamped)
-      D xb[3], xl[5];
-      minv_apply(fc, gb, gl, xb, xl);
-      D hb[3], hl[5];
-      if (integrate) {
-        Fact fh;
-        factor(mm, hdamp, true, fh);
-        minv_apply(fh, gb, gl, hb, hl);
-      }
-      lfor<0, 3>([&](auto bb) {
-        constexpr int Bc = decltype(bb)::value;
-        st.wb[Bc] = B::sel(go, xb[Bc], st.wb[Bc]);
-        if (integrate) {
-          const D vn = st.vb[Bc] + LH * hb[Bc];
-          st.vb[Bc] = B::sel(go, vn, st.vb[Bc]);
-          st.qb[Bc] = B::sel(go, st.qb[Bc] + LH * vn, st.qb[Bc]);
-        }
-      });
-      lfor<0, 5>([&](auto dd) {
-        constexpr int Dd = decltype(dd)::value;
-        st.wl[Dd] = B::sel(go, xl[Dd], st.wl[Dd]);
-        if (integrate) {
-          const D vn = st.vl[Dd] + LH * hl[Dd];
-          st.vl[Dd] = B::sel(go, vn, st.vl[Dd]);
-          st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
-        }
+      // joint limits: +-f on the limited dof
+      lfor<0, 4>([&](auto ljj) {
+        constexpr int LJ = decltype(ljj)::value;
+        constexpr int S = 7 - LJ;
+        D lpos, lsgn, linvw; I lj;
+        lds.ld_lim(LJ, lpos, lsgn, linvw, lj);
+        const M isl = kind[S] == K_LIM;
+        lfor<0, 4>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] += B::sel(isl & (lj == Dd), lsgn * f[S], D(0.0)); });
       });
     }
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = taub[Bc] + (sb[Bc] + B::swap(sb[Bc])); });
+    // qacc = M^-1 g (next warm start).  mj_Euler's implicit joint damping, (M + h B) qacc' = g, without a second factorisation:
+    // qacc' = (I + E)^-1 qacc with E = M^-1 h B a contraction whatever the pose (eigenvalues <= h B_d / (armature_d + joint
+    // inertia) = 0.0393 for this model; tests/test_implicit_damping_bound.py), so x <- qacc - E x from x = qacc converges with
+    // error 0.0393^n: DAMPING_SWEEPS = 12 leaves 1e-17.  The base dofs are undamped: E x only needs the leg part of x.
+    D xb[3], xl[5];
+    minv_apply(fc, gb, gl, xb, xl);
+    D hb[3], hl[5];
+    if (integrate) {
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; hb[Bc] = xb[Bc]; });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd]; });
+      const D zb[3] = {D(0.0), D(0.0), D(0.0)};
+      for (int it = 0; it < DAMPING_SWEEPS; it++) {
+        D dl[5], eb[3], el[5];
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; dl[Dd] = hdamp[Dd] * hl[Dd]; });
+        minv_apply(fc, zb, dl, eb, el);
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; hb[Bc] = xb[Bc] - eb[Bc]; });
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd] - el[Dd]; });
+      }
+    }
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      st.wb[Bc] = B::sel(go, xb[Bc], st.wb[Bc]);
+      if (integrate) {
+        const D vn = st.vb[Bc] + LH * hb[Bc];
+        st.vb[Bc] = B::sel(go, vn, st.vb[Bc]);
+        st.qb[Bc] = B::sel(go, st.qb[Bc] + LH * vn, st.qb[Bc]);
+      }
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      st.wl[Dd] = B::sel(go, xl[Dd], st.wl[Dd]);
+      if (integrate) {
+        const D vn = st.vl[Dd] + LH * hl[Dd];
+        st.vl[Dd] = B::sel(go, vn, st.vl[Dd]);
+        st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
+      }
+    });
   }
 
   // ------------------------------------------------------------------------------------------------ operational-space state
   // Cassie2d::GetOperationalSpaceState (Cassie2d.cpp:218-237) with the RBDL-semantics tables from the kinematics of the last
   // setState (quirks Q1/Q2): body site on both lanes, the own foot (mean of the two toe sites) per lane.
   static LEG_FN void opstate(const D (&kqb)[3], const D (&kql)[5], const D (&kvb)[3], const D (&kvl)[5], D (&body)[4], D (&foot)[4]) {
-    const I leg = B::leg();
+    const I leg = B::opq(B::leg());
     Kin k;
     fk<1>(kqb, kql, kvb, kvl, leg, k);
     const D bx = kqb[0] - cp_qpos0[0] + cp_link_off[1][0][0], bz = kqb[1] - cp_qpos0[1] + cp_link_off[1][0][1];
@@ -731,143 +815,6 @@ template <class B> struct Core {
 
   static LEG_FN M in_range(D x) { return B::fabs(x) <= FINITE_BOUND; }  // false for NaN and +-inf
 
-  // ------------------------------------------------------------------------------------------------ fused Env.step
-  // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (StepOsc / StepJacobian:
-  // the controller kernel wrote them).  act3: the own leg's action components (hip, knee, toe); a2own: this lane's share of
-  // sum(action^2) (cassie_stand2d.py reward).  valid: the lane's environment exists.
-  template <int MODE>
-  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, Lane& st, const D (&act3)[3], D a2own, M valid, Out& o) {
-    const I leg = B::leg();
-    const I db = leg * 5 + 3;
-    M live = valid;
-    o.set_state = (valid & !valid);
-    o.pend = 0; o.niter = 0;
-    o.do_reset = o.set_state; o.bad = o.set_state; o.done = o.set_state; o.stored = o.set_state;
-    o.reward = 0.0;
-    D ctl[3] = {D(0.0), D(0.0), D(0.0)};
-    SubOut so;
-    for (int sub = 0; sub < cfg.n_sub; sub++) {
-      D qb0[3], ql0[5], vb0[3], vl0[5];
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; qb0[Bc] = st.qb[Bc]; vb0[Bc] = st.vb[Bc]; });
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ql0[Dd] = st.ql[Dd]; vl0[Dd] = st.vl[Dd]; });
-      D cnew[3];
-      lfor<0, 3>([&](auto aa) {
-        constexpr int A_ = decltype(aa)::value;
-        constexpr int Dd = A_ == 2 ? 3 : A_;
-        if constexpr (MODE == 2) cnew[A_] = st.ctrl[A_];
-        else if constexpr (MODE == 0) cnew[A_] = 10.0 * (act3[A_] - ql0[Dd]) + 5.0 * (0.0 - vl0[Dd]);
-        else cnew[A_] = act3[A_];
-      });
-      substep(lds, st, cnew, live, true, so);
-      const M ovf = live & so.overflow;
-      o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);
-      live = live & !ovf;
-      // DynamicModel::setState of this substep (the pre-step state), ctrl, clock
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.kqb[Bc] = B::sel(live, qb0[Bc], st.kqb[Bc]); st.kvb[Bc] = B::sel(live, vb0[Bc], st.kvb[Bc]); });
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; st.kql[Dd] = B::sel(live, ql0[Dd], st.kql[Dd]); st.kvl[Dd] = B::sel(live, vl0[Dd], st.kvl[Dd]); });
-      lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; ctl[A_] = B::sel(live, cnew[A_], ctl[A_]); });
-      o.niter = o.niter + B::seli(live, so.niter, I(0));
-      st.time = B::sel(live, st.time + 0.0005, st.time);
-      o.set_state = o.set_state | live;
-      if (!B::any(live)) break;
-    }
-    lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; st.ctrl[A_] = B::sel(live, ctl[A_], st.ctrl[A_]); });
-    if (!cfg.want_obs) return;
-    // ---- end-of-step section
-    const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
-    D body[4], foot[4];
-    if (fix_kin) opstate(st.qb, st.ql, st.vb, st.vl, body, foot);
-    else opstate(st.kqb, st.kql, st.kvb, st.kvl, body, foot);
-    const D bodyx = body[0], zz = body[1], pitch = st.qb[2];
-    // obs[0..4] = z, pitch, xd, zd, pitchd ; own foot: x - bodyx, z, 0 (Q4), xd, zd, 0 (Q4)
-    auto fill_obs = [&](D (&ob)[5], D (&of)[6]) {
-      ob[0] = zz; ob[1] = pitch; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
-      of[0] = foot[0] - bodyx; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
-    };
-    fill_obs(o.body, o.foot);
-    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = 0.0; });
-    D reward = 0.0;
-    M done;
-    if (cfg.env_kind == 0) {
-      // reference-gait lookup (cassie2d_trajectory.py:16-19), reward (cassie2d.py:197-218); qstate is the reset pose unless
-      // FLAG_FIX_STALE_QSTATE (quirk Q3)
-      const double tmax = cfg.traj_tmax;
-      const I idx = B::toint(B::fmod(st.time, tmax) / tmax * (double)cfg.traj_n);
-      constexpr int COLS[9] = {0, 1, 2, 3, 4, 6, 8, 9, 11};
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = B::ldg(cfg.traj_qpos, idx * LNV + COLS[Ii]); });
-      const bool fixq = (cfg.flags & FLAG_FIX_STALE_QSTATE) != 0;
-      // joints 3,4,6 (left) and 8,9,11 (right): own hip + knee + toe, partner's by exchange; left first as in the reference
-      const D mine3 = fixq ? st.ql[0] + st.ql[1] + st.ql[3] : st.qst[0] + st.qst[1] + st.qst[3];
-      const D other3 = B::swap(mine3);
-      D j = B::sel(leg == 0, mine3, other3);
-      j = j + B::sel(leg == 0, other3, mine3);
-      D sum = 0.0;
-      lfor<3, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; sum += o.ref[Ii]; });
-      j = j - sum; j = B::exp(-(j * j));
-      D pp = bodyx + zz;
-      pp = pp - (o.ref[0] + o.ref[1]); pp = B::exp(-(pp * pp));
-      D oo = pitch;
-      oo = oo - o.ref[2]; oo = B::exp(-(oo * oo));
-      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
-      done = (zz < 0.6) | (zz > 1.2) | (reward < 0.6);
-    } else {
-      const D a2 = a2own + B::swap(a2own);
-      // m = (left foot x - bodyx + right foot x - bodyx) / 2, left first
-      const D fo = B::swap(o.foot[0]);
-      const D m = (B::sel(leg == 0, o.foot[0], fo) + B::sel(leg == 0, fo, o.foot[0])) / 2.0;
-      reward = 0.0;
-      reward = reward - 2.0 * (0.9 - zz) * (0.9 - zz);
-      reward = reward - 2.0 * m * m;
-      reward = reward + 1.0;
-      reward = reward - 0.001 * a2;
-      done = zz < 0.5;
-    }
-    // failure guard (MuJoCo's mj_checkPos / mj_checkVel): a state outside the finite range terminates the episode
-    M okl = in_range(st.qb[0]) & in_range(st.qb[1]) & in_range(st.qb[2]) & in_range(st.vb[0]) & in_range(st.vb[1]) & in_range(st.vb[2]);
-    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; okl = okl & in_range(st.ql[Dd]) & in_range(st.vl[Dd]); });
-    okl = okl & B::swapm(okl);
-    const M bad = live & ((!okl) | (!in_range(reward)));
-    o.bad = bad;
-    lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.body[Ii] = B::sel(bad, D(0.0), o.body[Ii]); });
-    lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.foot[Ii] = B::sel(bad, D(0.0), o.foot[Ii]); });
-    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; o.ref[Ii] = B::sel(bad, D(0.0), o.ref[Ii]); });
-    reward = B::sel(bad, D(0.0), reward);
-    done = done | bad;
-    if (cfg.auto_reset) {
-      // the reset below also clears every NaN carrier (warm start, ctrl, setState copies)
-      lfor<0, 3>([&](auto bb) {
-        constexpr int Bc = decltype(bb)::value;
-        st.wb[Bc] = B::sel(bad, D(0.0), st.wb[Bc]); st.kqb[Bc] = B::sel(bad, D(cp_env_qinit[Bc]), st.kqb[Bc]); st.kvb[Bc] = B::sel(bad, D(0.0), st.kvb[Bc]);
-        st.ctrl[Bc] = B::sel(bad, D(0.0), st.ctrl[Bc]);
-      });
-      lfor<0, 5>([&](auto dd) {
-        constexpr int Dd = decltype(dd)::value;
-        st.wl[Dd] = B::sel(bad, D(0.0), st.wl[Dd]); st.kql[Dd] = B::sel(bad, ldc(cp_env_qinit, db + Dd), st.kql[Dd]); st.kvl[Dd] = B::sel(bad, D(0.0), st.kvl[Dd]);
-      });
-      o.set_state = o.set_state | bad;
-    }
-    o.reward = reward; o.done = done; o.stored = live;
-    o.do_reset = live & done & (cfg.auto_reset != 0);
-    if (!B::any(o.do_reset)) return;
-    // ---- Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.qb[Bc] = B::sel(o.do_reset, D(cp_env_qinit[Bc]), st.qb[Bc]); st.vb[Bc] = B::sel(o.do_reset, D(0.0), st.vb[Bc]); });
-    lfor<0, 5>([&](auto dd) {
-      constexpr int Dd = decltype(dd)::value;
-      const D qi = ldc(cp_env_qinit, db + Dd);
-      st.ql[Dd] = B::sel(o.do_reset, qi, st.ql[Dd]); st.vl[Dd] = B::sel(o.do_reset, D(0.0), st.vl[Dd]); st.qst[Dd] = B::sel(o.do_reset, qi, st.qst[Dd]);
-    });
-    st.time = B::sel(o.do_reset, D(0.0), st.time);
-    substep(lds, st, st.ctrl, o.do_reset, false, so);   // the reset pose on the flat floor has 12 rows: never an overflow
-    // reset observation: 17 op-space values from the kinematics of the last setState (quirk Q2), pitch from the reset pose
-    if (fix_kin) opstate(st.qb, st.ql, st.vb, st.vl, body, foot);
-    else opstate(st.kqb, st.kql, st.kvb, st.kvl, body, foot);
-    {
-      const D bx2 = body[0];
-      o.rbody[0] = body[1]; o.rbody[1] = st.qb[2]; o.rbody[2] = body[2]; o.rbody[3] = body[3]; o.rbody[4] = st.vb[2];
-      o.rfoot[0] = foot[0] - bx2; o.rfoot[1] = foot[1]; o.rfoot[2] = 0.0; o.rfoot[3] = foot[2]; o.rfoot[4] = foot[3]; o.rfoot[5] = 0.0;
-    }
-  }
-
   // ------------------------------------------------------------------------------------------------ HBM <-> lane
   // Per-lane "pointers" (B::P: the lane's state record / action row / observation row ...); base-dof fields are read by both
   // lanes of an environment and written by the left lane only.
@@ -877,84 +824,191 @@ template <class B> struct Core {
     bool has_act, has_tobs;
   };
 
-  static LEG_FN void load_lane(typename B::P rec, Lane& st) {
-    const I leg = B::leg();
-    const I lo = leg * 5 + 3, ao = leg * 3;
-    lfor<0, 3>([&](auto bb) {
-      constexpr int Bc = decltype(bb)::value;
-      st.qb[Bc] = B::pld(rec, I(ES_Q + Bc)); st.vb[Bc] = B::pld(rec, I(ES_V + Bc)); st.wb[Bc] = B::pld(rec, I(ES_WS + Bc));
-      st.kqb[Bc] = 0.0; st.kvb[Bc] = 0.0;   // ES_KQ / ES_KV are not read: the first setState of the step overwrites them
-      st.ctrl[Bc] = B::pld(rec, ao + (ES_CTRL + Bc));
-    });
-    lfor<0, 5>([&](auto dd) {
-      constexpr int Dd = decltype(dd)::value;
-      st.ql[Dd] = B::pld(rec, lo + (ES_Q + Dd)); st.vl[Dd] = B::pld(rec, lo + (ES_V + Dd)); st.wl[Dd] = B::pld(rec, lo + (ES_WS + Dd));
-      st.kql[Dd] = 0.0; st.kvl[Dd] = 0.0;
-      st.qst[Dd] = B::pld(rec, lo + (ES_QSTATE + Dd));
-    });
-    st.time = B::pld(rec, I(ES_TIME));
-  }
-
-  static LEG_FN void store_lane(typename B::P rec, const Lane& st, const Out& o, M valid) {
-    const I leg = B::leg();
-    const I lo = leg * 5 + 3, ao = leg * 3;
-    const M left = valid & (leg == 0);
-    lfor<0, 3>([&](auto bb) {
-      constexpr int Bc = decltype(bb)::value;
-      B::pst(rec, I(ES_Q + Bc), st.qb[Bc], left); B::pst(rec, I(ES_V + Bc), st.vb[Bc], left); B::pst(rec, I(ES_WS + Bc), st.wb[Bc], left);
-      B::pst(rec, I(ES_KQ + Bc), st.kqb[Bc], left & o.set_state); B::pst(rec, I(ES_KV + Bc), st.kvb[Bc], left & o.set_state);
-      B::pst(rec, ao + (ES_CTRL + Bc), st.ctrl[Bc], valid);
-    });
-    lfor<0, 5>([&](auto dd) {
-      constexpr int Dd = decltype(dd)::value;
-      B::pst(rec, lo + (ES_Q + Dd), st.ql[Dd], valid); B::pst(rec, lo + (ES_V + Dd), st.vl[Dd], valid); B::pst(rec, lo + (ES_WS + Dd), st.wl[Dd], valid);
-      B::pst(rec, lo + (ES_KQ + Dd), st.kql[Dd], valid & o.set_state); B::pst(rec, lo + (ES_KV + Dd), st.kvl[Dd], valid & o.set_state);
-      B::pst(rec, lo + (ES_QSTATE + Dd), st.qst[Dd], valid & o.do_reset);
-    });
-    // qstate of the base dofs: reset writes qinit there too (only ever read back by the general kernels' record copy)
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; B::pst(rec, I(ES_QSTATE + Bc), D(cp_env_qinit[Bc]), left & o.do_reset); });
-    B::pst(rec, I(ES_TIME), st.time, left);
-    B::pst(rec, I(ES_NITER), B::toD(o.niter), left);
-    B::pst(rec, I(ES_QPWSET), D(0.0), left & o.do_reset);   // new episode: cold start of the OSC QP too
-  }
-
-  // one Env.step of the lane's environment: load, step, outputs, write-back.  Returns through `o` what the caller still has to do
-  // (pending count, failure-guard counter).
+  // ------------------------------------------------------------------------------------------------ fused Env.step
+  // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (StepOsc / StepJacobian:
+  // the controller kernel wrote them).  valid: the lane's environment exists.  One loop, ONE copy of the substep code: passes
+  // 0..n_sub-1 are the physics substeps; the end-of-step section computes observation / reward / termination and stores them; if
+  // any environment of the wave terminated, one more pass (mj_forward only, on the reset pose, for those environments) leaves
+  // the reset observation.  On return `o` says what the caller still has to do (pending count, failure-guard counter).
   template <int MODE>
-  static LEG_FN void env_step_io(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o) {
+  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o) {
     const I leg = B::leg();
+    const I lo = leg * 5 + 3, ao = leg * 3;
+    const M left = leg == 0;
     Lane st;
-    load_lane(io.rec, st);
-    D act3[3] = {D(0.0), D(0.0), D(0.0)};
-    D a2own = 0.0;
-    if (io.has_act) {
-      if constexpr (MODE != 2) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; act3[A_] = B::pld(io.act, leg * 3 + A_); });
+    // ---- load: hot part to registers, cold part to the lane's LDS slots (ES_KQ / ES_KV are not read: the first setState of the
+    // step overwrites them)
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      st.qb[Bc] = B::pld(io.rec, I(ES_Q + Bc)); st.vb[Bc] = B::pld(io.rec, I(ES_V + Bc)); st.wb[Bc] = B::pld(io.rec, I(ES_WS + Bc));
+      lds.cst(C_CTRL + Bc, B::pld(io.rec, ao + (ES_CTRL + Bc)), valid | !valid);
+      D a = 0.0;
+      if (io.has_act && MODE != 2) a = B::pld(io.act, ao + Bc);
+      lds.cst(C_ACT + Bc, a, valid | !valid);
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      st.ql[Dd] = B::pld(io.rec, lo + (ES_Q + Dd)); st.vl[Dd] = B::pld(io.rec, lo + (ES_V + Dd)); st.wl[Dd] = B::pld(io.rec, lo + (ES_WS + Dd));
+      lds.cst(C_QST + Dd, B::pld(io.rec, lo + (ES_QSTATE + Dd)), valid | !valid);
+    });
+    lds.cst(C_TIME, B::pld(io.rec, I(ES_TIME)), valid | !valid);
+    {
       // sum(action^2) of cassie_stand2d.py's reward: the own leg's three components; component 6 (OSC) rides on the left lane
-      if (cfg.env_kind != 0) {
-        lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; const D a = B::pld(io.act, leg * 3 + A_); a2own += a * a; });
-        if (cfg.adim == 7) { const D a = B::pld(io.act, I(6)); a2own += B::sel(leg == 0, a * a, D(0.0)); }
+      D a2own = 0.0;
+      if (io.has_act && cfg.env_kind != 0) {
+        lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; const D a = B::pld(io.act, ao + A_); a2own += a * a; });
+        if (cfg.adim == 7) { const D a = B::pld(io.act, I(6)); a2own += B::sel(left, a * a, D(0.0)); }
       }
+      lds.cst(C_A2, a2own, valid | !valid);
     }
-    env_step<MODE>(cfg, lds, st, act3, a2own, valid, o);
-    if (cfg.want_obs) {
-      const M left = leg == 0;
-      auto put = [&](typename B::P row, const D (&ob)[5], const D (&of)[6], M m) {
+    M live = valid;
+    o.set_state = (valid & !valid);
+    o.pend = 0; o.niter = 0;
+    o.do_reset = o.set_state; o.bad = o.set_state;
+    const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
+    bool reset_pass = false;
+    int sub = 0;
+    SubOut so;
+    while (true) {
+      substep<MODE>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so);
+      if (!reset_pass) {
+        const M ovf = live & so.overflow;
+        o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);   // hand the rest of this environment to the next kernel tier
+        live = live & !ovf;
+        o.niter = o.niter + B::seli(live, so.niter, I(0));
+        o.set_state = o.set_state | live;
+        sub++;
+        if (sub < cfg.n_sub && B::any(live)) continue;
+      }
+      if (!cfg.want_obs) break;
+      // ---- end-of-step section: operational-space state from the kinematics of the last setState (quirks Q1/Q2)
+      D body[4], foot[4];
+      {
+        D kqb[3], kql[5], kvb[3], kvl[5];
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; kqb[Bc] = fix_kin ? st.qb[Bc] : lds.cld(C_KQ + Bc); kvb[Bc] = fix_kin ? st.vb[Bc] : lds.cld(C_KV + Bc); });
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; kql[Dd] = fix_kin ? st.ql[Dd] : lds.cld(C_KQ + 3 + Dd); kvl[Dd] = fix_kin ? st.vl[Dd] : lds.cld(C_KV + 3 + Dd); });
+        opstate(kqb, kql, kvb, kvl, body, foot);
+      }
+      const D bodyx = body[0], zz = body[1], pitch = st.qb[2];
+      // obs[0..4] = z, pitch, xd, zd, pitchd ; own foot at obs[5 + 6 leg ..]: x - bodyx, z, 0 (Q4), xd, zd, 0 (Q4)
+      D ob[5], of[6];
+      ob[0] = zz; ob[1] = pitch; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
+      of[0] = foot[0] - bodyx; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
+      auto put = [&](typename B::P row, M m) {
         lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, I(Ii), ob[Ii], m & left); });
         lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, leg * 6 + (5 + Ii), of[Ii], m); });
       };
-      if (io.has_tobs) {
-        put(io.tobs, o.body, o.foot, o.stored);
-        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.tobs, I(17 + Ii), o.ref[Ii], o.stored & !left); });
+      if (reset_pass) {
+        // Cassie2dEnv.reset returns the 17 op-space values; the trajectory slots of the observation are zero there
+        put(io.obs, o.do_reset);
+        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), o.do_reset & !left); });
+        break;
       }
-      put(io.obs, o.body, o.foot, o.stored);
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), o.ref[Ii], o.stored & !left); });
-      B::pst(io.rew, I(0), o.reward, o.stored & left);
-      B::pst8(io.done, o.done, o.stored & left);
-      // Cassie2dEnv.reset returns the 17 op-space values; the trajectory slots of the observation are zero there
-      put(io.obs, o.rbody, o.rfoot, o.do_reset);
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), o.do_reset & !left); });
+      D ref[9];
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = 0.0; });
+      D reward = 0.0;
+      M done;
+      if (cfg.env_kind == 0) {
+        // reference-gait lookup (cassie2d_trajectory.py:16-19), reward (cassie2d.py:197-218); qstate is the reset pose unless
+        // FLAG_FIX_STALE_QSTATE (quirk Q3)
+        const double tmax = cfg.traj_tmax;
+        const I idx = B::toint(B::fmod(lds.cld(C_TIME), tmax) / tmax * (double)cfg.traj_n);
+        constexpr int COLS[9] = {0, 1, 2, 3, 4, 6, 8, 9, 11};
+        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::ldg(cfg.traj_qpos, idx * LNV + COLS[Ii]); });
+        const bool fixq = (cfg.flags & FLAG_FIX_STALE_QSTATE) != 0;
+        // joints 3,4,6 (left) and 8,9,11 (right): own hip + knee + toe, partner's by exchange; left first as in the reference
+        const D mine3 = fixq ? st.ql[0] + st.ql[1] + st.ql[3] : lds.cld(C_QST + 0) + lds.cld(C_QST + 1) + lds.cld(C_QST + 3);
+        const D other3 = B::swap(mine3);
+        D j = B::sel(left, mine3, other3);
+        j = j + B::sel(left, other3, mine3);
+        D sum = 0.0;
+        lfor<3, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; sum += ref[Ii]; });
+        j = j - sum; j = B::exp(-(j * j));
+        D pp = bodyx + zz;
+        pp = pp - (ref[0] + ref[1]); pp = B::exp(-(pp * pp));
+        D oo = pitch;
+        oo = oo - ref[2]; oo = B::exp(-(oo * oo));
+        reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+        done = (zz < 0.6) | (zz > 1.2) | (reward < 0.6);
+      } else {
+        const D a2own = lds.cld(C_A2);
+        const D a2 = a2own + B::swap(a2own);
+        // m = (left foot x - bodyx + right foot x - bodyx) / 2, left first
+        const D fo = B::swap(of[0]);
+        const D m = (B::sel(left, of[0], fo) + B::sel(left, fo, of[0])) / 2.0;
+        reward = 0.0;
+        reward = reward - 2.0 * (0.9 - zz) * (0.9 - zz);
+        reward = reward - 2.0 * m * m;
+        reward = reward + 1.0;
+        reward = reward - 0.001 * a2;
+        done = zz < 0.5;
+      }
+      // failure guard (MuJoCo's mj_checkPos / mj_checkVel): a state outside the finite range terminates the episode
+      M okl = in_range(st.qb[0]) & in_range(st.qb[1]) & in_range(st.qb[2]) & in_range(st.vb[0]) & in_range(st.vb[1]) & in_range(st.vb[2]);
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; okl = okl & in_range(st.ql[Dd]) & in_range(st.vl[Dd]); });
+      okl = okl & B::swapm(okl);
+      const M bad = live & ((!okl) | (!in_range(reward)));
+      o.bad = bad;
+      lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ob[Ii] = B::sel(bad, D(0.0), ob[Ii]); });
+      lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; of[Ii] = B::sel(bad, D(0.0), of[Ii]); });
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::sel(bad, D(0.0), ref[Ii]); });
+      reward = B::sel(bad, D(0.0), reward);
+      done = done | bad;
+      if (cfg.auto_reset) {
+        // the reset below also clears every NaN carrier (warm start, ctrl, setState copies)
+        lfor<0, 3>([&](auto bb) {
+          constexpr int Bc = decltype(bb)::value;
+          st.wb[Bc] = B::sel(bad, D(0.0), st.wb[Bc]);
+          lds.cst(C_KQ + Bc, D(cp_env_qinit[Bc]), bad); lds.cst(C_KV + Bc, D(0.0), bad);
+          lds.cst(C_CTRL + Bc, D(0.0), bad);
+        });
+        lfor<0, 5>([&](auto dd) {
+          constexpr int Dd = decltype(dd)::value;
+          st.wl[Dd] = B::sel(bad, D(0.0), st.wl[Dd]);
+          lds.cst(C_KQ + 3 + Dd, ldc(cp_env_qinit, lo + Dd), bad); lds.cst(C_KV + 3 + Dd, D(0.0), bad);
+        });
+        o.set_state = o.set_state | bad;
+      }
+      if (io.has_tobs) {
+        put(io.tobs, live);
+        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.tobs, I(17 + Ii), ref[Ii], live & !left); });
+      }
+      put(io.obs, live);
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), ref[Ii], live & !left); });
+      B::pst(io.rew, I(0), reward, live & left);
+      B::pst8(io.done, done, live & left);
+      o.do_reset = live & done & (cfg.auto_reset != 0);
+      if (!B::any(o.do_reset)) break;
+      // ---- Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.qb[Bc] = B::sel(o.do_reset, D(cp_env_qinit[Bc]), st.qb[Bc]); st.vb[Bc] = B::sel(o.do_reset, D(0.0), st.vb[Bc]); });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        const D qi = ldc(cp_env_qinit, lo + Dd);
+        st.ql[Dd] = B::sel(o.do_reset, qi, st.ql[Dd]); st.vl[Dd] = B::sel(o.do_reset, D(0.0), st.vl[Dd]);
+        lds.cst(C_QST + Dd, qi, o.do_reset);
+      });
+      lds.cst(C_TIME, D(0.0), o.do_reset);
+      reset_pass = true;   // the reset pose on the flat floor has 12 rows: never an overflow
     }
-    store_lane(io.rec, st, o, valid);
+    // ---- state write-back
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      const M lv = valid & left;
+      B::pst(io.rec, I(ES_Q + Bc), st.qb[Bc], lv); B::pst(io.rec, I(ES_V + Bc), st.vb[Bc], lv); B::pst(io.rec, I(ES_WS + Bc), st.wb[Bc], lv);
+      B::pst(io.rec, I(ES_KQ + Bc), lds.cld(C_KQ + Bc), lv & o.set_state); B::pst(io.rec, I(ES_KV + Bc), lds.cld(C_KV + Bc), lv & o.set_state);
+      B::pst(io.rec, ao + (ES_CTRL + Bc), lds.cld(C_CTRL + Bc), valid);
+      // qstate of the base dofs: reset writes qinit there too (only the general kernels' record copy ever reads it back)
+      B::pst(io.rec, I(ES_QSTATE + Bc), D(cp_env_qinit[Bc]), lv & o.do_reset);
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      B::pst(io.rec, lo + (ES_Q + Dd), st.ql[Dd], valid); B::pst(io.rec, lo + (ES_V + Dd), st.vl[Dd], valid); B::pst(io.rec, lo + (ES_WS + Dd), st.wl[Dd], valid);
+      B::pst(io.rec, lo + (ES_KQ + Dd), lds.cld(C_KQ + 3 + Dd), valid & o.set_state); B::pst(io.rec, lo + (ES_KV + Dd), lds.cld(C_KV + 3 + Dd), valid & o.set_state);
+      B::pst(io.rec, lo + (ES_QSTATE + Dd), lds.cld(C_QST + Dd), valid & o.do_reset);
+    });
+    B::pst(io.rec, I(ES_TIME), lds.cld(C_TIME), valid & left);
+    B::pst(io.rec, I(ES_NITER), B::toD(o.niter), valid & left);
+    B::pst(io.rec, I(ES_QPWSET), D(0.0), valid & left & o.do_reset);   // new episode: cold start of the OSC QP too
   }
 };
 

@@ -52,6 +52,9 @@ struct HostB {
   struct Lds {
     double pr[3][4][2]; int pdepth[3][2];
     double lm[4][3][2]; int lmj[4][2];
+    double cold[cassie::leg::Core<HostB>::C_N][2];
+    VD cld(int i) const { VD r; r.v[0] = cold[i][0]; r.v[1] = cold[i][1]; return r; }
+    void cst(int i, VD v, VM m) { for (int l = 0; l < 2; l++) if (m.v[l]) cold[i][l] = v.v[l]; }
     void st_pair(VI slot, VD px, VD pz, VD dist, VD invw, VI depth, VM m) {
       for (int l = 0; l < 2; l++) if (m.v[l]) { int s = slot.v[l]; pr[s][0][l] = px.v[l]; pr[s][1][l] = pz.v[l]; pr[s][2][l] = dist.v[l]; pr[s][3][l] = invw.v[l]; pdepth[s][l] = depth.v[l]; }
     }
@@ -66,6 +69,8 @@ struct HostB {
     }
   };
   static VI leg() { VI r; r.v[0] = 0; r.v[1] = 1; return r; }
+  static VI opq(VI x) { return x; }
+  static int zs() { return 0; }
   static VD sel(VM m, VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VI seli(VM m, VI a, VI b) { VI r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VD swap(VD x) { VD r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
@@ -121,9 +126,9 @@ int leg_host_step(double* state, const double* actions, int n, int adim, int mod
     io.done.p[0] = io.done.p[1] = done ? done + e : &dummy8;
     VM valid; valid.v[0] = valid.v[1] = true;
     HCore::Out o;
-    if (mode == 0) HCore::env_step_io<0>(cfg, lds, io, valid, o);
-    else if (mode == 1) HCore::env_step_io<1>(cfg, lds, io, valid, o);
-    else HCore::env_step_io<2>(cfg, lds, io, valid, o);
+    if (mode == 0) HCore::env_step<0>(cfg, lds, io, valid, o);
+    else if (mode == 1) HCore::env_step<1>(cfg, lds, io, valid, o);
+    else HCore::env_step<2>(cfg, lds, io, valid, o);
     if (pending) pending[e] = o.pend.v[0];
     if (nonfinite && o.bad.v[0]) (*nonfinite)++;
   }
