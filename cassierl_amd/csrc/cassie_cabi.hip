@@ -241,6 +241,8 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   // Below LEG_MIN_ENVS the 4-environments-per-wavefront kernel (8x more wavefronts, two per SIMD) has the shorter critical path.
   h->leg = h->g16 && n_envs >= LEG_MIN_ENVS;
   { const char* e = getenv("CASSIE2D_LEG"); if (e && (e[0] == '0' || e[0] == '1')) h->leg = h->g16 && e[0] == '1'; }
+  if (h->cfg.flags & CASSIE_LEG_TIER_OFF) h->leg = false;
+  if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   L2::init_state(n_envs, h->stream, h->state);

@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     if (l < NU) st2[ES_CTRL + l] = sm.ctrl[l];
     if (l == 0) {
       st2[ES_TIME] = sm.tim[0]; st2[ES_NITER] = (double)niter_sum; pending[e2] = pend;
-      if (pend > 0 && p.stats) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
+      if (pend > 0 && p.stats && !p.pending) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);   // counted once, by the first tier
     }
   }
   PHASE_MARK(pc, 0);

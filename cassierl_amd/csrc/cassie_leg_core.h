@@ -630,10 +630,10 @@ template <class B> struct Core {
         D d = -(res * Ainv[S]);
         D chg = d * (0.5 * Adiag[S] * d + res);
         d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
+        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
         acc += chg;
         f[S] = f[S] + d;
         lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
-        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
       };
       auto lim_step = [&](auto ss, M owner) {
         constexpr int S = decltype(ss)::value;
@@ -644,11 +644,14 @@ template <class B> struct Core {
         D chg = d * (0.5 * Adiag[S] * d + res);
         const M keep = mine & (chg <= 1e-10);
         d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
         acc += chg;
         f[S] = f[S] + d;
         lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
-        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
       };
+      // 1 / (f' A f) of the ray update of pair P: a function of the pair's own force only, which nothing but the pair's own step
+      // changes -- so it is formed at the head of the sweep, off the chain that runs from step to step through a~.
+      D rden[3];
       auto pair_step = [&](auto pp, M owner) {
         constexpr int P = decltype(pp)::value;
         constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
@@ -659,11 +662,9 @@ template <class B> struct Core {
         const D Ann = Adiag[N], Att = Adiag[T], Ant_ = Ant[P];
         // normal-only update (taken when the normal force is ~0)
         const D fn_n = B::fmax(on - rn * Ainv[N], D(0.0));
-        // ray update
-        const D denom = on * (Ann * on + Ant_ * ot) + ot * (Ant_ * on + Att * ot);
-        D x = -(on * rn + ot * rt) * B::rcp(denom);
+        // ray update; rden = 0 where f' A f < MINVAL
+        D x = -(on * rn + ot * rt) * rden[P];
         x = B::fmax(x, D(-1.0));
-        x = B::sel(denom >= LMINVAL, x, D(0.0));
         const M use_n = on < LMINVAL;
         D fn = B::sel(use_n, fn_n, on + x * on);
         D ft = B::sel(use_n, D(0.0), ot + x * ot);
@@ -676,21 +677,31 @@ template <class B> struct Core {
         const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
         ft = B::sel(fn >= LMINVAL, ftc, ft);
         D dn = fn - on, dt = ft - ot;
-        D chg = 0.5 * (Ann * dn * dn + 2.0 * Ant_ * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
+        // 1/2 d'A d + d'res, grouped so that few operations wait for the tangent step
+        D chg = dt * (0.5 * Att * dt + (Ant_ * dn + rt)) + dn * (0.5 * Ann * dn + rn);
         const M keep = mine & (chg <= 1e-10);
         dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+        // the exchange first (its latency is what the next step waits for), the own rows' residuals behind it
+        share(ut[N][0] * dn + ut[T][0] * dt, ut[N][1] * dn + ut[T][1] * dt, ut[N][2] * dn + ut[T][2] * dt);
         acc += chg;
         f[N] = f[N] + dn; f[T] = f[T] + dt;
         lfor<0, CAP>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
           r[Ii] = r[Ii] + Al[symidx(CAP, Ii, N)] * dn + Al[symidx(CAP, Ii, T)] * dt;
         });
-        share(ut[N][0] * dn + ut[T][0] * dt, ut[N][1] * dn + ut[T][1] * dt, ut[N][2] * dn + ut[T][2] * dt);
+      };
+      auto ray_den = [&](auto pp) {
+        constexpr int P = decltype(pp)::value;
+        constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+        const D on = f[N], ot = f[T];
+        const D denom = on * (Adiag[N] * on + Ant[P] * ot) + ot * (Ant[P] * on + Adiag[T] * ot);
+        rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
       };
       I niter = 0;
       for (int iter = 0; iter < CP_ITERATIONS; iter++) {
         if (!B::any(sweeping)) break;
         acc = 0.0;
+        ray_den(LI<0>{}); ray_den(LI<1>{}); ray_den(LI<2>{});
         eq_step(LI<0>{}, isL); eq_step(LI<1>{}, isL);
         eq_step(LI<0>{}, !isL); eq_step(LI<1>{}, !isL);
         lfor<0, 2>([&](auto ww) {

@@ -41,6 +41,8 @@ extern "C" {
 #define CASSIE_WAVE_PER_ENV 4 /* use only the wave-per-environment kernels (A/B and cross-check of the 4-envs-per-wave path) */
 #define CASSIE_NO_PINV_SHORTCUT 8 /* tests: controllers evaluate pseudoinverse(.,tol) by SVD / eigen-decomposition even where the
                                     certified inverse / normal-equations shortcut applies (same result) */
+#define CASSIE_LEG_TIER_OFF 16 /* never start with the two-lanes-per-environment kernel (A/B, cross-check) */
+#define CASSIE_LEG_TIER_ON 32  /* always start with it, also below the batch size where it pays (tests) */
 
 #define CASSIE_NQ 13
 #define CASSIE_NOBS 26
