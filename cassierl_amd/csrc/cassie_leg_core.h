@@ -617,9 +617,14 @@ template <class B> struct Core {
       lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; anyLim[0][Jj] = B::any(go & isL & (nlim > Jj)); anyLim[1][Jj] = B::any(go & (!isL) & (nlim > Jj)); });
       lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & isL & (ncon > P)); anyPair[1][P] = B::any(go & (!isL) & (ncon > P)); });
       D acc = 0.0;
-      // exchange of the step's contribution to a~ : (d0, d1, d2) is non-zero on the owner lane only
-      auto share = [&](D d0, D d1, D d2) {
-        a0 = a0 + (d0 + B::swap(d0)); a1 = a1 + (d1 + B::swap(d1)); a2 = a2 + (d2 + B::swap(d2));
+      // a~ is kept per lane.  MuJoCo's row order groups the rows of a leg into blocks (connect L | connect R | limits L | limits R
+      // | contacts L | contacts R): inside a block only the owner lane's steps change a~ -- the other lane's deltas are zero, its
+      // copy stays at the value both lanes shared when the block began -- so the lanes exchange a~ once per BLOCK (the bystander
+      // copies the owner's value: `sync`), not once per step: 12 instructions per block instead of 15 per step, and no DPP move on
+      // the chain that runs from one step to the next.
+      auto share = [&](D d0, D d1, D d2) { a0 = a0 + d0; a1 = a1 + d1; a2 = a2 + d2; };
+      auto sync = [&](M owner) {
+        a0 = B::sel(owner, a0, B::swap(a0)); a1 = B::sel(owner, a1, B::swap(a1)); a2 = B::sel(owner, a2, B::swap(a2));
       };
       // a connect row (slots 0, 1).  Reduced form: no clamp and no cost-increase revert -- for an unclamped row d = -res / A exactly
       // minimises its own quadratic, the change is -res^2 / (2 A) <= 0, so mj_solPGS's revert can never fire (see cassie_kernels_g16.hip).
@@ -703,14 +708,22 @@ template <class B> struct Core {
         acc = 0.0;
         ray_den(LI<0>{}); ray_den(LI<1>{}); ray_den(LI<2>{});
         eq_step(LI<0>{}, isL); eq_step(LI<1>{}, isL);
+        sync(isL);
         eq_step(LI<0>{}, !isL); eq_step(LI<1>{}, !isL);
+        sync(!isL);
         lfor<0, 2>([&](auto ww) {
           constexpr int W = decltype(ww)::value;
-          lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[W][Jj]) lim_step(LI<7 - Jj>{}, W == 0 ? isL : !isL); });
+          if (anyLim[W][0]) {   // limit j exists only if limit j - 1 does
+            lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[W][Jj]) lim_step(LI<7 - Jj>{}, W == 0 ? isL : !isL); });
+            sync(W == 0 ? isL : !isL);
+          }
         });
         lfor<0, 2>([&](auto ww) {
           constexpr int W = decltype(ww)::value;
-          lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[W][P]) pair_step(LI<P>{}, W == 0 ? isL : !isL); });
+          if (anyPair[W][0]) {
+            lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[W][P]) pair_step(LI<P>{}, W == 0 ? isL : !isL); });
+            sync(W == 0 ? isL : !isL);
+          }
         });
         const D improvement = -(acc + B::swap(acc));
         niter = niter + B::toI(sweeping);
