@@ -32,7 +32,7 @@ struct DevB {
   struct Lds {
     double pr[3][4][64];
     double lm[4][3][64];
-    double cold[29][64];   // Core::C_* slots
+    double cold[49][64];   // Core::C_* slots
     int pdepth[3][64];
     int lmj[4][64];
     LEG_FN double cld(int i) const { return cold[i][threadIdx.x]; }
@@ -59,6 +59,7 @@ struct DevB {
     }
   };
   static LEG_FN int leg() { return (int)threadIdx.x & 1; }
+  static LEG_FN void fence() { __builtin_amdgcn_sched_barrier(0); }   // nothing is scheduled across this point
   static LEG_FN int opq(int x) { asm volatile("" : "+v"(x)); return x; }     // the value, unknown to the optimiser
   static LEG_FN int zs() { int z = 0; asm volatile("" : "+s"(z)); return z; }  // a wave-uniform zero, unknown to the optimiser
   static LEG_FN double sel(bool m, double a, double b) { return m ? a : b; }

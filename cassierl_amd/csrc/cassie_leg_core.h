@@ -88,7 +88,12 @@ template <class B> struct Core {
     C_TIME = 24,  // env clock
     C_ACT = 25,   // 3: this step's action components of the own leg's actuators
     C_A2 = 28,    // this lane's share of sum(action^2) (cassie_stand2d.py reward)
-    C_N = 29
+    // per-substep values that are produced before the solve and consumed after it (parked here across the PGS sweeps)
+    C_TAUB = 29,  // 3: smooth generalised force, base dofs
+    C_TAUL = 32,  // 5: ... own leg
+    C_OX = 37,    // 6: link origins (Kin numbering) relative to the pelvis origin, x
+    C_OZ = 43,    // 6: ... z
+    C_N = 49
   };
   struct Out {
     M do_reset, bad, set_state;
@@ -352,119 +357,125 @@ template <class B> struct Core {
     // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
     const I leg = B::opq(B::leg());
     const I db = leg * 5 + 3;
-    D taub[3], taul[5], hdamp[5];
     Fact fc;
-    D qsb[3], qsl[5];
-    D oxk[6], ozk[6];           // link origins (kept for the generalised-force accumulation after the solve)
     D p1x, p1z, p2x, p2z;       // connect anchors
     I nlim = 0, ncon = 0;
     M go;
     // ---- rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
     D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP];
-    D Ant[3], AttInv[3];
+    D Ant[3];
     I kind[CAP];
     D a0, a1, a2;
     {
-      Kin k;
-      fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+      D qsb[3], qsl[5];
       Mass mm;
-      mass_bias<0>(k, leg, mm);
-      lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; oxk[J] = k.ox[J]; ozk[J] = k.oz[J]; });
-      // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
-      D cu[3];
-      lfor<0, 3>([&](auto aa) {
-        constexpr int A_ = decltype(aa)::value;
-        constexpr int Dd = A_ == 2 ? 3 : A_;
-        if (from_rec) cu[A_] = lds.cld(C_CTRL + A_);
-        else if constexpr (MODE == 0) cu[A_] = 10.0 * (lds.cld(C_ACT + A_) - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
-        else cu[A_] = lds.cld(C_ACT + A_);
-      });
-      // smooth force: passive damping, bias, actuation (ctrl clamped to ctrlrange, times gear)
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; });
-      lfor<0, 5>([&](auto dd) {
-        constexpr int Dd = decltype(dd)::value;
-        const D damp = ldc(cp_dof_damping, db + Dd);
-        hdamp[Dd] = LH * damp;
-        D t = -damp * st.vl[Dd] - mm.biasl[Dd];
-        if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
-          constexpr int A_ = Dd == 3 ? 2 : Dd;
-          const I ai = leg * 3 + A_;
-          const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
-          const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
-          t = t + ldc(cp_act_gear, ai) * u;
-        }
-        taul[Dd] = t;
-      });
-      factor(mm, fc);
-      minv_apply(fc, taub, taul, qsb, qsl);
-
-      // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
-      const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
-      lfor<0, 4>([&](auto jj) {
-        constexpr int Jj = decltype(jj)::value;
-        const D qd = st.ql[Jj];
-        const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
-        const D dlo = qd - lo, dhi = hi - qd;
-        const M act = (dlo < 0.0) | (dhi < 0.0);
-        const D pos = B::sel(dlo < 0.0, dlo, dhi);
-        const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
-        lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
-        nlim = nlim + B::toI(act);
-      });
-      lfor<0, 9>([&](auto cc) {
-        constexpr int Cc = decltype(cc)::value;
-        constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
-        const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
-        D cx, cz;
-        link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
-        const D dist = basez + cz - ldc(cp_sph_r, sph);
-        M act = dist < 0.0;
-        if constexpr (Cc == 0) act = act & (leg == 0);
-        // contact point: half-way into the penetration, on the vertical through the sphere centre
-        lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
-        ncon = ncon + B::toI(act);
-      });
+      {
+        Kin k;
+        fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+        mass_bias<0>(k, leg, mm);
+        lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; lds.cst(C_OX + J, k.ox[J], live | !live); lds.cst(C_OZ + J, k.oz[J], live | !live); });
+        // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
+        const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+        lfor<0, 4>([&](auto jj) {
+          constexpr int Jj = decltype(jj)::value;
+          const D qd = st.ql[Jj];
+          const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
+          const D dlo = qd - lo, dhi = hi - qd;
+          const M act = (dlo < 0.0) | (dhi < 0.0);
+          const D pos = B::sel(dlo < 0.0, dlo, dhi);
+          const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
+          lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
+          nlim = nlim + B::toI(act);
+        });
+        lfor<0, 9>([&](auto cc) {
+          constexpr int Cc = decltype(cc)::value;
+          constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
+          const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
+          D cx, cz;
+          link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
+          const D dist = basez + cz - ldc(cp_sph_r, sph);
+          M act = dist < 0.0;
+          if constexpr (Cc == 0) act = act & (leg == 0);
+          // contact point: half-way into the penetration, on the vertical through the sphere centre
+          lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
+          ncon = ncon + B::toI(act);
+        });
+        // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
+        const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
+        link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
+        link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
+      }
+      B::fence();
       const I nrows = nlim + ncon * 2 + 2;
       M ovf = live & (nrows > CAP);
       ovf = ovf | B::swapm(ovf);
       out.overflow = ovf;
       go = live & !ovf;
       out.go = go;
-      if (integrate) {
-        // DynamicModel::setState of this substep (pre-step state), mj_data->ctrl, env clock -- for environments that carry it out
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.cst(C_KQ + Bc, st.qb[Bc], go); lds.cst(C_KV + Bc, st.vb[Bc], go); });
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.cst(C_KQ + 3 + Dd, st.ql[Dd], go); lds.cst(C_KV + 3 + Dd, st.vl[Dd], go); });
-        if (!from_rec) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; lds.cst(C_CTRL + A_, cu[A_], go); });
-        lds.cst(C_TIME, lds.cld(C_TIME) + 0.0005, go);
-      }
-
-      // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
       {
-        const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
-        link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
-        link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
+        // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
+        D cu[3];
+        lfor<0, 3>([&](auto aa) {
+          constexpr int A_ = decltype(aa)::value;
+          constexpr int Dd = A_ == 2 ? 3 : A_;
+          if (from_rec) cu[A_] = lds.cld(C_CTRL + A_);
+          else if constexpr (MODE == 0) cu[A_] = 10.0 * (lds.cld(C_ACT + A_) - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
+          else cu[A_] = lds.cld(C_ACT + A_);
+        });
+        if (integrate) {
+          // DynamicModel::setState of this substep (pre-step state), mj_data->ctrl, env clock -- for environments that carry it out
+          lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.cst(C_KQ + Bc, st.qb[Bc], go); lds.cst(C_KV + Bc, st.vb[Bc], go); });
+          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.cst(C_KQ + 3 + Dd, st.ql[Dd], go); lds.cst(C_KV + 3 + Dd, st.vl[Dd], go); });
+          if (!from_rec) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; lds.cst(C_CTRL + A_, cu[A_], go); });
+          lds.cst(C_TIME, lds.cld(C_TIME) + 0.0005, go);
+        }
+        // smooth force: passive damping, bias, actuation (ctrl clamped to ctrlrange, times gear)
+        D taub[3], taul[5];
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; lds.cst(C_TAUB + Bc, taub[Bc], live | !live); });
+        lfor<0, 5>([&](auto dd) {
+          constexpr int Dd = decltype(dd)::value;
+          D t = -ldc(cp_dof_damping, db + Dd) * st.vl[Dd] - mm.biasl[Dd];
+          if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
+            constexpr int A_ = Dd == 3 ? 2 : Dd;
+            const I ai = leg * 3 + A_;
+            const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
+            const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
+            t = t + ldc(cp_act_gear, ai) * u;
+          }
+          taul[Dd] = t;
+          lds.cst(C_TAUL + Dd, t, live | !live);
+        });
+        B::fence();
+        factor(mm, fc);
+        B::fence();
+        minv_apply(fc, taub, taul, qsb, qsl);
       }
-      D bvec[CAP], jar[CAP], Rr[CAP];
-      D jl[CAP][5], z[CAP][5];
+      B::fence();
+      // The rows are built one slot at a time: a row's z = L^-1 jl is kept (5 doubles per row), its Jacobian is not -- the entry
+      // A_ij of the leg block is z_i . jl_j, formed when row j >= i is built -- and its warm-start force is formed as soon as the
+      // row (for a contact pair: the tangent row) is complete, so nothing but z, u~, b and the packed A survives a slot.
+      D bvec[CAP], z[CAP][5];
+      D jar_prev = 0.0, Rr_prev = 1.0;   // the normal row's values while its tangent row is built
+      const D mu = CP_CONTACT_MU;
       lfor<0, CAP>([&](auto ss) {
         constexpr int S = decltype(ss)::value;
         D pos = 0.0, invw = 0.0;
-        D jb[3];
+        D jb[3], jl[5];
         I kd = K_NONE;
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = 0.0; });
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = 0.0; });
         jb[0] = 0.0; jb[1] = 0.0; jb[2] = 0.0;
         if constexpr (S < 2) {
           kd = K_EQ;
           invw = ldc(cp_eq_invweight, leg);
           pos = S == 0 ? p1x - p2x : p1z - p2z;
           // J = J(p1 on rod: pitch, hip, rod) - J(p2 on tarsus: pitch, hip, knee, ankle); the base slides cancel
-          auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - ozk[Jl] : -(px - oxk[Jl]); };  // y^ x (p - o), component S
+          auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - lds.cld(C_OZ + Jl) : -(px - lds.cld(C_OX + Jl)); };  // y^ x (p - o), component S
           jb[2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
           const D sg0 = ldc(cp_dof_sigma, db + 0), sg1 = ldc(cp_dof_sigma, db + 1), sg2 = ldc(cp_dof_sigma, db + 2), sg4 = ldc(cp_dof_sigma, db + 4);
-          jl[S][0] = sg0 * ent(p1x, p1z, LI<1>{}) - sg0 * ent(p2x, p2z, LI<1>{});
-          jl[S][1] = -(sg1 * ent(p2x, p2z, LI<2>{}));
-          jl[S][2] = -(sg2 * ent(p2x, p2z, LI<3>{}));
-          jl[S][4] = sg4 * ent(p1x, p1z, LI<5>{});
+          jl[0] = sg0 * ent(p1x, p1z, LI<1>{}) - sg0 * ent(p2x, p2z, LI<1>{});
+          jl[1] = -(sg1 * ent(p2x, p2z, LI<2>{}));
+          jl[2] = -(sg2 * ent(p2x, p2z, LI<3>{}));
+          jl[4] = sg4 * ent(p1x, p1z, LI<5>{});
         } else {
           constexpr int P = (S - 2) >> 1;     // contact pair that may live here
           constexpr int ODD = (S - 2) & 1;    // 0 normal (z row), 1 tangent (x row)
@@ -478,7 +489,7 @@ template <class B> struct Core {
           D cjl[4];
           lfor<0, 4>([&](auto dd) {
             constexpr int Dd = decltype(dd)::value;
-            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - ozk[Dd + 1] : -(px - oxk[Dd + 1]));
+            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - lds.cld(C_OZ + Dd + 1) : -(px - lds.cld(C_OX + Dd + 1)));
             cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
           });
           const D cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
@@ -487,7 +498,7 @@ template <class B> struct Core {
           if constexpr (LJ < 4) lds.ld_lim(LJ, lpos, lsgn, linvw, lj);
           lfor<0, 4>([&](auto dd) {
             constexpr int Dd = decltype(dd)::value;
-            jl[S][Dd] = B::sel(isc, cjl[Dd], B::sel(isl & (lj == Dd), lsgn, D(0.0)));
+            jl[Dd] = B::sel(isc, cjl[Dd], B::sel(isl & (lj == Dd), lsgn, D(0.0)));
           });
           jb[0] = B::sel(isc, D(ODD ? 1.0 : 0.0), D(0.0));
           jb[1] = B::sel(isc, D(ODD ? 0.0 : 1.0), D(0.0));
@@ -510,7 +521,7 @@ template <class B> struct Core {
         D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
         lfor<0, 5>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
-          vel += jl[S][Dd] * st.vl[Dd]; bq += jl[S][Dd] * qsl[Dd]; jw += jl[S][Dd] * st.wl[Dd];
+          vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd];
         });
         const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
         const D kk_ = 1.0 / (simp1 * simp1 * tc * tc * solref1 * solref1), bb_ = 2.0 / (simp1 * tc);
@@ -522,69 +533,63 @@ template <class B> struct Core {
         const D imp_own = B::sel(ist, impedance(simp0, simp1, simp2, D(0.0)), imp);
         const D aref = -bb_ * vel - kk_ * imp_own * own_pos;
         bvec[S] = B::sel(active, bq - aref, D(0.0));
-        jar[S] = jw - aref;
-        Rr[S] = B::sel(active, R, D(1.0));
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[S][Dd] = B::sel(active, jl[S][Dd], D(0.0)); });
+        const D jar = jw - aref;
+        const D Rr = B::sel(active, R, D(1.0));
+        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = B::sel(active, jl[Dd], D(0.0)); });
         lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = B::sel(active, jb[Bc], D(0.0)); });
         // z = L^-1 jl, u = jb - C' z, u~ = G u
         lfor<0, 5>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * jl[S][Jj]; });
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * jl[Jj]; });
           z[S][Ii] = a;
         });
         D u[3];
         lfor<0, 3>([&](auto bb) {
           constexpr int Bc = decltype(bb)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += mm.C[Jj][Bc] * z[S][Jj]; });
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Y[Jj][Bc] * jl[Jj]; });   // C' z = C' L^-1 jl = Y' jl
           u[Bc] = jb[Bc] - a;
         });
         Gmul(fc, u, ut[S]);
-      });
-      // own-leg block of A (R on the diagonal) and the full diagonal
-      lfor<0, CAP>([&](auto ii) {
-        constexpr int Ii = decltype(ii)::value;
-        lfor<Ii, CAP>([&](auto jj) {
-          constexpr int Jj = decltype(jj)::value;
+        // column S of the own-leg block of A (R on the diagonal) and the full diagonal entry
+        lfor<0, S + 1>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; a += jl[Ii][Dd] * z[Jj][Dd]; });
-          if constexpr (Ii == Jj) a += Rr[Ii];
-          Al[symidx(CAP, Ii, Jj)] = a;
+          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; a += z[Ii][Dd] * jl[Dd]; });
+          if constexpr (Ii == S) a += Rr;
+          Al[symidx(CAP, Ii, S)] = a;
         });
-        Adiag[Ii] = Al[symidx(CAP, Ii, Ii)] + (ut[Ii][0] * ut[Ii][0] + ut[Ii][1] * ut[Ii][1] + ut[Ii][2] * ut[Ii][2]);
-        Ainv[Ii] = 1.0 / Adiag[Ii];
-      });
-      lfor<0, 3>([&](auto pp) {
-        constexpr int P = decltype(pp)::value;
-        constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
-        Ant[P] = Al[symidx(CAP, N, T)] + (ut[N][0] * ut[T][0] + ut[N][1] * ut[T][1] + ut[N][2] * ut[T][2]);
-        AttInv[P] = 1.0 / Adiag[T];
-      });
-      // ---- warm start (mj_constraintUpdate from qacc_warmstart), kept only if its dual cost beats zero force
-      const D mu = CP_CONTACT_MU;
-      lfor<0, CAP>([&](auto ss) {
-        constexpr int S = decltype(ss)::value;
-        const D Dd_ = 1.0 / Rr[S];
+        Adiag[S] = Al[symidx(CAP, S, S)] + (ut[S][0] * ut[S][0] + ut[S][1] * ut[S][1] + ut[S][2] * ut[S][2]);
+        Ainv[S] = 1.0 / Adiag[S];
+        // warm start (mj_constraintUpdate from qacc_warmstart) of a single row; of a contact pair when its tangent row is complete
+        const D Dd_ = 1.0 / Rr;
         D fv = 0.0;
-        fv = B::sel(kind[S] == K_EQ, -Dd_ * jar[S], fv);
-        fv = B::sel((kind[S] == K_LIM) & (jar[S] < 0.0), -Dd_ * jar[S], fv);
-        if constexpr (S >= 2) {
-          constexpr int ODD = (S - 2) & 1;
-          constexpr int NS = S - ODD, TS = NS + 1;
-          const D jn = jar[NS], jt = jar[TS];
+        fv = B::sel(kd == K_EQ, -Dd_ * jar, fv);
+        fv = B::sel((kd == K_LIM) & (jar < 0.0), -Dd_ * jar, fv);
+        f[S] = fv;
+        if constexpr (S >= 3 && ((S - 2) & 1)) {
+          constexpr int NS = S - 1, P = (S - 2) >> 1;
+          const D jn = jar_prev, jt = jar;
+          const D Dn_ = 1.0 / Rr_prev;
           const D Nn = jn * mu, U1 = jt * mu, Tt = B::fabs(U1);
           const M top = (Nn >= mu * Tt) | ((Tt <= 0.0) & (Nn >= 0.0));
           const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
-          const D Dm = Dd_ / (mu * mu * (1.0 + mu * mu)), NmT = Nn - mu * Tt;
-          const D fnm = -Dm * NmT * mu;
-          const D ftm = -fnm / Tt * U1 * mu;
-          const D fn = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jn, fnm));
+          // middle zone: each row with its own D, as mj_constraintUpdate does (the two are equal: the pair shares its regulariser)
+          const D NmT = Nn - mu * Tt;
+          const D fnm_n = -(Dn_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
+          const D fnm_t = -(Dd_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
+          const D ftm = -fnm_t / Tt * U1 * mu;
+          const D fn = B::sel(top, D(0.0), B::sel(bot, -Dn_ * jn, fnm_n));
           const D ft = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jt, ftm));
-          fv = B::sel((kind[S] == K_CN) | (kind[S] == K_CT), ODD ? ft : fn, fv);
+          f[NS] = B::sel(kind[NS] == K_CN, fn, f[NS]);
+          f[S] = B::sel(kd == K_CT, ft, f[S]);
+          Ant[P] = Al[symidx(CAP, NS, S)] + (ut[NS][0] * ut[S][0] + ut[NS][1] * ut[S][1] + ut[NS][2] * ut[S][2]);
         }
-        f[S] = fv;
+        jar_prev = jar; Rr_prev = Rr;
+        B::fence();   // keep the scheduler from interleaving the slots (longer live ranges -> spills)
       });
+      B::fence();
       D at[3] = {D(0.0), D(0.0), D(0.0)};
       lfor<0, CAP>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
       lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
@@ -606,6 +611,7 @@ template <class B> struct Core {
       });
       a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
     }
+    B::fence();
     // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = (a0, a1, a2) = sum_j u~_j f_j is shared by the two lanes
     {
       const D mu = CP_CONTACT_MU;
@@ -675,7 +681,7 @@ template <class B> struct Core {
         D ft = B::sel(use_n, D(0.0), ot + x * ot);
         // friction on one dimension: unconstrained minimiser unless it leaves the cone
         const D bc = rt - Att * ot + Ant_ * (fn - on);
-        const D x0 = -bc * AttInv[P];
+        const D x0 = -bc * Ainv[T];
         const D v1 = x0 * (1.0 / mu);
         const D val = v1 * v1 - fn * fn;
         const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
@@ -731,11 +737,14 @@ template <class B> struct Core {
       }
       out.niter = niter;
     }
+    B::fence();
     // ---- total generalised force g = tau + J' f, accumulated from the rows' geometry (no Jacobian rows kept across the solve):
     // a force (Fx, Fz) at point p moves dof d (origin o_d, sign sigma_d) by sigma_d (Fx (pz - oz_d) - Fz (px - ox_d))
     D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
-    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = taul[Dd]; });
+    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = lds.cld(C_TAUL + Dd); });
     {
+      D oxk[6], ozk[6];
+      lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; oxk[J] = lds.cld(C_OX + J); ozk[J] = lds.cld(C_OZ + J); });
       D sg[5];
       lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sg[Dd] = ldc(cp_dof_sigma, db + Dd); });
       auto push = [&](D Fx, D Fz, D px, D pz, auto jl_) {   // generalised force of (Fx, Fz) at p on the dof whose link is Kin link Jl
@@ -775,18 +784,22 @@ template <class B> struct Core {
         lfor<0, 4>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] += B::sel(isl & (lj == Dd), lsgn * f[S], D(0.0)); });
       });
     }
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = taub[Bc] + (sb[Bc] + B::swap(sb[Bc])); });
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = lds.cld(C_TAUB + Bc) + (sb[Bc] + B::swap(sb[Bc])); });
     // qacc = M^-1 g (next warm start).  mj_Euler's implicit joint damping, (M + h B) qacc' = g, without a second factorisation:
     // qacc' = (I + E)^-1 qacc with E = M^-1 h B a contraction whatever the pose (eigenvalues <= h B_d / (armature_d + joint
     // inertia) = 0.0393 for this model; tests/test_implicit_damping_bound.py), so x <- qacc - E x from x = qacc converges with
     // error 0.0393^n: DAMPING_SWEEPS = 12 leaves 1e-17.  The base dofs are undamped: E x only needs the leg part of x.
+    B::fence();
     D xb[3], xl[5];
     minv_apply(fc, gb, gl, xb, xl);
+    B::fence();
     D hb[3], hl[5];
     if (integrate) {
       lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; hb[Bc] = xb[Bc]; });
       lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd]; });
       const D zb[3] = {D(0.0), D(0.0), D(0.0)};
+      D hdamp[5];
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hdamp[Dd] = LH * ldc(cp_dof_damping, db + Dd); });
       for (int it = 0; it < DAMPING_SWEEPS; it++) {
         D dl[5], eb[3], el[5];
         lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; dl[Dd] = hdamp[Dd] * hl[Dd]; });

@@ -70,6 +70,7 @@ struct HostB {
   };
   static VI leg() { VI r; r.v[0] = 0; r.v[1] = 1; return r; }
   static VI opq(VI x) { return x; }
+  static void fence() {}
   static int zs() { return 0; }
   static VD sel(VM m, VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VI seli(VM m, VI a, VI b) { VI r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
