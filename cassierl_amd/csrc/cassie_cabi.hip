@@ -121,7 +121,9 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
   const bool scripted = zpos != nullptr;
   if (mode != CASSIE_CTRL_OSC && mode != CASSIE_CTRL_JACOBIAN)
     return fail(h, CASSIE_EINVAL, "controller-in-the-loop stepping exists for OSC and Jacobian modes only");
-  if (h->hf.h) return fail(h, CASSIE_EINVAL, "a height field is set: only PD and torque control modes step on terrain");
+  // On terrain (rllab/envs/terrain_random.py rewrites the one MJCF every Step* variant loads) the controllers are what they are on
+  // the floor -- OSC_RBDL / StepJacobian work from the RBDL model and the foot SITES, they never see MuJoCo's contacts
+  // (OSC_RBDL.cpp:41-71, Cassie2d.cpp:119-209) -- and only the mj_step behind them collides with the height field.
   const int ctrl = mode == CASSIE_CTRL_OSC ? 2 : 3;
   if (h->g16 && !p.debug) {
     // Per StepOsc / StepJacobian: the packed controller kernel writes the motor commands into the state record, the packed
@@ -132,7 +134,14 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
       ps.n_sub = 1;
       if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
       L2::ctrl_g16(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
-      launch_physics_tiers(h, 2, ps);
+      if (h->hf.h) {
+        L2::step_g16_hf(2, h->n, h->stream, ps, h->pending);
+        cassie::VecParams pc = ps;
+        pc.pending = h->pending;
+        L2::step_k1_hf(2, h->n, h->stream, pc);
+      } else {
+        launch_physics_tiers(h, 2, ps);
+      }
     }
   } else {
     // wave-per-environment kernels only (CASSIE_WAVE_PER_ENV cross-check, debug record): same split, one wavefront per environment
@@ -142,7 +151,8 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
       if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
       L2::ctrl_k4(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
       ps.debug = nullptr;
-      L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, ps);
+      if (h->hf.h) L2::step_k1_hf(2, h->n, h->stream, ps);
+      else L2::step_k1(2, L2::K1_DEEP, h->n, h->stream, ps);
     }
   }
   HIPCHK(h, hipGetLastError());
@@ -152,8 +162,8 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
 int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
   const bool pdtq = mode == CASSIE_CTRL_PD || mode == CASSIE_CTRL_TORQUE;
   if (h->hf.h) {
-    // height-field terrain: PD / torque physics only (the controllers' contact model assumes the flat floor, OSC_RBDL.cpp:41-71)
-    if (!pdtq) return fail(h, CASSIE_EINVAL, "a height field is set: only PD and torque control modes step on terrain");
+    // height-field terrain: the 4-environments-per-wavefront and wave-per-environment kernels with the terrain collision stage
+    if (!pdtq) return launch_ctrl_step(h, mode, p, nullptr, nullptr);
     if (p.debug) return fail(h, CASSIE_EINVAL, "the debug substep has no height-field variant");
     if (h->g16) {
       L2::step_g16_hf(mode, h->n, h->stream, p, h->pending);

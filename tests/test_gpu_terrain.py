@@ -160,11 +160,99 @@ def test_zero_field_equals_flat_floor_and_field_can_be_removed(vec):
     a.close(); b.close()
 
 
-def test_controllers_refuse_terrain(vec):
-    env = vec(4, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
-    env.set_heightfield(np.zeros((4, 4)), 10.0, 10.0)
-    with pytest.raises(RuntimeError, match="height field"):
-        env.step_host(np.zeros((4, 7)))
-    env.set_heightfield(None)
-    env.step_host(np.zeros((4, 7)))
+def _py_standing_osc(o, zpos, zvel):
+    s = o.opstate(0)
+    act = np.zeros(7)
+    act[3] = 100.0 * (-5e-3 - s[7]); act[5] = 100.0 * (-5e-3 - s[13])
+    act[0] = 100.0 * ((s[6] + s[12]) / 2.0 - s[0]) + 20.0 * (0.0 - s[3])
+    act[1] = 100.0 * (zpos - s[1]) + 20.0 * (zvel - s[4])
+    act[6] = 20.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+    return act
+
+
+def _py_standing_jac(o, zpos, zvel):
+    s = o.opstate(0)
+    xt = (s[6] + s[12]) / 2.0
+    fx = 200.0 * (xt - s[0]) + 50.0 * (0.0 - s[3])
+    fz = max(0.5 * 9.806 * 31.0 + 200.0 * (zpos - s[1]) + 50.0 * (zvel - s[4]), 0.0)
+    my = 100.0 * (0.0 - s[2]) + 10.0 * (0.0 - s[5])
+    return np.array([fx, fz, my, fx, fz, my])
+
+
+@pytest.mark.parametrize("wave_per_env", [False, True])
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_controllers_step_on_the_ramp_teacher_forced(vec, oracle_mod, mode, wave_per_env):
+    """StepOsc / StepJacobian on terrain (rllab/envs/terrain_random.py:51-76 rewrites the MJCF every Step* variant loads,
+    Cassie2d.cpp:119-209): the controller is the flat-floor one -- it works from the RBDL model and the foot sites -- and the
+    mj_step behind it collides with the height field.  200 teacher-forced substeps of the scripted standing controllers' commands
+    on the flat part, across the kink and on the slope of the ramp: motor commands and states against the oracle."""
+    from cassierl_amd.vec_env import WAVE_PER_ENV
+    hm = T.ramp(nrow=64, ncol=2001, size_x=10.0, slope=0.1, x0=0.5)
+    shifts = [(-1.0, 0.0), (0.4, 0.0), (0.45, 0.002), (1.0, 0.05), (2.0, 0.15), (3.3, 0.28)]
+    os_ = _oracles(oracle_mod, hm, shifts)
+    n = len(os_)
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=WAVE_PER_ENV if wave_per_env else 0)
+    env.set_heightfield(hm, 10.0, 10.0)
+    worst, worst_u, sloped = 0.0, 0.0, 0
+    for t in range(200):
+        acts = np.array([(_py_standing_osc if mode == "OSC" else _py_standing_jac)(o, 0.9 + 0.03 * np.sin(0.02 * t), 0.0) for o in os_])
+        env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart(), ctrl=o.ctrl()) for o in os_]))
+        env.substep_host(mode, acts, 1)
+        sg = env.get_full_state_host()
+        for i, o in enumerate(os_):
+            (o.step_osc if mode == "OSC" else o.step_jacobian)(acts[i])
+            q1, v1 = o.state()
+            worst = max(worst, np.abs(sg[i, :13] - q1).max(), np.abs(sg[i, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+            worst_u = max(worst_u, np.abs(sg[i, 78:84] - o.ctrl()).max())
+            if o.ncon and np.abs(o.contacts()["frame"][:, 0]).max() > 0.05:
+                sloped += 1
+    assert worst < 1e-8 and worst_u < 1e-6, (worst, worst_u)
+    assert sloped > 200  # contacts with a tilted frame were really exercised
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
+def test_standing_controllers_hold_the_robot_on_the_slope_closed_loop(vec, oracle_mod, mode):
+    """Closed loop on the ramp: the scripted standing controller (device side, CassieVecStandingStep) keeps robots standing on the
+    flat part and on the 10 % slope for 400 substeps, and follows the oracle running the same law (free-running, 1e-5)."""
+    from cassierl_amd.vec_env import CONTROL_MODES
+    import torch
+    hm = T.ramp(nrow=64, ncol=2001, size_x=10.0, slope=0.1, x0=0.5)
+    shifts = [(-1.0, 0.0), (1.0, 0.05), (2.0, 0.15)]
+    os_ = _oracles(oracle_mod, hm, shifts)
+    n = len(os_)
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False)
+    env.set_heightfield(hm, 10.0, 10.0)
+    env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart(), ctrl=o.ctrl()) for o in os_]))
+    zp = torch.full((n,), 0.9, dtype=torch.float64, device="cuda")
+    zv = torch.zeros(n, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for t in range(40):
+        env._chk(env.L.CassieVecStandingStep(env.h, CONTROL_MODES[mode], zp.data_ptr(), zv.data_ptr(), 10))
+        for o in os_:
+            for _ in range(10):
+                a = (_py_standing_osc if mode == "OSC" else _py_standing_jac)(o, 0.9, 0.0)
+                (o.step_osc if mode == "OSC" else o.step_jacobian)(a)
+        sg = env.get_full_state_host()
+        for i, o in enumerate(os_):
+            worst = max(worst, rel_err(sg[i], *o.state()))
+    assert worst < 1e-5, worst
+    q = env.get_full_state_host()[:, :13]
+    assert (q[:, 1] > 0.7).all()   # nobody fell
+    env.close()
+
+
+def test_controllers_on_terrain_and_field_removal(vec):
+    """A zero field under the OSC controller is the flat floor; the field can be set and removed between steps."""
+    a = vec(4, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    b = vec(4, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
+    b.set_heightfield(np.zeros((4, 4)), 10.0, 10.0)
+    act = np.tile([0.5, -0.5, 0.0, 0.2, 0.0, 0.2, 0.1], (4, 1))
+    for _ in range(5):
+        oa, ra, da = a.step_host(act)
+        ob, rb, db = b.step_host(act)
+        assert np.abs(oa - ob).max() < 1e-9 and np.abs(ra - rb).max() < 1e-10
+    b.set_heightfield(None)
+    b.set_full_state_host(a.get_full_state_host())
+    assert np.array_equal(a.step_host(act)[0], b.step_host(act)[0])
+    a.close(); b.close()

@@ -160,3 +160,47 @@ def test_robot_settles_on_real_terrain(oracle_mod, png):
     assert np.isfinite(q).all() and np.isfinite(v).all()
     assert seen >= 3 and deepest > -0.03  # it lands ON the terrain: no sphere sinks more than 3 cm during the impacts
     assert q[1] < 0.8 + T.height_at(hm, 10, 10, q[0], 0.0)  # it fell
+
+
+def test_ridge_counter_example_where_the_slice_restatement_differs_from_a_closest_feature_test(oracle_mod):
+    """What the sagittal-slice restatement of the hfield collision gets WRONG, pinned by hand arithmetic.
+    MuJoCo collides a sphere with the prisms under it by its convex solver (mjc_ConvexHField): the contact refers to the
+    CLOSEST FEATURE of the surface -- a face, an edge or a vertex.  The restatement (oracle hfield_sphere = kernel terrain_sphere)
+    only ever tests the plane of the triangle under the sphere's CENTRE, extended without bound.  Counter-example: a convex ridge,
+    flat up to x0 and falling with slope -0.5 beyond it.  A toe sphere (r = 0.02) whose centre sits 2 mm past the ridge and
+    20.5 mm above the flat part is nearest to the ridge EDGE at (x0, 0): distance sqrt(0.002^2 + 0.0205^2) - 0.02 = +0.597 mm,
+    no contact.  The restatement measures the distance to the extended downhill plane, (0.0205 + 0.5 * 0.002) / sqrt(1.25)
+    - 0.02 = -0.770 mm: it reports a contact 1.37 mm early, with the face normal (0.5, 0, 1)/sqrt(1.25) instead of the
+    edge-to-centre direction.  (At a concave kink the error has the other sign: the neighbouring uphill face is touched before
+    the plane under the centre is.)  Both deviations are confined to a band of ~r sin(kink angle) around an edge of the relief."""
+    flat = oracle_mod.Oracle()
+    q0, _ = flat.state()
+    flat.set_state_raw(q0 - np.array([0, 0.002] + [0] * 11), np.zeros(13), np.zeros(13))   # dip the feet 2 mm into the floor plane
+    flat.forward()
+    c = flat.contacts()
+    assert flat.ncon == 4
+    centres = c["pos"] + np.array([0, 0, 1.0]) * (0.02 + 0.5 * c["dist"])[:, None]
+    front = centres[:, 0].max()
+    cz = centres[np.argmax(centres[:, 0]), 2] + 0.002            # centre height of the front toe sphere in the nominal pose
+    ncol = 4001                                                   # dx = 5 mm
+    xg = np.linspace(-10.0, 10.0, ncol)
+    x0 = xg[np.searchsorted(xg, front - 0.002) - 1]               # a grid line just behind the sphere centre ...
+    shift = (x0 + 0.002) - front                                  # ... and the robot moved so that the centre is 2 mm past it
+    hm = T.ramp(nrow=8, ncol=ncol, size_x=10.0, slope=-0.5, x0=x0)
+    o = oracle_mod.Oracle()
+    o.set_hfield(hm, 10.0, 10.0)
+    q = q0.copy()
+    q[0] += shift
+    q[1] += 0.0205 - cz
+    o.set_state_raw(q, np.zeros(13), np.zeros(13))
+    o.forward()
+    con = o.contacts()
+    # the restatement: both front toe spheres "touch" the extended downhill plane
+    assert o.ncon == 2
+    n_face = np.array([0.5, 0.0, 1.0]) / np.sqrt(1.25)
+    for i in range(2):
+        assert np.abs(con["frame"][i].reshape(3, 3)[0] - n_face).max() < 1e-12
+        assert abs(con["dist"][i] - ((0.0205 + 0.5 * 0.002) / np.sqrt(1.25) - 0.02)) < 1e-7   # the placement above is good to ~1e-8 m
+    # the closest-feature answer for the same sphere: the ridge edge, 0.597 mm away -- no contact
+    true_dist = np.hypot(0.002, 0.0205) - 0.02
+    assert true_dist > 5e-4 and con["dist"][0] < -7e-4
