@@ -28,6 +28,7 @@ struct DevB {
   typedef bool M;
   typedef double* P;
   typedef uint8_t* P8;
+  struct OwnerScope { LEG_FN OwnerScope(bool) {} };
   // per-lane slots: [slot][field][lane]
   struct Lds {
     double pr[3][4][64];

@@ -635,6 +635,7 @@ template <class B> struct Core {
       // a connect row (slots 0, 1).  Reduced form: no clamp and no cost-increase revert -- for an unclamped row d = -res / A exactly
       // minimises its own quadratic, the change is -res^2 / (2 A) <= 0, so mj_solPGS's revert can never fire (see cassie_kernels_g16.hip).
       auto eq_step = [&](auto ss, M owner) {
+        typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_EQ);
         const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
@@ -647,6 +648,7 @@ template <class B> struct Core {
         lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
       };
       auto lim_step = [&](auto ss, M owner) {
+        typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_LIM);
         const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
@@ -664,6 +666,7 @@ template <class B> struct Core {
       // changes -- so it is formed at the head of the sweep, off the chain that runs from step to step through a~.
       D rden[3];
       auto pair_step = [&](auto pp, M owner) {
+        typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int P = decltype(pp)::value;
         constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
         const M mine = owner & sweeping & (kind[N] == K_CN);

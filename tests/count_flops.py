@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Counted USEFUL arithmetic of one Env.step of the bench workload ("replace by a counted figure from an op-counting
+build") -- not a test.  The source of the two-lanes-per-environment kernel is compiled for the CPU with an operation-counting lane
+type (tests/host_emul/leg_host.cpp): +, -, * count 1 (a*b+c counts 2), /, sqrt, 1/x, exp count 1, sincos 2; comparisons, selects and
+data movement count 0; inside a Gauss-Seidel step only the lane of the leg that owns the row is counted.  The figure is therefore the
+arithmetic the ALGORITHM needs in this formulation, independent of how many lanes issue it -- to be read against the ISSUED FP64
+lane-flops the hardware counters give (profiles/<tag>_pmc.json): useful / issued is the share of issue slots doing needed work.
+Writes profiles/useful_flops.json (read by profiles/summarize_pmc.py -> bench.py's fp64_valu.useful_frac)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    import torch
+    import oracle_py as O
+    from conftest import state_vec
+    from leg_host import LegHostEnv, lib
+    from cassierl_amd import rollout as R
+    from cassierl_amd.trajectory import default_gait
+    g = default_gait()
+    out = {}
+    for name, kind, mode, seed, lo, hi in (("pd_bench", "walk", "PD", 1, np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)),
+                                           ("stand_torque_random", "stand", "Torque", 3, -np.array([12.2, 12.2, 0.9] * 2), np.array([12.2, 12.2, 0.9] * 2))):
+        n, steps = 16, 12
+        env = LegHostEnv(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+        env.set_trajectory(g.time, g.qpos)
+        oe = O.OracleEnv(kind, mode, traj=dict(time=g.time, qpos=g.qpos))
+        oe.reset()
+        q, v = oe.oracle.state()
+        ctor = O.Oracle()
+        env.set_full_state_host(np.tile(state_vec(q, v, oe.oracle.warmstart(), kq=ctor.state()[0], kv=ctor.state()[1], qstate=q), (n, 1)))
+        ids = torch.arange(n)
+        for t in range(4):   # spread the batch a little (the stand workload; the walk workload resets every step, quirk Q3)
+            env.step_host(R.random_actions(seed, ids, t, lo, hi).numpy())
+        lib().leg_host_ops()
+        sweeps = 0.0
+        for t in range(steps):
+            env.step_host(R.random_actions(seed, ids, 4 + t, lo, hi).numpy())
+            sweeps += env.state[:, 85].sum()
+        ops = lib().leg_host_ops()
+        out[name] = dict(flop_per_env_step=ops / (n * steps), pgs_sweeps_per_env_step=sweeps / (n * steps), envs=n, env_steps=steps,
+                         convention="+,-,* = 1 (a*b+c = 2); /, sqrt, 1/x, exp = 1; sincos = 2; compare/select/move = 0; in a Gauss-Seidel step only "
+                                    "the owner leg's lane counts; the reset pass of a terminated environment is included")
+        print(name, json.dumps(out[name]))
+    with open(os.path.join(ROOT, "profiles", "useful_flops.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

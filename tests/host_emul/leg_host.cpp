@@ -14,6 +14,14 @@
 
 namespace {
 
+// Op counting (tests/count_flops.py): every arithmetic operation on a lane value adds 1 per COUNTED lane (a*b+c is written as a
+// multiply and an add in the core: 2); divisions, square roots and reciprocals count 1, sincos 2, exp 1; comparisons and selects 0.
+// Inside a Gauss-Seidel step only the owner leg's lane is counted (the other lane executes the same instructions on values
+// that are thrown away); everywhere else both lanes are.
+double g_ops = 0.0;
+bool g_cnt[2] = {true, true};
+inline void ops(int k = 1) { g_ops += k * ((int)g_cnt[0] + (int)g_cnt[1]); }
+
 struct VM {
   bool v[2];
   VM() {}
@@ -29,7 +37,7 @@ struct VD {
   VD() {}
   VD(double a) { v[0] = v[1] = a; }
 };
-#define VD_BIN(op) inline VD operator op(const VD& a, const VD& b) { VD r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
+#define VD_BIN(op) inline VD operator op(const VD& a, const VD& b) { ops(); VD r; r.v[0] = a.v[0] op b.v[0]; r.v[1] = a.v[1] op b.v[1]; return r; }
 VD_BIN(+) VD_BIN(-) VD_BIN(*) VD_BIN(/)
 inline VD operator-(const VD& a) { VD r; r.v[0] = -a.v[0]; r.v[1] = -a.v[1]; return r; }
 inline VD& operator+=(VD& a, const VD& b) { a = a + b; return a; }
@@ -47,6 +55,11 @@ struct HostB {
   typedef VD D;
   typedef VI I;
   typedef VM M;
+  struct OwnerScope {
+    bool old[2];
+    OwnerScope(VM owner) { old[0] = g_cnt[0]; old[1] = g_cnt[1]; g_cnt[0] = owner.v[0]; g_cnt[1] = owner.v[1]; }
+    ~OwnerScope() { g_cnt[0] = old[0]; g_cnt[1] = old[1]; }
+  };
   struct P { double* p[2]; };
   struct P8 { uint8_t* p[2]; };
   struct Lds {
@@ -82,12 +95,12 @@ struct HostB {
   static VI toI(VM m) { VI r; r.v[0] = m.v[0]; r.v[1] = m.v[1]; return r; }
   static VD toD(VI i) { VD r; r.v[0] = i.v[0]; r.v[1] = i.v[1]; return r; }
   static VI toint(VD x) { VI r; r.v[0] = (int)x.v[0]; r.v[1] = (int)x.v[1]; return r; }
-  static void sincos(VD x, VD& s, VD& c) { for (int l = 0; l < 2; l++) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
-  static VD sqrt(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::sqrt(x.v[l]); return r; }
-  static VD rcp(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = 1.0 / x.v[l]; return r; }
+  static void sincos(VD x, VD& s, VD& c) { ops(2); for (int l = 0; l < 2; l++) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
+  static VD sqrt(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = std::sqrt(x.v[l]); return r; }
+  static VD rcp(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = 1.0 / x.v[l]; return r; }
   static VD fabs(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fabs(x.v[l]); return r; }
   static VD fmax(VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fmax(a.v[l], b.v[l]); return r; }
-  static VD exp(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::exp(x.v[l]); return r; }
+  static VD exp(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = std::exp(x.v[l]); return r; }
   static VD fmod(VD a, double b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fmod(a.v[l], b); return r; }
   static VD copysign(VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::copysign(a.v[l], b.v[l]); return r; }
   static VD pld(P p, VI off) { VD r; for (int l = 0; l < 2; l++) r.v[l] = p.p[l][off.v[l]]; return r; }
@@ -135,5 +148,8 @@ int leg_host_step(double* state, const double* actions, int n, int adim, int mod
   }
   return 0;
 }
+
+// arithmetic operations counted since the last call (see the note at g_ops)
+double leg_host_ops(void) { double r = g_ops; g_ops = 0.0; return r; }
 
 }  // extern "C"

@@ -25,6 +25,7 @@ def lib():
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
         _LIB = ct.CDLL(so)
+        _LIB.leg_host_ops.restype = ct.c_double
     return _LIB
 
 
