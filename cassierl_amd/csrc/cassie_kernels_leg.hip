@@ -36,6 +36,12 @@ struct DevB {
     double cold[49][64];   // Core::C_* slots
     int pdepth[3][64];
     int lmj[4][64];
+#ifdef CASSIE_PHASE_TIMING
+    unsigned long long t_last, acc[16];   // profiling builds: shader cycles per code phase of this wavefront (tests/phase_profile.py leg)
+    LEG_FN void mark(int k) { if (threadIdx.x == 0) { unsigned long long n = __builtin_readcyclecounter(); acc[k] += n - t_last; t_last = n; } }
+#else
+    LEG_FN void mark(int) {}
+#endif
     LEG_FN double cld(int i) const { return cold[i][threadIdx.x]; }
     LEG_FN void cst(int i, double v, bool m) { if (m) cold[i][threadIdx.x] = v; }
     LEG_FN void st_pair(int slot, double px, double pz, double dist, double invw, int depth, bool m) {
@@ -69,6 +75,11 @@ struct DevB {
   static LEG_FN int swapi(int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, false); }
   static LEG_FN double swap(double x) { return __hiloint2double(swapi(__double2hiint(x)), swapi(__double2loint(x))); }
   static LEG_FN bool swapm(bool m) { return swapi((int)m) != 0; }
+  // both lanes of every pair <- the pair's lane W (0 even = left, 1 odd = right): DPP quad_perm [0,0,2,2] / [1,1,3,3]
+  template <int W> static LEG_FN double pair_bcast(double x) {
+    constexpr int CTRL = W == 0 ? 0xA0 : 0xF5;
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, false), __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, false));
+  }
   static LEG_FN bool any(bool m) { return __ballot(m) != 0ull; }
   static LEG_FN double ldc(const double* t, int i) { return t[i]; }
   static LEG_FN double ldg(const double* t, int i) { return t[i]; }
@@ -119,8 +130,15 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   io.tobs = p.terminal_obs + (io.has_tobs ? e * 26 : 0);
   io.rew = p.reward + (cfg.want_obs ? e : 0);
   io.done = p.done + (cfg.want_obs ? e : 0);
+#ifdef CASSIE_PHASE_TIMING
+  if (lane == 0) { for (int i = 0; i < 16; i++) lds.acc[i] = 0; lds.t_last = __builtin_readcyclecounter(); }
+#endif
   DCore::Out o;
   DCore::env_step<MODE>(cfg, lds, io, valid, o);
+#ifdef CASSIE_PHASE_TIMING
+  lds.mark(0);
+  if (lane == 0 && p.phase) for (int i = 0; i < 16; i++) atomicAdd(p.phase + i, lds.acc[i]);
+#endif
   if (valid && (lane & 1) == 0) {
     pending[e] = o.pend;
     if (p.stats) {

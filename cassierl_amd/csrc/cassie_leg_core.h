@@ -361,6 +361,11 @@ template <class B> struct Core {
     D p1x, p1z, p2x, p2z;       // connect anchors
     I nlim = 0, ncon = 0;
     M go;
+    // The common configuration -- no joint limit active, at most two contact pairs per leg, in EVERY environment of the wavefront
+    // (robots on their feet) -- leaves slots 6 and 7 empty: those two row slots are not built and the sweeps touch six residuals per
+    // step instead of eight (no limit steps, no third pair).  Decided per wavefront, once per substep; the arithmetic of an
+    // environment is the same either way (the skipped work adds exact zeros to rows that nobody reads).
+    bool small;
     // ---- rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
     D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP];
     D Ant[3];
@@ -369,10 +374,13 @@ template <class B> struct Core {
     {
       D qsb[3], qsl[5];
       Mass mm;
+      lds.mark(0);
       {
         Kin k;
         fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+        lds.mark(1);
         mass_bias<0>(k, leg, mm);
+        lds.mark(2);
         lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; lds.cst(C_OX + J, k.ox[J], live | !live); lds.cst(C_OZ + J, k.oz[J], live | !live); });
         // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
         const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
@@ -406,12 +414,14 @@ template <class B> struct Core {
         link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
       }
       B::fence();
+      lds.mark(3);
       const I nrows = nlim + ncon * 2 + 2;
       M ovf = live & (nrows > CAP);
       ovf = ovf | B::swapm(ovf);
       out.overflow = ovf;
       go = live & !ovf;
       out.go = go;
+      small = !B::any(go & ((nlim > 0) | (ncon > 2)));
       {
         // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
         D cu[3];
@@ -451,6 +461,7 @@ template <class B> struct Core {
         minv_apply(fc, taub, taul, qsb, qsl);
       }
       B::fence();
+      lds.mark(2);
       // The rows are built one slot at a time: a row's z = L^-1 jl is kept (5 doubles per row), its Jacobian is not -- the entry
       // A_ij of the leg block is z_i . jl_j, formed when row j >= i is built -- and its warm-start force is formed as soon as the
       // row (for a contact pair: the tangent row) is complete, so nothing but z, u~, b and the packed A survives a slot.
@@ -590,6 +601,7 @@ template <class B> struct Core {
         B::fence();   // keep the scheduler from interleaving the slots (longer live ranges -> spills)
       });
       B::fence();
+      lds.mark(4);
       D at[3] = {D(0.0), D(0.0), D(0.0)};
       lfor<0, CAP>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
       lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
@@ -612,6 +624,7 @@ template <class B> struct Core {
       a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
     }
     B::fence();
+    lds.mark(6);
     // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = (a0, a1, a2) = sum_j u~_j f_j is shared by the two lanes
     {
       const D mu = CP_CONTACT_MU;
@@ -625,33 +638,36 @@ template <class B> struct Core {
       D acc = 0.0;
       // a~ is kept per lane.  MuJoCo's row order groups the rows of a leg into blocks (connect L | connect R | limits L | limits R
       // | contacts L | contacts R): inside a block only the owner lane's steps change a~ -- the other lane's deltas are zero, its
-      // copy stays at the value both lanes shared when the block began -- so the lanes exchange a~ once per BLOCK (the bystander
-      // copies the owner's value: `sync`), not once per step: 12 instructions per block instead of 15 per step, and no DPP move on
+      // copy stays at the value both lanes shared when the block began -- so the lanes exchange a~ once per BLOCK (both lanes take the
+      // owner lane's value by one DPP broadcast per word: `sync`), not once per step: 12 instructions per block instead of 15 per step, and no DPP move on
       // the chain that runs from one step to the next.
       auto share = [&](D d0, D d1, D d2) { a0 = a0 + d0; a1 = a1 + d1; a2 = a2 + d2; };
-      auto sync = [&](M owner) {
-        a0 = B::sel(owner, a0, B::swap(a0)); a1 = B::sel(owner, a1, B::swap(a1)); a2 = B::sel(owner, a2, B::swap(a2));
+      auto sync = [&](auto ww) {   // both lanes of every pair take the value of the owner's lane: one DPP broadcast per word
+        constexpr int W = decltype(ww)::value;
+        a0 = B::template pair_bcast<W>(a0); a1 = B::template pair_bcast<W>(a1); a2 = B::template pair_bcast<W>(a2);
       };
       // a connect row (slots 0, 1).  Reduced form: no clamp and no cost-increase revert -- for an unclamped row d = -res / A exactly
       // minimises its own quadratic, the change is -res^2 / (2 A) <= 0, so mj_solPGS's revert can never fire (see cassie_kernels_g16.hip).
-      auto eq_step = [&](auto ss, M owner) {
+      auto eq_step = [&](auto ss, M owner, auto nr_) {
+        constexpr int NR = decltype(nr_)::value;   // own-row slots in use in this wavefront (6 or CAP)
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_EQ);
-        const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
+        const D res = r[S] + ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2;
         D d = -(res * Ainv[S]);
         D chg = d * (0.5 * Adiag[S] * d + res);
         d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
         share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
         acc += chg;
         f[S] = f[S] + d;
-        lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
       };
-      auto lim_step = [&](auto ss, M owner) {
+      auto lim_step = [&](auto ss, M owner, auto nr_) {
+        constexpr int NR = decltype(nr_)::value;
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_LIM);
-        const D res = r[S] + (ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2);
+        const D res = r[S] + ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2;
         const D cand = B::fmax(f[S] - res * Ainv[S], D(0.0));
         D d = cand - f[S];
         D chg = d * (0.5 * Adiag[S] * d + res);
@@ -660,18 +676,19 @@ template <class B> struct Core {
         share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
         acc += chg;
         f[S] = f[S] + d;
-        lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
       };
       // 1 / (f' A f) of the ray update of pair P: a function of the pair's own force only, which nothing but the pair's own step
       // changes -- so it is formed at the head of the sweep, off the chain that runs from step to step through a~.
       D rden[3];
-      auto pair_step = [&](auto pp, M owner) {
+      auto pair_step = [&](auto pp, M owner, auto nr_) {
+        constexpr int NR = decltype(nr_)::value;
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int P = decltype(pp)::value;
         constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
         const M mine = owner & sweeping & (kind[N] == K_CN);
-        const D rn = r[N] + (ut[N][0] * a0 + ut[N][1] * a1 + ut[N][2] * a2);
-        const D rt = r[T] + (ut[T][0] * a0 + ut[T][1] * a1 + ut[T][2] * a2);
+        const D rn = r[N] + ut[N][0] * a0 + ut[N][1] * a1 + ut[N][2] * a2;
+        const D rt = r[T] + ut[T][0] * a0 + ut[T][1] * a1 + ut[T][2] * a2;
         const D on = f[N], ot = f[T];
         const D Ann = Adiag[N], Att = Adiag[T], Ant_ = Ant[P];
         // normal-only update (taken when the normal force is ~0)
@@ -699,7 +716,7 @@ template <class B> struct Core {
         share(ut[N][0] * dn + ut[T][0] * dt, ut[N][1] * dn + ut[T][1] * dt, ut[N][2] * dn + ut[T][2] * dt);
         acc += chg;
         f[N] = f[N] + dn; f[T] = f[T] + dt;
-        lfor<0, CAP>([&](auto ii) {
+        lfor<0, NR>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
           r[Ii] = r[Ii] + Al[symidx(CAP, Ii, N)] * dn + Al[symidx(CAP, Ii, T)] * dt;
         });
@@ -712,35 +729,44 @@ template <class B> struct Core {
         rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
       };
       I niter = 0;
-      for (int iter = 0; iter < CP_ITERATIONS; iter++) {
-        if (!B::any(sweeping)) break;
-        acc = 0.0;
-        ray_den(LI<0>{}); ray_den(LI<1>{}); ray_den(LI<2>{});
-        eq_step(LI<0>{}, isL); eq_step(LI<1>{}, isL);
-        sync(isL);
-        eq_step(LI<0>{}, !isL); eq_step(LI<1>{}, !isL);
-        sync(!isL);
-        lfor<0, 2>([&](auto ww) {
-          constexpr int W = decltype(ww)::value;
-          if (anyLim[W][0]) {   // limit j exists only if limit j - 1 does
-            lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[W][Jj]) lim_step(LI<7 - Jj>{}, W == 0 ? isL : !isL); });
-            sync(W == 0 ? isL : !isL);
+      auto sweeps = [&](auto nr_) {
+        constexpr int NR = decltype(nr_)::value;
+        constexpr int NPAIR = NR == CAP ? 3 : 2;
+        for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+          if (!B::any(sweeping)) break;
+          acc = 0.0;
+          lfor<0, NPAIR>([&](auto pp) { ray_den(pp); });
+          eq_step(LI<0>{}, isL, nr_); eq_step(LI<1>{}, isL, nr_);
+          sync(LI<0>{});
+          eq_step(LI<0>{}, !isL, nr_); eq_step(LI<1>{}, !isL, nr_);
+          sync(LI<1>{});
+          if constexpr (NR == CAP) {
+            lfor<0, 2>([&](auto ww) {
+              constexpr int W = decltype(ww)::value;
+              if (anyLim[W][0]) {   // limit j exists only if limit j - 1 does
+                lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[W][Jj]) lim_step(LI<7 - Jj>{}, W == 0 ? isL : !isL, nr_); });
+                sync(ww);
+              }
+            });
           }
-        });
-        lfor<0, 2>([&](auto ww) {
-          constexpr int W = decltype(ww)::value;
-          if (anyPair[W][0]) {
-            lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[W][P]) pair_step(LI<P>{}, W == 0 ? isL : !isL); });
-            sync(W == 0 ? isL : !isL);
-          }
-        });
-        const D improvement = -(acc + B::swap(acc));
-        niter = niter + B::toI(sweeping);
-        sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
-      }
+          lfor<0, 2>([&](auto ww) {
+            constexpr int W = decltype(ww)::value;
+            if (anyPair[W][0]) {
+              lfor<0, NPAIR>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[W][P]) pair_step(LI<P>{}, W == 0 ? isL : !isL, nr_); });
+              sync(ww);
+            }
+          });
+          const D improvement = -(acc + B::swap(acc));
+          niter = niter + B::toI(sweeping);
+          sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
+        }
+      };
+      if (small) sweeps(LI<6>{});
+      else sweeps(LI<CAP>{});
       out.niter = niter;
     }
     B::fence();
+    lds.mark(7);
     // ---- total generalised force g = tau + J' f, accumulated from the rows' geometry (no Jacobian rows kept across the solve):
     // a force (Fx, Fz) at point p moves dof d (origin o_d, sign sigma_d) by sigma_d (Fx (pz - oz_d) - Fz (px - ox_d))
     D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
@@ -829,6 +855,7 @@ template <class B> struct Core {
         st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
       }
     });
+    lds.mark(8);
   }
 
   // ------------------------------------------------------------------------------------------------ operational-space state

@@ -66,6 +66,7 @@ struct HostB {
     double pr[3][4][2]; int pdepth[3][2];
     double lm[4][3][2]; int lmj[4][2];
     double cold[cassie::leg::Core<HostB>::C_N][2];
+    void mark(int) {}
     VD cld(int i) const { VD r; r.v[0] = cold[i][0]; r.v[1] = cold[i][1]; return r; }
     void cst(int i, VD v, VM m) { for (int l = 0; l < 2; l++) if (m.v[l]) cold[i][l] = v.v[l]; }
     void st_pair(VI slot, VD px, VD pz, VD dist, VD invw, VI depth, VM m) {
@@ -88,6 +89,7 @@ struct HostB {
   static VD sel(VM m, VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VI seli(VM m, VI a, VI b) { VI r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VD swap(VD x) { VD r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
+  template <int W> static VD pair_bcast(VD x) { VD r; r.v[0] = r.v[1] = x.v[W]; return r; }
   static VM swapm(VM x) { VM r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
   static bool any(VM m) { return m.v[0] || m.v[1]; }
   static VD ldc(const double* t, VI i) { VD r; r.v[0] = t[i.v[0]]; r.v[1] = t[i.v[1]]; return r; }

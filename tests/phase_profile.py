@@ -39,7 +39,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "physics":
                  "3 active limits / contacts, row kinds", "4 constraint rows (J, aref, M^-1 J')", "5 A = J M^-1 J' + R", "6 warm start, initial residual",
                  "7 PGS sweeps", "8 J'f, qacc, implicit damping"]
         tot = v[:9].sum()
-        print("%s env, %s mode, %d envs: %.0f cycles per wavefront per Env.step" % (kind, mode, n, tot / (n / 4) / 20))
+        per_wave = 32 if os.environ.get("PHASE_LEG") else 4   # PHASE_LEG=1: the two-lanes-per-environment kernel is the one instrumented
+        print("%s env, %s mode, %d envs: %.0f cycles per wavefront per Env.step" % (kind, mode, n, tot / (n / per_wave) / 20))
         for i, nm in enumerate(names):
             print("  %-72s %6.2f %%" % (nm, 100 * v[i] / tot))
         env.close()
