@@ -29,6 +29,9 @@ struct DevB {
   typedef double* P;
   typedef uint8_t* P8;
   struct OwnerScope { LEG_FN OwnerScope(bool) {} };
+  typedef const double* K;   // the lane's row of cp_legk
+  static LEG_FN K kbase(int leg) { return &cp_legk[0][0] + leg * LK_N; }
+  static LEG_FN double kld(K k, int idx) { return k[idx]; }
   // per-lane slots: [slot][field][lane]
   struct Lds {
     double pr[3][4][64];
@@ -38,7 +41,13 @@ struct DevB {
     int lmj[4][64];
 #ifdef CASSIE_PHASE_TIMING
     unsigned long long t_last, acc[16];   // profiling builds: shader cycles per code phase of this wavefront (tests/phase_profile.py leg)
-    LEG_FN void mark(int k) { if (threadIdx.x == 0) { unsigned long long n = __builtin_readcyclecounter(); acc[k] += n - t_last; t_last = n; } }
+    LEG_FN void mark(int k) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long n = __builtin_readcyclecounter();
+      if (threadIdx.x == 0) { acc[k] += n - t_last; t_last = n; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #else
     LEG_FN void mark(int) {}
 #endif
@@ -66,7 +75,11 @@ struct DevB {
     }
   };
   static LEG_FN int leg() { return (int)threadIdx.x & 1; }
-  static LEG_FN void fence() { __builtin_amdgcn_sched_barrier(0); }   // nothing is scheduled across this point
+#ifdef LEG_NO_FENCE
+  static LEG_FN void fence() {}
+#else
+  static LEG_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif   // nothing is scheduled across this point
   static LEG_FN int opq(int x) { asm volatile("" : "+v"(x)); return x; }     // the value, unknown to the optimiser
   static LEG_FN int zs() { int z = 0; asm volatile("" : "+s"(z)); return z; }  // a wave-uniform zero, unknown to the optimiser
   static LEG_FN double sel(bool m, double a, double b) { return m ? a : b; }

@@ -35,6 +35,7 @@
 #define CASSIE_LEG_CORE_H_
 
 #include "cassie2d_planar.h"
+#include "cassie2d_legk.h"
 #include "cassie_vec_layout.h"
 
 #ifndef LEG_FN
@@ -48,6 +49,9 @@ constexpr int LNV = CP_NV;
 constexpr double LH = CP_TIMESTEP;
 constexpr double LMINVAL = 1e-15;
 constexpr int CAP = 8;  // constraint rows per leg
+#ifndef LEG_ITERS
+#define LEG_ITERS CP_ITERATIONS   // (timing experiments only: -DLEG_ITERS=n)
+#endif
 enum { K_NONE = 0, K_EQ = 1, K_LIM = 2, K_CN = 3, K_CT = 4 };
 
 template <int I_> struct LI { static constexpr int value = I_; };
@@ -106,13 +110,16 @@ template <class B> struct Core {
   };
 
   static LEG_FN D ldc(const double* t, I i) { return B::ldc(t, i); }
+  // model constant IDX of the lane's leg from the packed per-leg row (cassie2d_legk.h): base(leg) + a compile-time offset
+  typedef typename B::K KP_;
+  static LEG_FN D kc(KP_ K, int idx) { return B::kld(K, idx); }
 
   // parent of leg link j (1..5) in the Kin numbering
   static constexpr int kparent(int j) { return j == 1 ? 0 : (j == 5 ? 1 : j - 1); }
 
   // ------------------------------------------------------------------------------------------------ planar FK of one leg
   template <int SEM>
-  static LEG_FN void fk(const D (&qb)[3], const D (&ql)[5], const D (&vb)[3], const D (&vl)[5], I leg, Kin& k) {
+  static LEG_FN void fk(const D (&qb)[3], const D (&ql)[5], const D (&vb)[3], const D (&vl)[5], I leg, KP_ K, Kin& k) {   // K is read for SEM 0 only
     const I lb = leg * 5 + 1;      // first link of the leg in the model tables
     const I db = leg * 5 + 3;      // first dof of the leg
     D th[6];
@@ -121,8 +128,8 @@ template <class B> struct Core {
     lfor<1, 6>([&](auto jj) {
       constexpr int J = decltype(jj)::value;
       constexpr int P = kparent(J);
-      const D sg = ldc(cp_link_sigma, lb + (J - 1));
-      th[J] = th[P] + sg * (ql[J - 1] - ldc(cp_qpos0, db + (J - 1)));
+      const D sg = SEM == 0 ? kc(K, LK_LINK_SIGMA + J - 1) : ldc(cp_link_sigma, lb + (J - 1));
+      th[J] = th[P] + sg * (ql[J - 1] - (SEM == 0 ? kc(K, LK_QPOS0 + J - 1) : ldc(cp_qpos0, db + (J - 1))));
       k.w[J] = k.w[P] + sg * vl[J - 1];
     });
     lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; B::sincos(th[J], k.s[J], k.c[J]); });
@@ -133,7 +140,7 @@ template <class B> struct Core {
       constexpr int J = decltype(jj)::value;
       constexpr int P = kparent(J);
       const I li = (lb + (J - 1)) * 2 + SEM * (CP_NLINK * 2);
-      const D fx = ldc(&cp_link_off[0][0][0], li), fz = ldc(&cp_link_off[0][0][0], li + 1);
+      const D fx = SEM == 0 ? kc(K, LK_LINK_OFF + 2 * (J - 1)) : ldc(&cp_link_off[0][0][0], li), fz = SEM == 0 ? kc(K, LK_LINK_OFF + 2 * (J - 1) + 1) : ldc(&cp_link_off[0][0][0], li + 1);
       const D tx = k.c[P] * fx + k.s[P] * fz, tz = -k.s[P] * fx + k.c[P] * fz;
       const D pw = k.w[P];
       k.ox[J] = k.ox[P] + tx; k.oz[J] = k.oz[P] + tz;
@@ -144,8 +151,8 @@ template <class B> struct Core {
       constexpr int J = decltype(jj)::value;
       const I l = J == 0 ? I(0) : lb + (J - 1);
       const I ci = l * 2 + SEM * (CP_NLINK * 2);
-      const D cx0 = ldc(&cp_link_com[0][0][0], ci), cz0 = ldc(&cp_link_com[0][0][0], ci + 1);
-      const D m = ldc(cp_link_mass, l);
+      const D cx0 = SEM == 0 ? kc(K, LK_LINK_COM + 2 * J) : ldc(&cp_link_com[0][0][0], ci), cz0 = SEM == 0 ? kc(K, LK_LINK_COM + 2 * J + 1) : ldc(&cp_link_com[0][0][0], ci + 1);
+      const D m = SEM == 0 ? kc(K, LK_LINK_MASS + J) : ldc(cp_link_mass, l);
       const D rx = k.c[J] * cx0 + k.s[J] * cz0, rz = -k.s[J] * cx0 + k.c[J] * cz0;
       k.cx[J] = k.ox[J] + rx; k.cz[J] = k.oz[J] + rz;
       const D w2 = k.w[J] * k.w[J];
@@ -170,20 +177,20 @@ template <class B> struct Core {
   static constexpr bool anc(int i, int j) { return i == j || (i == 0) || (i == 1 && (j == 2 || j == 3)) || (i == 2 && j == 3); }
 
   template <int SEM>
-  static LEG_FN void mass_bias(const Kin& k, I leg, Mass& mm) {
+  static LEG_FN void mass_bias(const Kin& k, I leg, KP_ K, Mass& mm) {
     const I lb = leg * 5 + 1, db = leg * 5 + 3;
     D mass[6], inert[6];
     lfor<0, 6>([&](auto jj) {
       constexpr int J = decltype(jj)::value;
       const I l = J == 0 ? I(0) : lb + (J - 1);
-      mass[J] = ldc(cp_link_mass, l);
-      inert[J] = ldc(&cp_link_inertia[0][0], l + SEM * CP_NLINK);
+      mass[J] = SEM == 0 ? kc(K, LK_LINK_MASS + J) : ldc(cp_link_mass, l);
+      inert[J] = SEM == 0 ? kc(K, LK_LINK_INERTIA + J) : ldc(&cp_link_inertia[0][0], l + SEM * CP_NLINK);
     });
     D s1x[5], s1z[5], s2[5], sg[5];
     lfor<0, 5>([&](auto dd) {
       constexpr int Dd = decltype(dd)::value;
       const D odx = k.ox[Dd + 1], odz = k.oz[Dd + 1];
-      sg[Dd] = ldc(cp_dof_sigma, db + Dd);
+      sg[Dd] = SEM == 0 ? kc(K, LK_DOF_SIGMA + Dd) : ldc(cp_dof_sigma, db + Dd);
       D a1x = 0.0, a1z = 0.0, a2 = 0.0, bs = 0.0;
       lfor<1, 6>([&](auto ll) {
         constexpr int Lk = decltype(ll)::value;
@@ -205,7 +212,7 @@ template <class B> struct Core {
         if constexpr (anc(Ii, Jj)) {  // deep = Jj
           val = sg[Ii] * sg[Jj] * (s2[Jj] + (k.ox[Jj + 1] - k.ox[Ii + 1]) * s1x[Jj] + (k.oz[Jj + 1] - k.oz[Ii + 1]) * s1z[Jj]);
         }
-        if constexpr (Ii == Jj) val += ldc(cp_dof_armature, db + Ii);
+        if constexpr (Ii == Jj) val += SEM == 0 ? kc(K, LK_DOF_ARMATURE + Ii) : ldc(cp_dof_armature, db + Ii);
         mm.Ls[symidx(5, Ii, Jj)] = val;
       });
     });
@@ -343,7 +350,10 @@ template <class B> struct Core {
 
   // ------------------------------------------------------------------------------------------------ one mj_forward (+ Euler)
   struct SubOut { I niter; M overflow, go; };
-  constexpr static int DAMPING_SWEEPS = 12;
+#ifndef LEG_DAMPING_SWEEPS
+#define LEG_DAMPING_SWEEPS 12
+#endif
+  constexpr static int DAMPING_SWEEPS = LEG_DAMPING_SWEEPS;
 
   // `live` masks environments that must not be touched (identical on the two lanes of an environment).  `integrate` (wave-uniform)
   // = false gives mj_forward only (Cassie2d::Reset) and none of the per-substep bookkeeping.  `from_rec` (wave-uniform): the motor
@@ -356,7 +366,7 @@ template <class B> struct Core {
     // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
     // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
     const I leg = B::opq(B::leg());
-    const I db = leg * 5 + 3;
+    const KP_ K = B::kbase(leg);
     Fact fc;
     D p1x, p1z, p2x, p2z;       // connect anchors
     I nlim = 0, ncon = 0;
@@ -377,9 +387,9 @@ template <class B> struct Core {
       lds.mark(0);
       {
         Kin k;
-        fk<0>(st.qb, st.ql, st.vb, st.vl, leg, k);
+        fk<0>(st.qb, st.ql, st.vb, st.vl, leg, K, k);
         lds.mark(1);
-        mass_bias<0>(k, leg, mm);
+        mass_bias<0>(k, leg, K, mm);
         lds.mark(2);
         lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; lds.cst(C_OX + J, k.ox[J], live | !live); lds.cst(C_OZ + J, k.oz[J], live | !live); });
         // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
@@ -387,31 +397,29 @@ template <class B> struct Core {
         lfor<0, 4>([&](auto jj) {
           constexpr int Jj = decltype(jj)::value;
           const D qd = st.ql[Jj];
-          const D lo = ldc(&cp_jnt_range[0][0], (db + Jj) * 2), hi = ldc(&cp_jnt_range[0][0], (db + Jj) * 2 + 1);
+          const D lo = kc(K, LK_JNT_RANGE + 2 * Jj), hi = kc(K, LK_JNT_RANGE + 2 * Jj + 1);
           const D dlo = qd - lo, dhi = hi - qd;
           const M act = (dlo < 0.0) | (dhi < 0.0);
           const D pos = B::sel(dlo < 0.0, dlo, dhi);
           const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
-          lds.st_lim(nlim, pos, sgn, ldc(cp_dof_invweight0, db + Jj), I(Jj), act & (nlim < 4));
+          lds.st_lim(nlim, pos, sgn, kc(K, LK_DOF_INVWEIGHT + Jj), I(Jj), act & (nlim < 4));
           nlim = nlim + B::toI(act);
         });
         lfor<0, 9>([&](auto cc) {
           constexpr int Cc = decltype(cc)::value;
           constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
-          const I sph = Cc == 0 ? I(0) : leg * 8 + Cc;
           D cx, cz;
-          link_point<Lk>(k, ldc(&cp_sph_d[0][0], sph * 2), ldc(&cp_sph_d[0][0], sph * 2 + 1), cx, cz);
-          const D dist = basez + cz - ldc(cp_sph_r, sph);
+          link_point<Lk>(k, kc(K, LK_SPH_D + 2 * Cc), kc(K, LK_SPH_D + 2 * Cc + 1), cx, cz);
+          const D dist = basez + cz - kc(K, LK_SPH_R + Cc);
           M act = dist < 0.0;
           if constexpr (Cc == 0) act = act & (leg == 0);
           // contact point: half-way into the penetration, on the vertical through the sphere centre
-          lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, ldc(cp_sph_invweight, sph), I(Lk), act & (ncon < 3));
+          lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, kc(K, LK_SPH_INVWEIGHT + Cc), I(Lk), act & (ncon < 3));
           ncon = ncon + B::toI(act);
         });
         // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
-        const I e4 = leg * 4;   // cp_eq_d1[leg][sem 0][2]
-        link_point<5>(k, ldc(&cp_eq_d1[0][0][0], e4), ldc(&cp_eq_d1[0][0][0], e4 + 1), p1x, p1z);
-        link_point<3>(k, ldc(&cp_eq_d2[0][0][0], e4), ldc(&cp_eq_d2[0][0][0], e4 + 1), p2x, p2z);
+        link_point<5>(k, kc(K, LK_EQ_D1), kc(K, LK_EQ_D1 + 1), p1x, p1z);
+        link_point<3>(k, kc(K, LK_EQ_D2), kc(K, LK_EQ_D2 + 1), p2x, p2z);
       }
       B::fence();
       lds.mark(3);
@@ -444,13 +452,12 @@ template <class B> struct Core {
         lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; lds.cst(C_TAUB + Bc, taub[Bc], live | !live); });
         lfor<0, 5>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
-          D t = -ldc(cp_dof_damping, db + Dd) * st.vl[Dd] - mm.biasl[Dd];
+          D t = -kc(K, LK_DOF_DAMPING + Dd) * st.vl[Dd] - mm.biasl[Dd];
           if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
             constexpr int A_ = Dd == 3 ? 2 : Dd;
-            const I ai = leg * 3 + A_;
-            const D lo = ldc(&cp_act_ctrlrange[0][0], ai * 2), hi = ldc(&cp_act_ctrlrange[0][0], ai * 2 + 1);
+            const D lo = kc(K, LK_ACT_RANGE + 2 * A_), hi = kc(K, LK_ACT_RANGE + 2 * A_ + 1);
             const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
-            t = t + ldc(cp_act_gear, ai) * u;
+            t = t + kc(K, LK_ACT_GEAR + A_) * u;
           }
           taul[Dd] = t;
           lds.cst(C_TAUL + Dd, t, live | !live);
@@ -461,10 +468,25 @@ template <class B> struct Core {
         minv_apply(fc, taub, taul, qsb, qsl);
       }
       B::fence();
-      lds.mark(2);
+      lds.mark(4);
       // The rows are built one slot at a time: a row's z = L^-1 jl is kept (5 doubles per row), its Jacobian is not -- the entry
       // A_ij of the leg block is z_i . jl_j, formed when row j >= i is built -- and its warm-start force is formed as soon as the
       // row (for a contact pair: the tangent row) is complete, so nothing but z, u~, b and the packed A survives a slot.
+      // soft-constraint constants of the three row kinds: k = 1 / (dmax^2 tc^2 dampratio^2), b = 2 / (dmax tc), tc >= 2 h; the
+      // impedance at position 0 (what a friction row uses for its own reference acceleration)
+      struct KindPar { D kk, bb, d0, d1, w, imp0; };
+      auto kind_par = [&](D solref0, D solref1, D d0, D d1, D w) {
+        KindPar k_;
+        const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
+        k_.kk = 1.0 / (d1 * d1 * tc * tc * solref1 * solref1); k_.bb = 2.0 / (d1 * tc);
+        k_.d0 = d0; k_.d1 = d1; k_.w = w; k_.imp0 = impedance(d0, d1, w, D(0.0));
+        return k_;
+      };
+      const KindPar kp_eq = kind_par(kc(K, LK_EQ_SOLREF), kc(K, LK_EQ_SOLREF + 1), kc(K, LK_EQ_SOLIMP), kc(K, LK_EQ_SOLIMP + 1), kc(K, LK_EQ_SOLIMP + 2));
+      const KindPar kp_lim = kind_par(D(cp_limit_solref[0]), D(cp_limit_solref[1]), D(cp_limit_solimp[0]), D(cp_limit_solimp[1]), D(cp_limit_solimp[2]));
+      const KindPar kp_con = kind_par(D(cp_contact_solref[0]), D(cp_contact_solref[1]), D(cp_contact_solimp[0]), D(cp_contact_solimp[1]), D(cp_contact_solimp[2]));
+      D sgl[5];   // signs of the leg's dofs
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sgl[Dd] = kc(K, LK_DOF_SIGMA + Dd); });
       D bvec[CAP], z[CAP][5];
       D jar_prev = 0.0, Rr_prev = 1.0;   // the normal row's values while its tangent row is built
       const D mu = CP_CONTACT_MU;
@@ -477,12 +499,12 @@ template <class B> struct Core {
         jb[0] = 0.0; jb[1] = 0.0; jb[2] = 0.0;
         if constexpr (S < 2) {
           kd = K_EQ;
-          invw = ldc(cp_eq_invweight, leg);
+          invw = kc(K, LK_EQ_INVWEIGHT);
           pos = S == 0 ? p1x - p2x : p1z - p2z;
           // J = J(p1 on rod: pitch, hip, rod) - J(p2 on tarsus: pitch, hip, knee, ankle); the base slides cancel
           auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - lds.cld(C_OZ + Jl) : -(px - lds.cld(C_OX + Jl)); };  // y^ x (p - o), component S
           jb[2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
-          const D sg0 = ldc(cp_dof_sigma, db + 0), sg1 = ldc(cp_dof_sigma, db + 1), sg2 = ldc(cp_dof_sigma, db + 2), sg4 = ldc(cp_dof_sigma, db + 4);
+          const D sg0 = sgl[0], sg1 = sgl[1], sg2 = sgl[2], sg4 = sgl[4];
           jl[0] = sg0 * ent(p1x, p1z, LI<1>{}) - sg0 * ent(p2x, p2z, LI<1>{});
           jl[1] = -(sg1 * ent(p2x, p2z, LI<2>{}));
           jl[2] = -(sg2 * ent(p2x, p2z, LI<3>{}));
@@ -500,7 +522,7 @@ template <class B> struct Core {
           D cjl[4];
           lfor<0, 4>([&](auto dd) {
             constexpr int Dd = decltype(dd)::value;
-            const D val = ldc(cp_dof_sigma, db + Dd) * (ODD ? pz - lds.cld(C_OZ + Dd + 1) : -(px - lds.cld(C_OX + Dd + 1)));
+            const D val = sgl[Dd] * (ODD ? pz - lds.cld(C_OZ + Dd + 1) : -(px - lds.cld(C_OX + Dd + 1)));
             cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
           });
           const D cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
@@ -520,13 +542,11 @@ template <class B> struct Core {
         kd = B::seli(go, kd, I(K_NONE));
         kind[S] = kd;
         const M active = kd != K_NONE;
-        const M iseq = kd == K_EQ, islim = kd == K_LIM;
-        // solver parameters of the row's kind
-        const D solref0 = B::sel(iseq, ldc(&cp_eq_solref[0][0], leg * 2), B::sel(islim, D(cp_limit_solref[0]), D(cp_contact_solref[0])));
-        const D solref1 = B::sel(iseq, ldc(&cp_eq_solref[0][0], leg * 2 + 1), B::sel(islim, D(cp_limit_solref[1]), D(cp_contact_solref[1])));
-        const D simp0 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3), B::sel(islim, D(cp_limit_solimp[0]), D(cp_contact_solimp[0])));
-        const D simp1 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 1), B::sel(islim, D(cp_limit_solimp[1]), D(cp_contact_solimp[1])));
-        const D simp2 = B::sel(iseq, ldc(&cp_eq_solimp[0][0], leg * 3 + 2), B::sel(islim, D(cp_limit_solimp[2]), D(cp_contact_solimp[2])));
+        const M islim = kd == K_LIM;
+        // solver parameters of the row's kind (formed once per substep, above): slots 0, 1 are connect rows, the others limit or contact
+        const D kk_ = S < 2 ? kp_eq.kk : B::sel(islim, kp_lim.kk, kp_con.kk), bb_ = S < 2 ? kp_eq.bb : B::sel(islim, kp_lim.bb, kp_con.bb);
+        const D simp0 = S < 2 ? kp_eq.d0 : B::sel(islim, kp_lim.d0, kp_con.d0), simp1 = S < 2 ? kp_eq.d1 : B::sel(islim, kp_lim.d1, kp_con.d1);
+        const D simp2 = S < 2 ? kp_eq.w : B::sel(islim, kp_lim.w, kp_con.w), imp_at0 = S < 2 ? kp_eq.imp0 : B::sel(islim, kp_lim.imp0, kp_con.imp0);
         D vel = jb[0] * st.vb[0] + jb[1] * st.vb[1] + jb[2] * st.vb[2];
         D bq = jb[0] * qsb[0] + jb[1] * qsb[1] + jb[2] * qsb[2];
         D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
@@ -534,14 +554,12 @@ template <class B> struct Core {
           constexpr int Dd = decltype(dd)::value;
           vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd];
         });
-        const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
-        const D kk_ = 1.0 / (simp1 * simp1 * tc * tc * solref1 * solref1), bb_ = 2.0 / (simp1 * tc);
         const D imp = impedance(simp0, simp1, simp2, pos);
         D R = (1.0 - imp) / imp * invw;
         R = B::sel(R > LMINVAL, R, D(LMINVAL));
         const M ist = kd == K_CT;
         const D own_pos = B::sel(ist, D(0.0), pos);
-        const D imp_own = B::sel(ist, impedance(simp0, simp1, simp2, D(0.0)), imp);
+        const D imp_own = B::sel(ist, imp_at0, imp);   // the tangent row's own position is 0
         const D aref = -bb_ * vel - kk_ * imp_own * own_pos;
         bvec[S] = B::sel(active, bq - aref, D(0.0));
         const D jar = jw - aref;
@@ -572,9 +590,9 @@ template <class B> struct Core {
           Al[symidx(CAP, Ii, S)] = a;
         });
         Adiag[S] = Al[symidx(CAP, S, S)] + (ut[S][0] * ut[S][0] + ut[S][1] * ut[S][1] + ut[S][2] * ut[S][2]);
-        Ainv[S] = 1.0 / Adiag[S];
+        Ainv[S] = B::rcp(Adiag[S]);
         // warm start (mj_constraintUpdate from qacc_warmstart) of a single row; of a contact pair when its tangent row is complete
-        const D Dd_ = 1.0 / Rr;
+        const D Dd_ = B::rcp(Rr);
         D fv = 0.0;
         fv = B::sel(kd == K_EQ, -Dd_ * jar, fv);
         fv = B::sel((kd == K_LIM) & (jar < 0.0), -Dd_ * jar, fv);
@@ -582,7 +600,7 @@ template <class B> struct Core {
         if constexpr (S >= 3 && ((S - 2) & 1)) {
           constexpr int NS = S - 1, P = (S - 2) >> 1;
           const D jn = jar_prev, jt = jar;
-          const D Dn_ = 1.0 / Rr_prev;
+          const D Dn_ = B::rcp(Rr_prev);
           const D Nn = jn * mu, U1 = jt * mu, Tt = B::fabs(U1);
           const M top = (Nn >= mu * Tt) | ((Tt <= 0.0) & (Nn >= 0.0));
           const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
@@ -601,7 +619,7 @@ template <class B> struct Core {
         B::fence();   // keep the scheduler from interleaving the slots (longer live ranges -> spills)
       });
       B::fence();
-      lds.mark(4);
+      lds.mark(5);
       D at[3] = {D(0.0), D(0.0), D(0.0)};
       lfor<0, CAP>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
       lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
@@ -732,7 +750,7 @@ template <class B> struct Core {
       auto sweeps = [&](auto nr_) {
         constexpr int NR = decltype(nr_)::value;
         constexpr int NPAIR = NR == CAP ? 3 : 2;
-        for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+        for (int iter = 0; iter < LEG_ITERS; iter++) {
           if (!B::any(sweeping)) break;
           acc = 0.0;
           lfor<0, NPAIR>([&](auto pp) { ray_den(pp); });
@@ -775,7 +793,7 @@ template <class B> struct Core {
       D oxk[6], ozk[6];
       lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; oxk[J] = lds.cld(C_OX + J); ozk[J] = lds.cld(C_OZ + J); });
       D sg[5];
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sg[Dd] = ldc(cp_dof_sigma, db + Dd); });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sg[Dd] = kc(K, LK_DOF_SIGMA + Dd); });
       auto push = [&](D Fx, D Fz, D px, D pz, auto jl_) {   // generalised force of (Fx, Fz) at p on the dof whose link is Kin link Jl
         constexpr int Jl = decltype(jl_)::value;
         return Fx * (pz - ozk[Jl]) - Fz * (px - oxk[Jl]);
@@ -819,6 +837,7 @@ template <class B> struct Core {
     // inertia) = 0.0393 for this model; tests/test_implicit_damping_bound.py), so x <- qacc - E x from x = qacc converges with
     // error 0.0393^n: DAMPING_SWEEPS = 12 leaves 1e-17.  The base dofs are undamped: E x only needs the leg part of x.
     B::fence();
+    lds.mark(8);
     D xb[3], xl[5];
     minv_apply(fc, gb, gl, xb, xl);
     B::fence();
@@ -828,7 +847,7 @@ template <class B> struct Core {
       lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd]; });
       const D zb[3] = {D(0.0), D(0.0), D(0.0)};
       D hdamp[5];
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hdamp[Dd] = LH * ldc(cp_dof_damping, db + Dd); });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hdamp[Dd] = LH * kc(K, LK_DOF_DAMPING + Dd); });
       for (int it = 0; it < DAMPING_SWEEPS; it++) {
         D dl[5], eb[3], el[5];
         lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; dl[Dd] = hdamp[Dd] * hl[Dd]; });
@@ -855,7 +874,7 @@ template <class B> struct Core {
         st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
       }
     });
-    lds.mark(8);
+    lds.mark(9);
   }
 
   // ------------------------------------------------------------------------------------------------ operational-space state
@@ -864,7 +883,7 @@ template <class B> struct Core {
   static LEG_FN void opstate(const D (&kqb)[3], const D (&kql)[5], const D (&kvb)[3], const D (&kvl)[5], D (&body)[4], D (&foot)[4]) {
     const I leg = B::opq(B::leg());
     Kin k;
-    fk<1>(kqb, kql, kvb, kvl, leg, k);
+    fk<1>(kqb, kql, kvb, kvl, leg, B::kbase(leg), k);
     const D bx = kqb[0] - cp_qpos0[0] + cp_link_off[1][0][0], bz = kqb[1] - cp_qpos0[1] + cp_link_off[1][0][1];
     auto site = [&](auto jj, I sid, D (&o)[4]) {
       constexpr int J = decltype(jj)::value;

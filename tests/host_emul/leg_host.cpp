@@ -60,6 +60,9 @@ struct HostB {
     OwnerScope(VM owner) { old[0] = g_cnt[0]; old[1] = g_cnt[1]; g_cnt[0] = owner.v[0]; g_cnt[1] = owner.v[1]; }
     ~OwnerScope() { g_cnt[0] = old[0]; g_cnt[1] = old[1]; }
   };
+  struct K { const double* p[2]; };
+  static K kbase(VI leg) { K k; k.p[0] = &cp_legk[0][0] + leg.v[0] * LK_N; k.p[1] = &cp_legk[0][0] + leg.v[1] * LK_N; return k; }
+  static VD kld(K k, int idx) { VD r; r.v[0] = k.p[0][idx]; r.v[1] = k.p[1][idx]; return r; }
   struct P { double* p[2]; };
   struct P8 { uint8_t* p[2]; };
   struct Lds {

@@ -38,7 +38,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "physics":
         names = ["0 outside the substep (load, glue, integrate, outputs, write-back)", "1 kinematics (FK, sincos)", "2 mass matrix, M^-1 (Gauss-Jordan), smooth accel.",
                  "3 active limits / contacts, row kinds", "4 constraint rows (J, aref, M^-1 J')", "5 A = J M^-1 J' + R", "6 warm start, initial residual",
                  "7 PGS sweeps", "8 J'f, qacc, implicit damping"]
-        tot = v[:9].sum()
+        if os.environ.get("PHASE_LEG"):
+            names = ["0 outside the substep (load, outputs, op-space state, write-back)", "1 kinematics (FK, sincos)", "2 subtree sums, mass-matrix blocks, bias",
+                     "3 active set (limits, collision spheres), connect anchors", "4 motor commands, setState bookkeeping, block factorisation, M^-1 tau",
+                     "5 constraint rows slot by slot (J, aref, R, z, u~, A), warm-start forces", "6 warm-start cost test, initial residuals", "7 PGS sweeps",
+                     "8 generalised force J'f from the rows' geometry", "9 M^-1 g, implicit damping iteration, integration"]
+        tot = v[:len(names)].sum()
         per_wave = 32 if os.environ.get("PHASE_LEG") else 4   # PHASE_LEG=1: the two-lanes-per-environment kernel is the one instrumented
         print("%s env, %s mode, %d envs: %.0f cycles per wavefront per Env.step" % (kind, mode, n, tot / (n / per_wave) / 20))
         for i, nm in enumerate(names):
