@@ -109,6 +109,7 @@ struct DevB {
     e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, e, r);
   }
+  static LEG_FN double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static LEG_FN double fabs(double x) { return ::fabs(x); }
   static LEG_FN double fmax(double a, double b) { return ::fmax(a, b); }
   static LEG_FN double exp(double x) { return ::exp(x); }

@@ -41,6 +41,9 @@
 #ifndef LEG_FN
 #define LEG_FN __device__ __forceinline__
 #endif
+#ifndef LEG_FP_CONTRACT_OFF
+#define LEG_FP_CONTRACT_OFF _Pragma("clang fp contract(off)")
+#endif
 
 namespace cassie {
 namespace leg {
@@ -659,91 +662,99 @@ template <class B> struct Core {
       // copy stays at the value both lanes shared when the block began -- so the lanes exchange a~ once per BLOCK (both lanes take the
       // owner lane's value by one DPP broadcast per word: `sync`), not once per step: 12 instructions per block instead of 15 per step, and no DPP move on
       // the chain that runs from one step to the next.
-      auto share = [&](D d0, D d1, D d2) { a0 = a0 + d0; a1 = a1 + d1; a2 = a2 + d2; };
       auto sync = [&](auto ww) {   // both lanes of every pair take the value of the owner's lane: one DPP broadcast per word
         constexpr int W = decltype(ww)::value;
         a0 = B::template pair_bcast<W>(a0); a1 = B::template pair_bcast<W>(a1); a2 = B::template pair_bcast<W>(a2);
       };
       // a connect row (slots 0, 1).  Reduced form: no clamp and no cost-increase revert -- for an unclamped row d = -res / A exactly
       // minimises its own quadratic, the change is -res^2 / (2 A) <= 0, so mj_solPGS's revert can never fire (see cassie_kernels_g16.hip).
+      // The step functions are instantiated twice (six-row and eight-row sweeps), and which of the two a wavefront runs depends on
+      // ALL of its 32 environments -- so their roundings must be identical, or an environment's result would depend on its
+      // neighbours (the compiler contracts a*b + c*d into an FMA one way or the other depending on the code around it; measured:
+      // the first version failed the neighbour tests).  Contraction is therefore off inside them and every fused multiply-add is
+      // written out (B::fma), as in the step functions of cassie_kernels_g16.hip.
       auto eq_step = [&](auto ss, M owner, auto nr_) {
+        LEG_FP_CONTRACT_OFF
         constexpr int NR = decltype(nr_)::value;   // own-row slots in use in this wavefront (6 or CAP)
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_EQ);
-        const D res = r[S] + ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2;
+        const D res = B::fma(ut[S][2], a2, B::fma(ut[S][1], a1, B::fma(ut[S][0], a0, r[S])));
         D d = -(res * Ainv[S]);
-        D chg = d * (0.5 * Adiag[S] * d + res);
+        D chg = d * B::fma(0.5 * Adiag[S], d, res);
         d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
-        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
-        acc += chg;
+        a0 = B::fma(ut[S][0], d, a0); a1 = B::fma(ut[S][1], d, a1); a2 = B::fma(ut[S][2], d, a2);
+        acc = acc + chg;
         f[S] = f[S] + d;
-        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = B::fma(Al[symidx(CAP, Ii, S)], d, r[Ii]); });
       };
       auto lim_step = [&](auto ss, M owner, auto nr_) {
+        LEG_FP_CONTRACT_OFF
         constexpr int NR = decltype(nr_)::value;
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int S = decltype(ss)::value;
         const M mine = owner & sweeping & (kind[S] == K_LIM);
-        const D res = r[S] + ut[S][0] * a0 + ut[S][1] * a1 + ut[S][2] * a2;
-        const D cand = B::fmax(f[S] - res * Ainv[S], D(0.0));
+        const D res = B::fma(ut[S][2], a2, B::fma(ut[S][1], a1, B::fma(ut[S][0], a0, r[S])));
+        const D cand = B::fmax(B::fma(-res, Ainv[S], f[S]), D(0.0));
         D d = cand - f[S];
-        D chg = d * (0.5 * Adiag[S] * d + res);
+        D chg = d * B::fma(0.5 * Adiag[S], d, res);
         const M keep = mine & (chg <= 1e-10);
         d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-        share(ut[S][0] * d, ut[S][1] * d, ut[S][2] * d);
-        acc += chg;
+        a0 = B::fma(ut[S][0], d, a0); a1 = B::fma(ut[S][1], d, a1); a2 = B::fma(ut[S][2], d, a2);
+        acc = acc + chg;
         f[S] = f[S] + d;
-        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = r[Ii] + Al[symidx(CAP, Ii, S)] * d; });
+        lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; r[Ii] = B::fma(Al[symidx(CAP, Ii, S)], d, r[Ii]); });
       };
       // 1 / (f' A f) of the ray update of pair P: a function of the pair's own force only, which nothing but the pair's own step
       // changes -- so it is formed at the head of the sweep, off the chain that runs from step to step through a~.
       D rden[3];
       auto pair_step = [&](auto pp, M owner, auto nr_) {
+        LEG_FP_CONTRACT_OFF
         constexpr int NR = decltype(nr_)::value;
         typename B::OwnerScope scope_(owner);   // op-counting builds of the CPU emulation only; empty on the device
         constexpr int P = decltype(pp)::value;
         constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
         const M mine = owner & sweeping & (kind[N] == K_CN);
-        const D rn = r[N] + ut[N][0] * a0 + ut[N][1] * a1 + ut[N][2] * a2;
-        const D rt = r[T] + ut[T][0] * a0 + ut[T][1] * a1 + ut[T][2] * a2;
+        const D rn = B::fma(ut[N][2], a2, B::fma(ut[N][1], a1, B::fma(ut[N][0], a0, r[N])));
+        const D rt = B::fma(ut[T][2], a2, B::fma(ut[T][1], a1, B::fma(ut[T][0], a0, r[T])));
         const D on = f[N], ot = f[T];
         const D Ann = Adiag[N], Att = Adiag[T], Ant_ = Ant[P];
         // normal-only update (taken when the normal force is ~0)
-        const D fn_n = B::fmax(on - rn * Ainv[N], D(0.0));
+        const D fn_n = B::fmax(B::fma(-rn, Ainv[N], on), D(0.0));
         // ray update; rden = 0 where f' A f < MINVAL
-        D x = -(on * rn + ot * rt) * rden[P];
+        D x = -B::fma(ot, rt, on * rn) * rden[P];
         x = B::fmax(x, D(-1.0));
         const M use_n = on < LMINVAL;
-        D fn = B::sel(use_n, fn_n, on + x * on);
-        D ft = B::sel(use_n, D(0.0), ot + x * ot);
+        D fn = B::sel(use_n, fn_n, B::fma(x, on, on));
+        D ft = B::sel(use_n, D(0.0), B::fma(x, ot, ot));
         // friction on one dimension: unconstrained minimiser unless it leaves the cone
-        const D bc = rt - Att * ot + Ant_ * (fn - on);
+        const D bc = B::fma(Ant_, fn - on, B::fma(-Att, ot, rt));
         const D x0 = -bc * Ainv[T];
         const D v1 = x0 * (1.0 / mu);
-        const D val = v1 * v1 - fn * fn;
+        const D val = B::fma(v1, v1, -(fn * fn));
         const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
         const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
         ft = B::sel(fn >= LMINVAL, ftc, ft);
         D dn = fn - on, dt = ft - ot;
         // 1/2 d'A d + d'res, grouped so that few operations wait for the tangent step
-        D chg = dt * (0.5 * Att * dt + (Ant_ * dn + rt)) + dn * (0.5 * Ann * dn + rn);
+        D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rt)), dn * B::fma(0.5 * Ann, dn, rn));
         const M keep = mine & (chg <= 1e-10);
         dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-        // the exchange first (its latency is what the next step waits for), the own rows' residuals behind it
-        share(ut[N][0] * dn + ut[T][0] * dt, ut[N][1] * dn + ut[T][1] * dt, ut[N][2] * dn + ut[T][2] * dt);
-        acc += chg;
+        // a~ first (the next step waits for it), the own rows' residuals behind it
+        a0 = B::fma(ut[T][0], dt, B::fma(ut[N][0], dn, a0)); a1 = B::fma(ut[T][1], dt, B::fma(ut[N][1], dn, a1)); a2 = B::fma(ut[T][2], dt, B::fma(ut[N][2], dn, a2));
+        acc = acc + chg;
         f[N] = f[N] + dn; f[T] = f[T] + dt;
         lfor<0, NR>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
-          r[Ii] = r[Ii] + Al[symidx(CAP, Ii, N)] * dn + Al[symidx(CAP, Ii, T)] * dt;
+          r[Ii] = B::fma(Al[symidx(CAP, Ii, T)], dt, B::fma(Al[symidx(CAP, Ii, N)], dn, r[Ii]));
         });
       };
       auto ray_den = [&](auto pp) {
+        LEG_FP_CONTRACT_OFF
         constexpr int P = decltype(pp)::value;
         constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
         const D on = f[N], ot = f[T];
-        const D denom = on * (Adiag[N] * on + Ant[P] * ot) + ot * (Ant[P] * on + Adiag[T] * ot);
+        const D denom = B::fma(ot, B::fma(Adiag[T], ot, Ant[P] * on), on * B::fma(Ant[P], ot, Adiag[N] * on));
         rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
       };
       I niter = 0;

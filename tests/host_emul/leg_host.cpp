@@ -10,6 +10,7 @@
 #define __constant__
 #define __forceinline__ inline
 #define LEG_FN inline
+#define LEG_FP_CONTRACT_OFF   /* the emulation is compiled with -ffp-contract=off */
 #include "../../cassierl_amd/csrc/cassie_leg_core.h"
 
 namespace {
@@ -103,6 +104,7 @@ struct HostB {
   static void sincos(VD x, VD& s, VD& c) { ops(2); for (int l = 0; l < 2; l++) { s.v[l] = std::sin(x.v[l]); c.v[l] = std::cos(x.v[l]); } }
   static VD sqrt(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = std::sqrt(x.v[l]); return r; }
   static VD rcp(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = 1.0 / x.v[l]; return r; }
+  static VD fma(VD a, VD b, VD c) { ops(2); VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
   static VD fabs(VD x) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fabs(x.v[l]); return r; }
   static VD fmax(VD a, VD b) { VD r; for (int l = 0; l < 2; l++) r.v[l] = std::fmax(a.v[l], b.v[l]); return r; }
   static VD exp(VD x) { ops(); VD r; for (int l = 0; l < 2; l++) r.v[l] = std::exp(x.v[l]); return r; }
