@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
-DOMINANT_KERNEL = "cassie::leg::env_step_leg_kernel<0>"  # the kernel one bench step launches (PD mode, flat floor, >= 16 384 envs)
+DOMINANT_KERNEL = "cassie::leg::env_step_leg_kernel<0>"  # the kernel one bench step launches (PD mode, flat floor, >= 6144 envs)
 PREROLL_SECONDS = 0.4                # untimed Env.steps before the timed region, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec

@@ -72,7 +72,7 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
-constexpr int LEG_MIN_ENVS = 16384;
+constexpr int LEG_MIN_ENVS = 6144;   // measured crossover (r03, bench workload): 4096 envs 0.63 ms (g16 tier) vs 0.75 ms (leg tier), 8192 envs 0.83 vs 0.74 ms
 constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
 constexpr int MAXACT_DBG = L2::K1_MAXACT_DBG;           // debug build of the substep: forces the overflow path in tests
@@ -247,8 +247,9 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipMemset(h->stats, 0, cassie::STAT_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_G16"); if (e && e[0] == '0') h->g16 = false; }
   if (h->cfg.flags & CASSIE_WAVE_PER_ENV) h->g16 = false;
-  // Two lanes per environment = 32 environments per wavefront, one wavefront per SIMD: 1024 SIMDs want >= 32 768 environments.
-  // Below LEG_MIN_ENVS the 4-environments-per-wavefront kernel (8x more wavefronts, two per SIMD) has the shorter critical path.
+  // Two lanes per environment = 32 environments per wavefront, one wavefront per SIMD: a launch of up to 32 768 environments takes
+  // one wavefront's time (0.74 ms per Env.step of ten substeps).  Below LEG_MIN_ENVS the 4-environments-per-wavefront kernel (8x
+  // more wavefronts, two per SIMD, 0.45-0.6 ms for a lone pair of wavefronts) is faster.
   h->leg = h->g16 && n_envs >= LEG_MIN_ENVS;
   { const char* e = getenv("CASSIE2D_LEG"); if (e && (e[0] == '0' || e[0] == '1')) h->leg = h->g16 && e[0] == '1'; }
   if (h->cfg.flags & CASSIE_LEG_TIER_OFF) h->leg = false;

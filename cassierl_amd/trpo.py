@@ -273,11 +273,17 @@ class TRPO:
         self.cg_iters, self.reg_coeff = cg_iters, reg_coeff
         self.backtrack_ratio, self.max_backtracks = backtrack_ratio, max_backtracks
         dev = next(policy.parameters()).device
-        # Exploration noise: a counter-based stream keyed by (seed, GLOBAL env id, noise step, action component), like the
-        # random-action stream of rollout.py -- the sampled batch does not depend on the number of ranks the envs are sharded over.
+        # Exploration noise that does not depend on the number of ranks the envs are sharded over: every rank draws the noise of
+        # ALL environments of the job from an identically seeded generator -- one randn kernel per Env.step, 3 M numbers at
+        # 512k envs -- and keeps the rows of its own shard [env_id0, env_id0 + n_envs).  (r03 first used a counter-based hash keyed
+        # by the global env id, rollout.counter_normal: ~55 elementwise launches per step, a third of the rollout's wall-clock.)
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.seed = seed
-        self.env_ids = torch.arange(n_envs, dtype=torch.int64, device=dev) + (rank * n_envs if env_id0 is None else env_id0)
+        self.env_id0 = rank * n_envs if env_id0 is None else env_id0
+        self.n_envs_global = n_envs * _world()
+        self.env_ids = torch.arange(n_envs, dtype=torch.int64, device=dev) + self.env_id0
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed * 1000003)
         self.noise_step = 0
         self.obs = None
         self.path_t = torch.zeros(n_envs, dtype=torch.int64, device=dev)
@@ -303,7 +309,8 @@ class TRPO:
         ep_sum = torch.zeros((), dtype=torch.float64, device=dev) # device: boolean-mask indexing would synchronise every step
         for t in range(T):
             o = self.obs.to(pol_dtype)
-            noise = R.counter_normal(self.seed, self.env_ids, self.noise_step, self.policy.log_std.numel())
+            noise = torch.randn((self.n_envs_global, self.policy.log_std.numel()), dtype=pol_dtype, device=dev,
+                                generator=self.gen)[self.env_id0:self.env_id0 + N]
             self.noise_step += 1
             a, mean, log_std = self.policy.get_actions(o, noise=noise)
             nobs, rew, done = self.env_step(self.act_map(a))
@@ -429,7 +436,7 @@ class TRPO:
         env = getattr(self, "env", None)
         ck = dict(policy={k: v.detach().cpu() for k, v in self.policy.state_dict().items()},
                   baseline=None if self.baseline.coeffs is None else self.baseline.coeffs.detach().cpu(), itr=int(self.itr), extra=extra,
-                  noise_step=int(self.noise_step), noise_seed=int(self.seed), obs=None if self.obs is None else self.obs.cpu(),
+                  noise_step=int(self.noise_step), noise_seed=int(self.seed), gen_state=self.gen.get_state(), obs=None if self.obs is None else self.obs.cpu(),
                   path_t=self.path_t.cpu(), path_ret=self.path_ret.cpu(), steps_to_trunc=int(self._steps_to_trunc),
                   env_state=None if env is None or not hasattr(env, "get_full_state_host") else torch.from_numpy(env.get_full_state_host()))
         mine = self._rank_path(path)
@@ -453,6 +460,8 @@ class TRPO:
                 and tuple(ck["env_state"].shape) == (self.n_envs, 88):
             env.set_full_state_host(ck["env_state"].numpy())
             self.noise_step, self.seed = ck["noise_step"], ck.get("noise_seed", self.seed)
+            if ck.get("gen_state") is not None:
+                self.gen.set_state(ck["gen_state"])
             self.obs = None if ck["obs"] is None else ck["obs"].to(dev)
             self.path_t, self.path_ret = ck["path_t"].to(dev), ck["path_ret"].to(dev)
             self._steps_to_trunc = ck.get("steps_to_trunc", 0)
