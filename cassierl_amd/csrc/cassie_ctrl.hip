@@ -27,8 +27,12 @@ constexpr double OSC_W_COM = 5.0, OSC_W_STANCE = 10.0, OSC_W_REST = 0.1, OSC_W_F
 // hosts a problem.  The wave-per-environment kernel runs it with one live row (rowok = lane < 16); the 4-envs-per-wave
 // kernel runs it with four.  Every cross-lane step is a DPP row operation and every loop is controlled by wave-wide
 // "any row still busy" ballots, so rows never diverge around a DPP instruction.
+// Scheduling fence between controller phases: keeps the loads and temporaries of one phase from being hoisted into the
+// previous one (where they only add register pressure).
+__device__ __forceinline__ void ctrl_fence() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
 struct CtrlSmem {
-  double Jd[NCR][NV];  // dense controller rows
+  double Jc[NCR][8];   // controller rows, compact: 3 base columns + the 5 joint columns of the row's own leg (the other leg's are 0)
   double acc[16];      // JdotQdot of each row (velocity-product acceleration, no gravity)
   double JH[4][NV];    // Jeq Hinv
   double S4[16];       // Jeq Hinv Jeq' (4x4)
@@ -42,6 +46,29 @@ struct CtrlSmem {
   double u[8];         // controller output
   double s18[18];
 };
+
+// Leg whose joint columns a controller row touches: rows 2,3 (right loop closure) and 10..13 (right foot sites) the right
+// leg's, every other row the left leg's (rows 4,5 = pelvis site and 14 = pitch have base columns only; their joint part is 0).
+__host__ __device__ constexpr int ctrl_row_leg(int r) { return (r == 2 || r == 3 || (r >= 10 && r < 14)) ? 1 : 0; }
+// Entry (r, C) of the dense 15 x 13 controller Jacobian: C is static, the row (and its leg) may be per-lane values.
+template <int C, class CS>
+__device__ __forceinline__ double jd(const CS& cs, int r, int rleg) {
+  if constexpr (C < 3) return cs.Jc[r][C];
+  else {
+    constexpr int LEGC = (C - 3) / 5, K = 3 + (C - 3) % 5;
+    return rleg == LEGC ? cs.Jc[r][K] : 0.0;
+  }
+}
+// ... with a static row: structural zeros are literal zeros (the multiply-adds on them disappear).
+template <int R, int C, class CS>
+__device__ __forceinline__ double jd(const CS& cs) {
+  if constexpr (C < 3) return cs.Jc[R][C];
+  else if constexpr (ctrl_row_leg(R) == (C - 3) / 5) return cs.Jc[R][3 + (C - 3) % 5];
+  else return 0.0;
+}
+// Hinv is stored by rows on the dof lanes; both layouts (dense in Smem, packed upper triangle in the 4-envs-per-wave LDS)
+// are read through SM::hidx(r, c), which always lands on the entry row min(r, c) wrote -- the two kernels therefore see
+// bit-identical matrices.
 
 // pseudoinverse of a symmetric 4x4 (singular values = |eigenvalues|, threshold tol) on per-environment registers.
 // Fast path: S = Jeq Hinv Jeq' is positive definite with eigenvalues ~0.2 .. 11 in every pose the robot reaches, far above the
@@ -126,10 +153,10 @@ __device__ __forceinline__ void pinv_sym4(const double* Sin /*LDS 16*/, double t
 }
 
 // ---------------------------------------------------------------- DynamicState + constraint projector (both controllers)
-// Leaves in LDS: sm.minv = Hinv (RBDL semantics), cs.Jd, cs.acc, cs.JH, cs.bias; returns the wave-uniform P4 = (Jeq Hinv Jeq')^+
+// Leaves in LDS: sm.minv = Hinv (RBDL semantics, read through SM::hidx), cs.Jc, cs.acc, cs.JH, cs.bias; returns the wave-uniform P4 = (Jeq Hinv Jeq')^+
 // and g4 = P4 * JeqdotQdot.
-template <class SM>
-__device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, double (&P4)[16], double (&g4)[4], bool noshort) {
+template <class SM, class CS>
+__device__ __forceinline__ void ctrl_dyn(SM& sm, CS& cs, const LaneConst& c, int l, bool rowok, double (&P4)[16], double (&g4)[4], bool noshort) {
   const int lane = rowok ? l : 63;  // role tests below are written against `lane`; dead rows take no role
   planar_fk<1>(sm, sm.q, sm.v, c, lane);
   {
@@ -139,7 +166,7 @@ __device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& 
     mass_rows<1>(sm, c, dc, l, Mr, bias, false);
     gauss_jordan_rows_legs<true>(Mr, l);
     if (c.dvalid && c.grp == 0 && rowok) {
-      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; sm.minv[c.d * NV + C] = Mr[C]; });
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; if (C >= c.d) sm.minv[SM::hidx(c.d, C)] = Mr[C]; });
       cs.bias[c.d] = bias + dc.damping * sm.v[c.d];
     }
   }
@@ -175,44 +202,40 @@ __device__ __forceinline__ void ctrl_dyn(SM& sm, CtrlSmem& cs, const LaneConst& 
   }
   const int vbase = leg == 0 ? 3 : 8;
   if (lane < NCR) {
-    static_for<0, NV>([&](auto cc) {
-      constexpr int C = decltype(cc)::value;
-      double val = 0.0;
-      if constexpr (C < 3) val = J[C];
-      else {
-        int k = C - vbase;
-        static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; if (k == K) val = J[3 + K]; });
-      }
-      cs.Jd[lane][C] = val;
-    });
+#pragma unroll
+    for (int k = 0; k < 8; k++) cs.Jc[lane][k] = J[k];
     cs.acc[lane] = racc;
   }
   lds_sync();
+  ctrl_fence();
   // JH = Jeq Hinv (rows 0..3) and S4 = JH Jeq'
   if (lane < 4) {
     double X[NV];
     static_for<0, NV>([&](auto cc) {
       constexpr int C = decltype(cc)::value;
-      double s = sm.minv[C * NV + 0] * J[0] + sm.minv[C * NV + 1] * J[1] + sm.minv[C * NV + 2] * J[2];
-      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; s += sm.minv[C * NV + vbase + K] * J[3 + K]; });
+      double s = sm.minv[SM::hidx(C, 0)] * J[0] + sm.minv[SM::hidx(C, 1)] * J[1] + sm.minv[SM::hidx(C, 2)] * J[2];
+      static_for<0, 5>([&](auto kk) { constexpr int K = decltype(kk)::value; s += sm.minv[SM::hidx(C, vbase + K)] * J[3 + K]; });
       X[C] = s;
       cs.JH[lane][C] = s;
     });
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) {
+    static_for<0, 4>([&](auto ss) {
+      constexpr int S = decltype(ss)::value;
       double d = 0;
-      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; d += X[C] * cs.Jd[s4][C]; });
-      cs.S4[4 * lane + s4] = d;
-    }
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; d += X[C] * jd<S, C>(cs); });
+      cs.S4[4 * lane + S] = d;
+    });
   }
   lds_sync();
-  pinv_sym4(cs.S4, 1e-3, P4, noshort);  // pseudoinverse(Jeq*Hinv*Jeq', 1e-3)  (Cassie2d.cpp:134, OSC_RBDL.cpp:171)
+  ctrl_fence();
+  pinv_sym4(cs.S4, 1e-3, P4, noshort);
+  ctrl_fence();  // pseudoinverse(Jeq*Hinv*Jeq', 1e-3)  (Cassie2d.cpp:134, OSC_RBDL.cpp:171)
 #pragma unroll
   for (int r = 0; r < 4; r++) g4[r] = P4[4 * r] * cs.acc[0] + P4[4 * r + 1] * cs.acc[1] + P4[4 * r + 2] * cs.acc[2] + P4[4 * r + 3] * cs.acc[3];
 }
 
 // y = Nc w (+ gamma when add_gamma):  Nc = I - Jeq' P4 Jeq Hinv,  gamma = Jeq' P4 JeqdotQdot
-__device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[16], const double (&g4)[4], bool add_gamma, double (&w)[NV]) {
+template <class CS>
+__device__ __forceinline__ void apply_nc(const CS& cs, const double (&P4)[16], const double (&g4)[4], bool add_gamma, double (&w)[NV]) {
   double t4[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -228,7 +251,7 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
   }
   static_for<0, NV>([&](auto cc) {
     constexpr int C = decltype(cc)::value;
-    w[C] -= cs.Jd[0][C] * s4[0] + cs.Jd[1][C] * s4[1] + cs.Jd[2][C] * s4[2] + cs.Jd[3][C] * s4[3];
+    w[C] -= jd<0, C>(cs) * s4[0] + jd<1, C>(cs) * s4[1] + jd<2, C>(cs) * s4[2] + jd<3, C>(cs) * s4[3];
   });
 }
 
@@ -238,8 +261,8 @@ __device__ __forceinline__ void apply_nc(const CtrlSmem& cs, const double (&P4)[
 // friction-cone generators at 0, motors free).  The QP is strictly convex, so the warm start changes the number of active-set
 // iterations (typically 8 -> 1 or 2), not the solution.
 constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
-template <class SM>
-__device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false,
+template <class SM, class CS>
+__device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false,
                                          PhaseClock* pc = nullptr) {
   const int lane = rowok ? l : 63;
   double P4[16], g4[4];
@@ -256,37 +279,42 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
     } else if (lane < 14) {
       const int cidx = (lane - 6) >> 1;
       const double sg = (lane & 1) ? -OSC_MU : OSC_MU;
-      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = sg * cs.Jd[6 + 2 * cidx][C] + cs.Jd[7 + 2 * cidx][C]; });
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = sg * jd<C>(cs, 6 + 2 * cidx, cidx >> 1) + jd<C>(cs, 7 + 2 * cidx, cidx >> 1); });
     } else if (lane == 14) {
       static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = cs.bias[C]; });
     }
     apply_nc(cs, P4, g4, lane == 14, w);  // lane 14: Nc bias + gamma = -ce
     // x = Hinv y ;  T column = A x  (A = controller rows 4..14)
     double x[NV];
-    static_for<0, NV>([&](auto rr) {
+    static_for<0, NV>([&](auto rr) { constexpr int R = decltype(rr)::value; x[R] = 0.0; });
+    static_for<0, NV>([&](auto rr) {  // one read per entry of the symmetric Hinv; every x[R] still sums its terms in column order
       constexpr int R = decltype(rr)::value;
-      double s = 0;
-      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += sm.minv[R * NV + C] * w[C]; });
-      x[R] = s;
+      static_for<R, NV>([&](auto cc) {
+        constexpr int C = decltype(cc)::value;
+        const double h = sm.minv[SM::hidx(R, C)];
+        x[R] += h * w[C];
+        if constexpr (C != R) x[C] += h * w[R];
+      });
     });
     if (lane < 15) {
-#pragma unroll
-      for (int r = 0; r < 11; r++) {
+      static_for<0, 11>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
         double s = 0;
-        static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += cs.Jd[4 + r][C] * x[C]; });
+        static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += jd<4 + r, C>(cs) * x[C]; });
         if (lane < 14) cs.T[lane][r] = s;
         else {
           // t0 = A q0 + AdotQdot - xdd, q0 = Hinv ce = -x ; xdd packing of Cassie2d.cpp:185-193
-          double xdd;
-          if (r == 10) xdd = cs.act[6];
-          else if (r < 2) xdd = cs.act[r];
-          else xdd = r < 6 ? cs.act[2 + (r & 1)] : cs.act[4 + (r & 1)];
-          cs.t0[r] = -s + (r < 10 ? cs.acc[4 + r] : 0.0) - xdd;
+          constexpr int XI = r == 10 ? 6 : (r < 2 ? r : (r < 6 ? 2 + (r & 1) : 4 + (r & 1)));
+          const double xdd = cs.act[XI];
+          double rowacc = 0.0;
+          if constexpr (r < 10) rowacc = cs.acc[4 + r];
+          cs.t0[r] = -s + rowacc - xdd;
         }
-      }
+      });
     }
   }
   lds_sync();
+  ctrl_fence();
   PHASE_MARK(*pc, 2);
   // ---- QP data: row i of G and c_i on lane i (< 14)
   double G[NZ], cq = 0.0;
@@ -308,7 +336,8 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
         if (lane == Jv) s += OSC_W_F * (OSC_MU * OSC_MU + 1.0);
         if (lane == (Jv ^ 1) && lane >= 6) s += OSC_W_F * (1.0 - OSC_MU * OSC_MU);
       }
-      G[Jv] = s;
+      asm volatile("" : "+v"(s));  // G[Jv] is finished HERE: without the pin the 154 T loads are hoisted above all the sums
+      G[Jv] = s;                   // and held in registers (r03: 116 of them spilled, one scratch round trip per reload)
     });
   }
   const bool isvar = rowok && l < NZ;
@@ -322,6 +351,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
   if (l >= 6) z = 0.0;                          // generators have no upper bound
   bool busy = rowok;  // uniform inside a row
   PHASE_MARK(*pc, 3);
+  ctrl_fence();
   for (int it = 0; it < 60; it++) {
     if (__ballot(busy) == 0) break;
 #ifdef CASSIE_PHASE_TIMING
@@ -394,12 +424,13 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CtrlSmem& cs, const LaneConst& 
   }
   if (lane < 6) cs.u[lane] = z;
   lds_sync();
+  ctrl_fence();
   PHASE_MARK(*pc, 4);
 }
 
 // ---------------------------------------------------------------- Cassie2d::StepJacobian controller: cs.act[6] -> cs.u[6]
-template <class SM>
-__device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, int rowid, double* dbg = nullptr, bool noshort = false) {
+template <class SM, class CS>
+__device__ __forceinline__ void ctrl_jacobian(SM& sm, CS& cs, const LaneConst& c, int l, bool rowok, int rowid, double* dbg = nullptr, bool noshort = false) {
   const int lane = rowok ? l : 63;
   (void)rowid;
   double P4[16], g4[4];
@@ -408,8 +439,11 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
     for (int i = 0; i < 13; i++) dbg[97 + i] = cs.bias[i];
     for (int i = 0; i < 4; i++) dbg[110 + i] = g4[i];
     for (int i = 0; i < 16; i++) dbg[114 + i] = P4[i];
-    for (int i = 0; i < NCR * NV; i++) dbg[130 + i] = cs.Jd[i / NV][i % NV];
-    for (int i = 0; i < NV * NV; i++) dbg[325 + i] = sm.minv[i];  // Hinv (RBDL semantics): inverse of DynamicState's M
+    for (int i = 0; i < NCR * NV; i++) {
+      const int r = i / NV, C = i % NV, lg = C < 3 ? -1 : (C - 3) / 5;
+      dbg[130 + i] = C < 3 ? cs.Jc[r][C] : (lg == ctrl_row_leg(r) ? cs.Jc[r][3 + (C - 3) % 5] : 0.0);
+    }
+    for (int i = 0; i < NV * NV; i++) dbg[325 + i] = sm.minv[SM::hidx(i / NV, i % NV)];  // Hinv (RBDL semantics): inverse of DynamicState's M
     for (int i = 0; i < NCR; i++) dbg[494 + i] = cs.acc[i];        // JdotQdot of every controller row (rows 0..3: JeqdotQdot)
   }
   // Jc6' f on the dof lanes: per foot the mean of the two 6-D site Jacobians; f = (My, Fx, Fz) (Cassie2d.cpp:139-163)
@@ -420,7 +454,10 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
       double Fx = cs.act[3 * foot + 0], Fz = cs.act[3 * foot + 1], My = cs.act[3 * foot + 2];
       // controller rows 6..9 (left foot sites 2,3) / 10..13 (right foot sites 4,5)
       int r0 = 6 + 4 * foot;
-      double jx = 0.5 * (cs.Jd[r0][c.d] + cs.Jd[r0 + 2][c.d]), jz = 0.5 * (cs.Jd[r0 + 1][c.d] + cs.Jd[r0 + 3][c.d]);
+      const int kc = foot == 0 ? c.kL : c.kR;  // compact column of this dof in a row of that foot's leg (-1: none)
+      const int kk = kc < 0 ? 0 : kc;
+      double jx = 0.5 * (cs.Jc[r0][kk] + cs.Jc[r0 + 2][kk]), jz = 0.5 * (cs.Jc[r0 + 1][kk] + cs.Jc[r0 + 3][kk]);
+      if (kc < 0) { jx = 0.0; jz = 0.0; }
       // angular Jacobian about +y of the toe link: sigma_d for every hinge on its path
       int toe = foot == 0 ? 4 : 9;
       int pm = cp_link_pathmask8[toe];
@@ -431,6 +468,7 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
     cs.y[c.d] = cs.bias[c.d] - jtf;
   }
   lds_sync();
+  ctrl_fence();
   {
     double w[NV];
     static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; w[C] = 0.0; });
@@ -443,10 +481,12 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
     }
     apply_nc(cs, P4, g4, lane == 6, w);
     lds_sync();
+  ctrl_fence();
     if (lane < 6) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; cs.U[lane][C] = w[C]; }); }
     if (lane == 6) { static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; cs.y[C] = w[C]; }); }
   }
   lds_sync();
+  ctrl_fence();
   // ---- u = pseudoinverse(Nc Bt, 1e-4) * rhs; row r of U = Nc Bt (13x6) on lane r
   // Fast path: U has full column rank in every reachable pose (singular values ~12 .. 100 against the 1e-4 threshold), and then
   // U^+ = (U'U)^-1 U'.  N = U'U is 6x6 and well conditioned (cond ~ 70), so the normal equations are safe in double precision;
@@ -537,6 +577,7 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
   }
   if (lane < 6) cs.u[lane] = u;
   lds_sync();
+  ctrl_fence();
   if (dbg && lane == 0) {
     for (int i = 0; i < 13; i++) dbg[i] = cs.y[i];
     for (int i = 0; i < 78; i++) dbg[13 + i] = cs.U[i / NV][i % NV];
@@ -546,8 +587,8 @@ __device__ __forceinline__ void ctrl_jacobian(SM& sm, CtrlSmem& cs, const LaneCo
 
 // ---------------------------------------------------------------- scripted standing controllers (cassie2d.py:263-331)
 // Reads the operational-space state exactly as the Python does (GetOperationalSpaceState before the step: stale kinematics).
-template <int CTRL, class SM>
-__device__ __forceinline__ void scripted_targets(SM& sm, CtrlSmem& cs, const LaneConst& c, int l, bool rowok, bool fix_kin, double zpos, double zvel) {
+template <int CTRL, class SM, class CS>
+__device__ __forceinline__ void scripted_targets(SM& sm, CS& cs, const LaneConst& c, int l, bool rowok, bool fix_kin, double zpos, double zvel) {
   opstate18(sm, c, rowok ? l : 63, fix_kin, cs.s18);
   if (rowok && l == 0) {
     const double* s = cs.s18;  // body_x 0..2, body_xd 3..5, left_x 6..8, left_xd 9..11, right_x 12..14, right_xd 15..17
@@ -571,6 +612,7 @@ __device__ __forceinline__ void scripted_targets(SM& sm, CtrlSmem& cs, const Lan
     }
   }
   lds_sync();
+  ctrl_fence();
 }
 
 // ---------------------------------------------------------------- controller kernel, one wavefront per environment
@@ -592,11 +634,13 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_kernel(VecParams p, const doub
   constexpr int ADIM = CTRL == 2 ? 7 : 6;
   if (!SCRIPTED && lane < ADIM) cs.act[lane] = p.actions[(size_t)env * ADIM + lane];
   lds_sync();
+  ctrl_fence();
   const bool fix_kin = (p.flags & FLAG_FIX_STALE_KIN) != 0, noshort = (p.flags & FLAG_NO_PINV_SHORTCUT) != 0;
   unsigned wset = (unsigned)st[ES_QPWSET];
   if (SCRIPTED) scripted_targets<CTRL>(sm, cs, c, lane, lane < 16, fix_kin, zpos[env], zvel[env]);  // kinematics of the LAST setState
   if (lane < 13) { st[ES_KQ + lane] = sm.q[lane]; st[ES_KV + lane] = sm.v[lane]; }  // DynamicModel::setState
   lds_sync();
+  ctrl_fence();
   if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort);
   else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr, noshort);
   if (lane < NU) st[ES_CTRL + lane] = cs.u[lane];  // mj_data->ctrl (pre-clamp), consumed by the physics kernel

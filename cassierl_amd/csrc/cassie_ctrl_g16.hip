@@ -19,25 +19,55 @@
 namespace cassie {
 namespace g16 {
 
-// LDS of one environment for the controller kernel.
+// LDS of one environment for the controller kernel: 582 doubles = 4.7 KB, 18.6 KB per wavefront, so that EIGHT wavefronts
+// (two per SIMD) share the 160 KB of a CU -- the kernel is latency-bound (r03 PMC: 10.7 cycles per VALU instruction at one
+// wavefront per SIMD), a second wavefront hides most of that.  r02 had 1035 doubles (33 KB per wavefront, one per SIMD).
+// The layout is also the controller's scratch (the `cs` argument of cassie_ctrl.hip is this same object).  Three things make
+// it small:
+//   * buffers with disjoint lifetimes share storage: the kinematics / mass-matrix exchange arrays are dead once the
+//     controller rows and Hinv exist (the lds_sync after the rows in ctrl_dyn), which is where JH, S4 and T / U are born;
+//     the stale-kinematics inputs kq / kv are only read by scripted_targets, before ctrl_dyn writes acc / bias;
+//   * controller rows are kept compact (3 base + 5 own-leg columns instead of 13);
+//   * Hinv is symmetric and stored as a packed upper triangle (91 instead of 169 doubles).
 struct EnvLdsC {
-  double q[16], v[16], kq[16], kv[16];
-  double lc[12], ls[12], lw[12], lox[12], loz[12], lcx[12], lcz[12], lfx[12], lfz[12];
-  double s1x[16], s1z[16], s2[16];
-  double minv[NV * NV + 7];
-  double lvx[12], lvz[12], lax[12], laz[12], site[2][6][4], s18[18];
-  CtrlSmem cs;
+  double q[16], v[16];
+  union {
+    struct { double kq[16], kv[16]; };      // kinematics of the LAST setState (scripted targets only)
+    struct { double acc[16], bias[16]; };   // JdotQdot of each controller row; NonlinearEffects + damping*qvel
+  };
+  double minv[NV * (NV + 1) / 2 + 5];       // Hinv, packed upper triangle
+  double Jc[NCR][8];                        // compact controller rows
+  double y[16], act[8], u[8], s18[18];
+  union {
+    struct {                                // forward kinematics and mass-matrix exchange
+      double lc[12], ls[12], lw[12], lox[12], loz[12], lcx[12], lcz[12], lfx[12], lfz[12];
+      double s1x[16], s1z[16], s2[16];
+      double lvx[12], lvz[12], lax[12], laz[12], site[2][6][4];
+    };
+    struct {                                // constraint projector and the controller's own matrices
+      double JH[4][NV], S4[16];
+      union {
+        struct { double T[NZ][12]; double t0[12]; };
+        struct { double U[6][NV]; };
+      };
+    };
+  };
+  __host__ __device__ static constexpr int hidx(int r, int c) {
+    const int lo = r <= c ? r : c, hi = r <= c ? c : r;
+    return lo * NV - lo * (lo - 1) / 2 + (hi - lo);
+  }
 };
+static_assert(sizeof(EnvLdsC) * 4 * 8 <= 160 * 1024, "eight controller wavefronts must fit the LDS of a CU");
 
 // CTRL: 2 = OSC, 3 = Jacobian.  SCRIPTED: targets from standing_controller_* (zpos/zvel per env) instead of actions.
 template <int CTRL, bool SCRIPTED>
-__global__ void __launch_bounds__(64, 1) env_ctrl_g16_kernel(VecParams p, const double* zpos, const double* zvel) {
+__global__ void __launch_bounds__(64, 2) env_ctrl_g16_kernel(VecParams p, const double* zpos, const double* zvel) {
   __shared__ EnvLdsC sm4[4];
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   const int env = blockIdx.x * 4 + g;
   const bool valid = env < p.n_envs;
   EnvLdsC& sm = sm4[g];
-  CtrlSmem& cs = sm.cs;
+  EnvLdsC& cs = sm;  // the controller's scratch lives in the same per-environment block
   const size_t e = valid ? (size_t)env : 0;
   double* st = p.state + e * ENV_STRIDE;
   LaneConst c;

@@ -99,6 +99,8 @@ struct Smem {
   double rowJ[NSLOT + 2][8];
   double rowf[NSLOT + 2];
   double site[2][6][4];
+  // index of Hinv(r, c) for the controllers (cassie_ctrl.hip): dense rows, the copy written by row min(r, c)
+  __host__ __device__ static constexpr int hidx(int r, int c) { return r <= c ? r * NV + c : c * NV + r; }
 };
 
 // Loop-invariant per-lane ROLE data.  Only small integers stay in registers for the whole kernel; the double-precision
