@@ -648,46 +648,57 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     if (lane == S) f += d;
     res += aS * Dd;
   };
-  // one elliptic contact pair: normal row on the even lane S (A column aN), tangent on S+1 (A column aT)
+  // one elliptic contact pair: normal row on the even lane S (A column aN), tangent on S+1 (A column aT).
+  // This kernel runs as the last hand-over tier, a few wavefronts on an idle machine: an environment costs the LENGTH OF THE
+  // DEPENDENCY CHAIN of its 50 sweeps, nothing else (r03 trace: ~900 cycles per pair, 180 us per substep).  So the step is
+  // written for a short chain: no branches (selects on every lane; only the owner lane's values are used), and the ray
+  // update's 1/denom -- a function of the pair's own forces alone -- is computed at the end of the pair's PREVIOUS update,
+  // where it overlaps the cost evaluation and the broadcast, instead of sitting between the residual and the new force.
+  auto ray_rden = [&](double fn, double ft) {
+    const double denom = fn * (Adiag * fn + Ant * ft) + ft * (Ant * fn + Apart * ft);
+    return denom >= MINVAL ? fast_rcp(denom) : 0.0;   // 0: the ray update leaves the point where it is (mj_solPGS: denom < mjMINVAL)
+  };
+  double rden = ray_rden(f, swap1(f));
   auto update_pair = [&](int S, double aN, double aT) {
     // lane S gathers the pair locally: its own (res,f) are the normal's; the partner's via DPP
-    double rt = swap1(res), ot = swap1(f);
-    double rn = res, on = f;
-    double Ann = Adiag, Att = Apart;
-    double fn = on, ft = ot;
-    const bool ray = (__ballot(on >= MINVAL) >> S) & 1;  // wave-uniform: decided by the owner lane
-    if (!ray) {
-      fn = fn - rn * Ainv;
-      fn = fn < 0 ? 0.0 : fn;
-      ft = 0.0;
-    } else {
-      double denom = fn * (Ann * fn + Ant * ft) + ft * (Ant * fn + Att * ft);
-      if (denom >= MINVAL) {
-        double x = -(fn * rn + ft * rt) / denom;
-        x = x < -1.0 ? -1.0 : x;  // keep the normal force non-negative: fn + x fn >= 0
-        fn = fn + x * fn; ft = ft + x * ft;
-      }
-    }
-    if (fn >= MINVAL) {
-      double bc = rt - Att * ot + Ant * (fn - on);
-      double x0 = -bc * AttInv;
-      // QCQP on one friction dimension (mu = CP_CONTACT_MU): unconstrained minimiser unless it leaves the cone
-      double v1 = x0 * (1.0 / mu);
-      double val = v1 * v1 - fn * fn;
-      ft = x0;
-      if (val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1)) ft = (x0 > 0 ? mu : -mu) * fn;
+    const double rt = swap1(res), ot = swap1(f);
+    const double rn = res, on = f;
+    const double Ann = Adiag, Att = Apart;
+    // normal: ray update through the current point when the normal force is positive, else the plain 1-D update
+    double x = -(on * rn + ot * rt) * rden;
+    x = x < -1.0 ? -1.0 : x;  // keep the normal force non-negative: fn + x fn >= 0
+    double fn1 = on - rn * Ainv;
+    fn1 = fn1 < 0 ? 0.0 : fn1;
+    const bool ray = on >= MINVAL;
+    const double fn = ray ? on + x * on : fn1;
+    double ft = ray ? ot + x * ot : 0.0;
+    // friction: QCQP on one dimension (mu = CP_CONTACT_MU): unconstrained minimiser unless it leaves the cone
+    {
+      const double bc = (rt - Att * ot) + Ant * (fn - on);
+      const double x0 = -bc * AttInv;
+      const double v1 = x0 * (1.0 / mu);
+      const double val = v1 * v1 - fn * fn;
+      const bool out_of_cone = val >= 1e-10 && val * Att * (mu * mu) >= 2e-10 * (v1 * v1);
+      const double ftq = out_of_cone ? (x0 > 0 ? mu : -mu) * fn : x0;
+      ft = fn >= MINVAL ? ftq : ft;
     }
     double dn = fn - on, dt = ft - ot;
     double chg = 0.5 * (Ann * dn * dn + 2.0 * Ant * dn * dt + Att * dt * dt) + dn * rn + dt * rt;
-    if (chg > 1e-10) { dn = 0.0; dt = 0.0; chg = 0.0; }
+    const double rden_new = ray_rden(fn, ft);   // off the chain: overlaps the cost test and the broadcast below (kept on every
+                                                 // lane by the select further down: inside an EXEC-masked block it would not overlap)
+    const bool reject = chg > 1e-10;
+    if (reject) { dn = 0.0; dt = 0.0; chg = 0.0; }
     double Dn = rdlane(dn, S), Dt = rdlane(dt, S);
     improvement -= rdlane(chg, S);
-    if (lane == S) f += dn;
-    if (lane == S + 1) f += Dt;
+    rden = (lane == S && !reject) ? rden_new : rden;
+    f += lane == S ? dn : (lane == S + 1 ? Dt : 0.0);
     res += aN * Dn + aT * Dt;
   };
   int niter = 0;
-  for (int iter = 0; iter < CP_ITERATIONS; iter++) {
+#ifndef K1_ITERS   // timing builds only (tests/k1_latency.py): fewer sweeps, to separate the solver from the rest of a substep
+#define K1_ITERS CP_ITERATIONS
+#endif
+  for (int iter = 0; iter < K1_ITERS; iter++) {
     improvement = 0.0;  // wave-uniform: every row's cost change is read back from its owner lane
     unsigned long long m = amask;
     static_for<0, MAXACT>([&](auto kk) {
@@ -882,8 +893,17 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   // workgroups that exit at once (r02 kernel trace), and touches neither state nor scratch.
   const int env0 = p.pending ? blockIdx.x * 64 : blockIdx.x;
   int mine = p.n_sub;
-  if (p.pending) mine = (env0 + lane < p.n_envs) ? p.pending[env0 + lane] : 0;
+  if (p.pending) mine = (env0 + lane < p.n_envs) ? pending_count(p.pending[env0 + lane], p.pending_pick) : 0;
   unsigned long long todo = p.pending ? __ballot(mine != 0) : (env0 < p.n_envs ? 1ull : 0ull);
+  if (p.pending && gridDim.y > 1) {
+    // A pending environment costs its remaining substeps end to end (~0.1 ms each), so the environments of one 64-block are
+    // dealt out over gridDim.y workgroups (the k-th pending one goes to workgroup k mod gridDim.y) instead of queueing behind
+    // each other in one wavefront (r03 trace of fallen robots: two pending environments in a block doubled the pass).
+    unsigned long long keep = 0, m = todo;
+    for (int k = 0; m; k++, m &= m - 1)
+      if (k % (int)gridDim.y == (int)blockIdx.y) keep |= m & (~m + 1);
+    todo = keep;
+  }
   while (todo) {
   const int bit = __ffsll((long long)todo) - 1;
   todo &= todo - 1;

@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   bool valid = env < p.n_envs;
   int first = 0;   // substep at which this environment joins
   if (p.pending) {
-    const int left = valid ? p.pending[env] : 0;
+    const int left = valid ? pending_count(p.pending[env], p.pending_pick) : 0;
     if (__ballot(left > 0) == 0) {
       if (valid && l == 0) pending[env] = 0;
       return;

@@ -26,6 +26,19 @@ enum {
 // route of the controllers' pseudo-inverses even where the certified shortcut applies
 enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2, FLAG_NO_PINV_SHORTCUT = 8 };
 
+// Hand-over between the kernel tiers: pending[env] = substeps the tier above left undone (0 normally), plus PENDING_DEEP when
+// the environment has more rows than the 4-environments-per-wavefront kernel holds, so that the two lower tiers can take
+// their environments at the same time (VecParams::pending_pick) instead of one after the other.
+enum { PENDING_DEEP = 1 << 30, PENDING_COUNT = PENDING_DEEP - 1 };
+enum { PICK_ALL = 0, PICK_DEEP = 1, PICK_SHALLOW = 2 };
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline int pending_count(int v, int pick) {
+  const bool deep = (v & PENDING_DEEP) != 0;
+  return ((pick == PICK_DEEP && !deep) || (pick == PICK_SHALLOW && deep)) ? 0 : (v & PENDING_COUNT);
+}
+
 // Event counters (CassieVecGetCounters).  Only rare paths touch them, so the common case issues no atomics.
 //   STAT_CLEANUP_SUBSTEPS  env-substeps the packed fast-path kernels handed to a slower general kernel (any tier)
 //   STAT_K1_SUBSTEPS       ... of those, env-substeps that went all the way to the wave-per-environment kernel
@@ -54,7 +67,8 @@ struct VecParams {
   double* debug;          // [n_envs][DBG_STRIDE] or null
   double* ovf;            // [n_envs][ovf_stride]: A columns beyond the register-resident ones (rare slow path)
   int ovf_stride;
-  const int* pending;     // [n_envs] substeps left per env (clean-up pass after the 4-envs-per-wave kernel) or null
+  const int* pending;     // [n_envs] substeps left per env (hand-over input of a lower kernel tier) or null
+  int pending_pick;       // which entries of `pending` this launch takes: PICK_ALL, PICK_DEEP (flagged PENDING_DEEP only), PICK_SHALLOW
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*
