@@ -51,6 +51,9 @@ struct CassieVec {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t side = nullptr;                // second stream: the two lower physics tiers run side by side behind the first
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int* deep_hint = nullptr;                  // pinned host word the first tier writes (launch serial of the last deep hand-over)
+  int* deep_hint_dev = nullptr;              // ... its device address
+  int serial = 64;                           // launches of the physics tiers so far (starts past the hint window)
   std::string err;
 };
 
@@ -106,30 +109,42 @@ cassie::VecParams make_params(CassieVec* h) {
 //   tier 1  two lanes per environment (<= 8 rows per leg)        cassie_kernels_leg.hip   [h->leg]
 //   tier 2  four environments per wavefront (<= 16 rows)          cassie_kernels_g16.hip
 //   tier 3  one wavefront per environment (any number of rows)    cassie_kernels.hip
-void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& p) {
+void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) {
+  cassie::VecParams p = pin;
+  p.deep_hint = h->deep_hint_dev; p.serial = ++h->serial;
   cassie::VecParams p2 = p, p3 = p;
   p3.pending = h->pending; p3.pending_pick = cassie::PICK_ALL;
-  if (!h->leg) {
+  // A handed-down environment costs its remaining substeps end to end whatever the batch size (~0.09 ms per substep in the middle
+  // tier, 0.13-0.18 ms in the last).  While robots are down the lower tiers therefore take their environments AT THE SAME TIME on
+  // two streams: a small kernel tags the environments the middle tier could not hold either (PENDING_DEEP), those go straight to
+  // the wave-per-environment kernel on the side stream, and the middle tier plus the pass behind it (what it passed on after all)
+  // run on the caller's stream -- disjoint sets of environments.  r03 trace of fallen robots: 0.9 + 1.7 ms one after the other
+  // before, max(1.7, 0.9 + <= 1.2) ms now.  The tagging kernel and the fork / join cost ~70 us per launch (r03_i: headline 1.43 ->
+  // 1.50 ms when they were unconditional), so this order is only used while the wave-per-environment kernel has had work in one
+  // of the last 32 launches (a word in pinned host memory it writes, read here without synchronisation: a stale value changes the
+  // schedule, never a result -- in the one-stream order the middle tier looks at the deep environments first, finds them too
+  // large at the same substep, and passes them on untouched).
+  const bool side_by_side = h->leg && h->deep_hint && h->serial - *(volatile int*)h->deep_hint <= 32;
+  if (!side_by_side) {
+    if (h->leg) {
+      L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+      p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
+    }
     L2::step_g16(mode, h->n, h->stream, p2, h->pending);
     L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3);
     return;
   }
-  // The first tier tags each environment it hands down with the tier that can hold it (PENDING_DEEP: more rows than the
-  // 4-environments-per-wavefront kernel takes).  A handed-down environment costs its remaining substeps end to end whatever the
-  // batch size (~0.09 ms per substep in the middle tier, 0.13-0.18 ms in the last), so the lower tiers take their environments
-  // AT THE SAME TIME on two streams: the deep ones go straight to the wave-per-environment kernel on the side stream while the
-  // middle tier and the pass behind it (what the middle tier passed on after all) run on the caller's stream -- disjoint sets of
-  // environments.  r03 trace of fallen robots: 0.9 + 1.7 ms one after the other before, max(1.7, 0.9 + <= 1.2) ms now.
   L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+  L2::classify_pending(h->n, h->stream, p, h->pending_leg);
   hipEventRecord(h->ev_fork, h->stream);
   hipStreamWaitEvent(h->side, h->ev_fork, 0);
   cassie::VecParams pd = p;
   pd.pending = h->pending_leg; pd.pending_pick = cassie::PICK_DEEP;
-  L2::step_k1(mode, L2::K1_DEEP, h->n, h->side, pd);
+  L2::step_k1(mode, L2::K1_DEEP, h->n, h->side, pd, L2::K1_HANDOVER_SPLIT);
   hipEventRecord(h->ev_join, h->side);
   p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_SHALLOW;
   L2::step_g16(mode, h->n, h->stream, p2, h->pending);
-  L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3);
+  L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3, L2::K1_HANDOVER_SPLIT);
   hipStreamWaitEvent(h->stream, h->ev_join, 0);
 }
 
@@ -273,6 +288,9 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
+  *h->deep_hint = 0;
+  if (hipHostGetDevicePointer((void**)&h->deep_hint_dev, h->deep_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return bail(CASSIE_EHIP);
   // Cassie2d::Cassie2d: ctor pose, mj_forward, setState (Cassie2d.cpp:56-64)
   L2::init_state(n_envs, h->stream, h->state);
@@ -291,7 +309,8 @@ void CassieVecFree(CassieVec* h) {
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  if (h->side) hipStreamDestroy(h->side);
+  if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+  if (h->deep_hint) hipHostFree(h->deep_hint);
   delete h;
 }
 

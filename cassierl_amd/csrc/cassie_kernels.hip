@@ -910,6 +910,7 @@ __global__ void __launch_bounds__(64, WPS) env_step_kernel(VecParams p) {
   const int env = env0 + bit;
   const int n_sub = p.pending ? __builtin_amdgcn_readlane(mine, bit) : p.n_sub;
   if (p.pending && p.stats && lane == 0) atomicAdd(p.stats + STAT_K1_SUBSTEPS, (unsigned long long)n_sub);
+  if (p.pending && p.deep_hint && lane == 0) *p.deep_hint = p.serial;   // robots are down: the host runs the lower tiers side by side for a while
   double* st = p.state + (size_t)env * ENV_STRIDE;
   LaneConst c;
   load_lane_const(c, lane);

@@ -714,6 +714,54 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
   pc.flush(p.phase, (int)threadIdx.x);
 }
 
+// ---------------------------------------------------------------- routing of handed-down environments
+// For every environment the two-lanes-per-environment kernel left pending: would THIS kernel's substep find more than MAXR rows at
+// the substep the environment is stopped at (same kinematics, same activity tests, same row count as `substep` above)?  Then
+// pending[env] gets PENDING_DEEP and the wave-per-environment kernel takes it directly, at the same time as this kernel works on
+// the others (launch_physics_tiers, cassie_cabi.hip).  Only a routing hint -- an environment that grows past MAXR rows later in the
+// step is passed on as before.  A separate tiny kernel because the two-lanes-per-environment kernel is not to be touched for this:
+// counting there cost 0.8-2.6 % of the headline launch in three formulations (register allocation of its solver loop).
+#ifdef CASSIE_TU_G16   // one definition: this file is also included by the terrain translation unit
+__global__ void __launch_bounds__(64, 2) classify_pending_kernel(VecParams p, int* pending) {
+  __shared__ EnvLds sm4[4];
+  const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+  const int env = blockIdx.x * 4 + g;
+  const bool valid = env < p.n_envs;
+  const int left = valid ? (pending[env] & PENDING_COUNT) : 0;
+  if (__ballot(left > 0) == 0) return;
+  EnvLds& sm = sm4[g];
+  const double* st = p.state + (valid ? (size_t)env : 0) * ENV_STRIDE;
+  LaneConst c;
+  load_lane_const(c, l);
+  c.grp = 0; c.dvalid = l < NV;
+  if (l < NV) { sm.q[l] = st[ES_Q + l]; sm.v[l] = 0.0; }
+  lds_sync();
+  planar_fk<0>(sm, sm.q, sm.v, c, l);
+  const double basez = sm.q[1] - cp_qpos0[1] + cp_link_off[0][0][1];
+  bool lim_act = false;
+  if (l < 8) {
+    const int dof = cp_slot_dof[SLOT_LIM + l];
+    const double qd = sm.q[dof];
+    lim_act = (qd - cp_jnt_range[dof][0] < 0) || (cp_jnt_range[dof][1] - qd < 0);
+  }
+  auto sphere_active = [&](int sph) {
+    double cx, cz;
+    link_point(sm, cp_sph_link[sph], cp_sph_d[sph][0], cp_sph_d[sph][1], cx, cz);
+    return basez + cz - cp_sph_r[sph] < 0;
+  };
+  const bool con_act0 = sphere_active(l);
+  const bool con_act1 = (l == 0) ? sphere_active(16) : false;
+  const unsigned long long bl = __ballot(lim_act), b0 = __ballot(con_act0), b1 = __ballot(con_act1);
+  const int nlim = __popc((unsigned)(bl >> (16 * g)) & 0xFFu);
+  const int ncon = __popc(((unsigned)(b0 >> (16 * g)) & 0xFFFFu) | ((((unsigned)(b1 >> (16 * g))) & 1u) << 16));
+  const int cbase = (nlim >= 1 && nlim <= 4 && ncon <= 4) ? 8 : ((4 + nlim + 1) & ~1);
+  if (valid && left > 0 && l == 0 && cbase + 2 * ncon > MAXR) {
+    pending[env] = left | PENDING_DEEP;
+    if (p.deep_hint) *p.deep_hint = p.serial;
+  }
+}
+#endif
+
 }  // namespace g16
 }  // namespace cassie
 #endif

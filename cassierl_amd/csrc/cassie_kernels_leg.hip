@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   if (valid && (lane & 1) == 0) {
     pending[e] = o.pend;
     if (p.stats) {
-      if (o.pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)(o.pend & PENDING_COUNT));
+      if (o.pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o.pend);
       if (o.bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
     }
   }

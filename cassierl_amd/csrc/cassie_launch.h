@@ -16,10 +16,10 @@ namespace launch {
 // while the 168-register build it replaced spilled 608 B per lane (r01/r02 PMC).
 enum K1Variant { K1_DEEP = 0 /* <.,1,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
 constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
-constexpr int K1_HANDOVER_SPLIT = 8;  // workgroups that share the pending environments of one 64-environment block (hand-over pass)
+constexpr int K1_HANDOVER_SPLIT = 8;  // workgroups that share the pending environments of one 64-environment block (hand-over pass while robots are down)
 
 // tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque, 2 motor commands from the state record; K1_DEBUG: modes 0, 1)
-void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p);
+void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p, int split = 1);  // split: workgroups sharing the pending envs of a 64-block (hand-over pass)
 void reset(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel);
 // tu_hf.hip: the same kernels with the height-field collision stage (p.hf.h != null); PD / torque modes
 void step_k1_hf(int mode, int n_envs, hipStream_t s, const VecParams& p);
@@ -33,6 +33,8 @@ void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 // tu_leg.hip: two lanes per environment (one per leg), 32 environments per wavefront; environments that need more than 8 rows on
 // a leg are handed on through `pending` (step_g16 with p.pending = that array, then step_k1)
 void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
+// tags the pending environments the 4-envs-per-wave kernel could not hold either (PENDING_DEEP): they go straight to step_k1
+void classify_pending(int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tu_ctrl.hip / tu_ctrl_g16.hip: controllers (ctrl: 2 OSC, 3 Jacobian): they write the motor commands into the state record
 void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
 // (the packed controller kernel only writes the motor commands; step_g16 / step_k1 with mode 2 then do the mj_step)

@@ -352,7 +352,7 @@ template <class B> struct Core {
   }
 
   // ------------------------------------------------------------------------------------------------ one mj_forward (+ Euler)
-  struct SubOut { I niter; M overflow, go, deep; };
+  struct SubOut { I niter; M overflow, go; };
 #ifndef LEG_DAMPING_SWEEPS
 #define LEG_DAMPING_SWEEPS 12
 #endif
@@ -430,16 +430,6 @@ template <class B> struct Core {
       M ovf = live & (nrows > CAP);
       ovf = ovf | B::swapm(ovf);
       out.overflow = ovf;
-      {
-        // Which lower tier takes an environment that does not fit here: the row count of the 4-environments-per-wavefront kernel
-        // (4 connect rows, limits padded to an even count -- or to row 8 when there are 1..4 of them and at most 4 contacts --
-        // and two rows per contact; cassie_kernels_g16.hip) says whether that kernel would pass it on again.  Only a routing hint:
-        // the wave-per-environment kernel holds anything.
-        const I nl = nlim + B::swapi(nlim), nc = ncon + B::swapi(ncon);
-        const M own8 = (nl >= 1) & (nl <= 4) & (nc <= 4);
-        const M odd = (nl == 1) | (nl == 3) | (nl == 5) | (nl == 7);
-        out.deep = (B::seli(own8, I(8), nl + B::toI(odd) + 4) + nc * 2) > 16;
-      }
       go = live & !ovf;
       out.go = go;
       small = !B::any(go & ((nlim > 0) | (ncon > 2)));
@@ -980,7 +970,7 @@ template <class B> struct Core {
       substep<MODE>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so);
       if (!reset_pass) {
         const M ovf = live & so.overflow;
-        o.pend = B::seli(ovf, B::seli(so.deep, I(cfg.n_sub - sub + PENDING_DEEP), I(cfg.n_sub - sub)), o.pend);   // hand the rest of this environment to a lower kernel tier
+        o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);   // hand the rest of this environment to the next kernel tier
         live = live & !ovf;
         o.niter = o.niter + B::seli(live, so.niter, I(0));
         o.set_state = o.set_state | live;

@@ -27,7 +27,7 @@ enum {
 enum { FLAG_FIX_STALE_KIN = 1, FLAG_FIX_STALE_QSTATE = 2, FLAG_NO_PINV_SHORTCUT = 8 };
 
 // Hand-over between the kernel tiers: pending[env] = substeps the tier above left undone (0 normally), plus PENDING_DEEP when
-// the environment has more rows than the 4-environments-per-wavefront kernel holds, so that the two lower tiers can take
+// the environment has more rows than the 4-environments-per-wavefront kernel holds (classify_pending_kernel), so that the two lower tiers can take
 // their environments at the same time (VecParams::pending_pick) instead of one after the other.
 enum { PENDING_DEEP = 1 << 30, PENDING_COUNT = PENDING_DEEP - 1 };
 enum { PICK_ALL = 0, PICK_DEEP = 1, PICK_SHALLOW = 2 };
@@ -69,6 +69,8 @@ struct VecParams {
   int ovf_stride;
   const int* pending;     // [n_envs] substeps left per env (hand-over input of a lower kernel tier) or null
   int pending_pick;       // which entries of `pending` this launch takes: PICK_ALL, PICK_DEEP (flagged PENDING_DEEP only), PICK_SHALLOW
+  int* deep_hint;         // host-visible word or null: `serial` is stored there whenever an environment needs the wave-per-environment kernel
+  int serial;             // launch counter of the handle (scheduling hint only, see launch_physics_tiers)
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*

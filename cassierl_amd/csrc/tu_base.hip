@@ -6,8 +6,8 @@
 namespace cassie {
 namespace launch {
 
-void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p) {
-  dim3 grid(p.pending ? (n_envs + 63) / 64 : n_envs, p.pending ? K1_HANDOVER_SPLIT : 1), block(64);  // hand-over pass: one workgroup scans 64 pending counts
+void step_k1(int mode, K1Variant variant, int n_envs, hipStream_t s, const VecParams& p, int split) {
+  dim3 grid(p.pending ? (n_envs + 63) / 64 : n_envs, p.pending ? split : 1), block(64);  // hand-over pass: one workgroup scans 64 pending counts
   if (variant == K1_DEBUG) {
     if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 2, K1_MAXACT_DBG>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((env_step_kernel<1, 2, K1_MAXACT_DBG>), grid, block, 0, s, p);

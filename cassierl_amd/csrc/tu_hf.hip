@@ -9,7 +9,7 @@ namespace cassie {
 namespace launch {
 
 void step_k1_hf(int mode, int n_envs, hipStream_t s, const VecParams& p) {
-  dim3 grid(p.pending ? (n_envs + 63) / 64 : n_envs, p.pending ? K1_HANDOVER_SPLIT : 1), block(64);
+  dim3 grid(p.pending ? (n_envs + 63) / 64 : n_envs, 1), block(64);
   if (mode == 0) hipLaunchKernelGGL((env_step_kernel<0, 1, K1_MAXACT, true>), grid, block, 0, s, p);
   else if (mode == 1) hipLaunchKernelGGL((env_step_kernel<1, 1, K1_MAXACT, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((env_step_kernel<2, 1, K1_MAXACT, true>), grid, block, 0, s, p);

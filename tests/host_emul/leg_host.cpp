@@ -94,7 +94,6 @@ struct HostB {
   static VI seli(VM m, VI a, VI b) { VI r; for (int l = 0; l < 2; l++) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
   static VD swap(VD x) { VD r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
   template <int W> static VD pair_bcast(VD x) { VD r; r.v[0] = r.v[1] = x.v[W]; return r; }
-  static VI swapi(VI x) { VI r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
   static VM swapm(VM x) { VM r; r.v[0] = x.v[1]; r.v[1] = x.v[0]; return r; }
   static bool any(VM m) { return m.v[0] || m.v[1]; }
   static VD ldc(const double* t, VI i) { VD r; r.v[0] = t[i.v[0]]; r.v[1] = t[i.v[1]]; return r; }

@@ -104,7 +104,7 @@ def test_limits_contacts_and_the_capacity_hand_over(oracle_mod):
             sg = env.get_full_state_host()[0]
             if env.pending[0]:
                 handed += 1
-                assert (env.pending[0] & 0xFFFF) == 1 and np.array_equal(sg[:39], s0[:39])   # bit 30: routing hint for the lower tiers
+                assert env.pending[0] == 1 and np.array_equal(sg[:39], s0[:39])
             else:
                 done_in += 1
                 q1, v1 = o.state()
