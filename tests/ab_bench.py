@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the extension on the bench workload (not a test): for each library given on the command line, the median
 kernel time of one 65 536-env Env.step (PD and torque) by HIP events, plus a spot check that the builds agree.
-usage: python tests/ab_bench.py libA.so libB.so"""
+usage: python tests/ab_bench.py libA.so libB.so      (AB_ENVS = batch size, default 65536; AB_FLAGS = CassieVecConfig flags, e.g. 16 = no leg tier)"""
 import json
 import os
 import subprocess
@@ -18,8 +18,8 @@ from cassierl_amd.vec_env import CassieVecEnv
 g = default_gait()
 out = {}
 for kind, mode in (("walk", "PD"), ("stand", "Torque")):
-    n = 65536
-    env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
+    n = int(os.environ.get("AB_ENVS", "65536"))
+    env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=int(os.environ.get("AB_FLAGS", "0")))
     env.set_trajectory(g.time, g.qpos)
     bufs = env.alloc(); env.reset(bufs)
     ids = torch.arange(n, device="cuda")
