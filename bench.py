@@ -255,6 +255,14 @@ def extra_workloads(traj, n):
     rows = []
     pd_box = VE.action_space("PD")
     tq_box = VE.action_space("Torque")
+    # (0) configs[1] as BASELINE.json words it: 4096 envs, random-policy rollout, PD mode, walk env (the headline is the same
+    #     workload at the north_star's 65 536 envs).  4096 envs are one wavefront per SIMD of the 4-envs-per-wave kernel: the
+    #     step time is one wavefront's dependency chain, not throughput.
+    n1 = 4096
+    ids1 = torch.arange(n1, device="cuda:0")
+    rows.append(run_env_workload("configs[1]_4096_envs_pd_random", n1, "walk", "PD", 0, traj, 300, 300,
+                                 lambda t: R.random_actions(1, ids1, t, pd_box.low, pd_box.high),
+                                 "configs[1] at its own size: walk env, StepPd with random joint targets, auto-reset"))
     # (a) stand env / PD mode, random joint targets over the PD box: robots thrash, hit joint limits and fall; reset at z < 0.5.
     #     (The walk env cannot serve here: its reward needs the pose to track the reference gait, so under a random policy every
     #     step ends the episode even with quirk Q3 fixed -- measured, episodes_terminated_per_env_step = 1.0.)

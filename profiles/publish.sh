@@ -7,6 +7,7 @@ src=gpurun_out/$tag
 [ -f $src/bench.json ] && tail -1 $src/bench.json > profiles/${tag}_bench.json
 [ -f $src/fullsize.jsonl ] && cp $src/fullsize.jsonl profiles/${tag}_fullsize.jsonl
 [ -f $src/pytest_gpu.log ] && tail -3 $src/pytest_gpu.log > profiles/${tag}_pytest_gpu.txt
+[ -f $src/pytest_gpu_leg_forced.log ] && tail -3 $src/pytest_gpu_leg_forced.log > profiles/${tag}_pytest_gpu_leg_forced.txt
 [ -f $src/trpo_65536.jsonl ] && cp $src/trpo_65536.jsonl profiles/${tag}_trpo_65536.jsonl
 ks=$(find $src/stats -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$ks" ] && grep -v "at::native\|__amd_rocclr" "$ks" > profiles/${tag}_kernel_stats.csv

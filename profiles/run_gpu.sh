@@ -21,6 +21,9 @@ for w in $what; do
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- \
           python3 "$root/bench.py" --no-extra --no-cpu-baseline > "$out/stats_bench.log" 2>&1 )
       find "$out/stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
+    legforced)   # the whole -m gpu suite once more with the two-lanes-per-environment tier forced on for every batch size
+      CASSIE2D_LEG=1 timeout 3000 python3 -m pytest tests -m gpu -q > "$out/pytest_gpu_leg_forced.log" 2>&1; echo "pytest(leg forced) rc=$?" >> "$out/pytest_gpu_leg_forced.log"
+      tail -3 "$out/pytest_gpu_leg_forced.log" ;;
     trpo)
       timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
       tail -2 "$out/trpo_65536.jsonl" | cut -c1-400 ;;
