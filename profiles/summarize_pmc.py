@@ -69,6 +69,11 @@ def workload(src, wl, want, envs, units_per_launch_name):
                                                                                            "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F64")),
                    hbm_read_bytes=2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0), hbm_write_bytes=1024.0 * v.get("WRITE_SIZE", 0.0))
         row["hbm_bytes"] = row["hbm_read_bytes"] + row["hbm_write_bytes"]
+        # Per SIMD (1024 of them): GRBM_GUI_ACTIVE is summed over the 8 XCDs.  cycles_per_valu_inst above is per WAVEFRONT (how long a
+        # wavefront lives per instruction it issues); with W wavefronts resident on a SIMD the SIMD issues W times as often.
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        row["simd_cycles_per_valu_inst"] = (gui / 8.0) * 1024.0 / valu if (gui and valu) else None
+        row["simd_valu_busy_frac"] = 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / ((gui / 8.0) * 1024.0) if gui else None
         rows.append(row)
     rows.sort(key=lambda r: -(r["counters"].get("SQ_INSTS_VALU", 0.0)))
     tot_flop = sum(r["fp64_lane_flops_issued"] for r in rows)
