@@ -113,11 +113,12 @@ __device__ __forceinline__ void gauss_jordan20(double (&Mr)[NV], int lane) {
   });
 }
 
-struct Out3 { int niter, nefc; bool overflow, capped; };
-
-// ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
-template <int MR, bool CAP>
-__device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, bool integrate, Out3& out, double* dbg) {
+// ---------------------------------------------------------------- kinematics, inertial forces, bias and the rows of M
+// Links on lanes 0..14 (one tree level at a time), dofs on lanes 0..19; leaves row d of M in lane d's row of sm.minv and returns the
+// lane's bias force.  `lane` is the ROLE index: the lane of the wavefront in the one-environment-per-wavefront kernels, the lane
+// inside its 32-lane half in the two-environments-per-wavefront kernel (cassie3d_pair.hip), where `sm` is the half's own block.
+template <int MR>
+__device__ __forceinline__ void kin_mass3(Smem3<MR>& sm, int lane, double& bias_out, double* dbg) {
   // ================= kinematics: links 0..14 on lanes 0..14, one tree level at a time
   const int lk = lane < NL ? lane : 0;
   const int depth = lane < NL ? c3_link_depth[lk] : 99, par = c3_link_parent[lk];
@@ -276,8 +277,20 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     if (J == d) val += c3_dof_armature[d];
     if (dvalid) sm.minv[d][J] = val;
   }
-  const double damping = c3_dof_damping[d];
+  bias_out = bias;
   if (dbg && dvalid) { for (int J = 0; J < NV; J++) dbg[D3_M + d * NV + J] = sm.minv[d][J]; dbg[D3_BIAS + d] = bias; }
+}
+
+struct Out3 { int niter, nefc; bool overflow, capped; };
+
+// ---------------------------------------------------------------- one mj_forward (+ Euler step) of one environment
+template <int MR, bool CAP>
+__device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: command of its motor, pre-clamp */, bool integrate, Out3& out, double* dbg) {
+  double bias;
+  kin_mass3(sm, lane, bias, dbg);
+  const int d = lane < NV ? lane : 0;
+  const bool dvalid = lane < NV;
+  const double damping = c3_dof_damping[d];
   double Mr[NV];
   static_for<0, NV>([&](auto jj) { constexpr int J = decltype(jj)::value; Mr[J] = dvalid ? sm.minv[d][J] : 0.0; });
   gauss_jordan20(Mr, lane);

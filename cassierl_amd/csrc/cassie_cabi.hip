@@ -601,6 +601,7 @@ struct Cassie3dVec {
   hipStream_t stream = nullptr, own_stream = nullptr;  // kernels run on `stream`; `own_stream` is the one this handle created
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
   int* pending = nullptr;
+  bool pair = true;   // first pass: two environments per wavefront (CASSIE3D_PAIR=0: the one-environment <= 32-row kernel, A/B and cross-check)
   unsigned long long* stats = nullptr;
   unsigned long long substeps_requested = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -616,7 +617,7 @@ void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
     return;
   }
   p.pending_in = nullptr; p.pending_out = h->pending;
-  L3::step3d(0, h->n, h->stream, p);
+  L3::step3d(h->pair ? 2 : 0, h->n, h->stream, p);
   p.pending_in = h->pending; p.pending_out = nullptr;
   L3::step3d(1, h->n, h->stream, p);
 }
@@ -651,6 +652,7 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
+  { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '0') h->pair = false; }
   if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
   return CASSIE_OK;

@@ -1,6 +1,7 @@
 // tu_3d.hip -- translation unit of the Cassie3d kernels (cassie3d_kernels.hip).
 #include "cassie_kernels.hip"
 #include "cassie3d_kernels.hip"
+#include "cassie3d_pair.hip"
 #include "cassie_launch.h"
 
 namespace cassie3d {
@@ -8,7 +9,8 @@ namespace launch {
 
 void step3d(int variant, int n_envs, hipStream_t s, const Params3& p) {
   dim3 grid(n_envs), block(64);
-  if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, 2>), grid, block, 0, s, p);
+  if (variant == 2) hipLaunchKernelGGL(env_step3d_pair_kernel, dim3((n_envs + 1) / 2), block, 0, s, p);   // two environments per wavefront
+  else if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, 2>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((env_step3d_kernel<MAXR, 1>), grid, block, 0, s, p);
 }
 void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const double* qvel) {
