@@ -33,26 +33,40 @@ using cassie::rdlane;
 using cassie::static_for;
 using cassie::wave_sum;
 
-// LDS of one environment.  Everything the kinematics produces (link frames, joint axes, collision spheres, velocity
-// by-products, composite inertias) is dead by the time A is filled, so A overlays all of it: 20.4 KB for MR = 32, i.e.
-// 8 wavefronts per CU (2 per SIMD, matching the 256-VGPR budget); 53 KB for MR = 64.
+// LDS of one environment, laid out by lifetime (r03: 17.2 -> 13.2 KB for MR = 32, so that 12 wavefronts share a CU instead of 9;
+// this kernel issues one VALU instruction per 7.5 cycles per SIMD and LDS was what capped its occupancy):
+//   * the by-products of the kinematics (velocities, accelerations, inertial forces, composite inertias: 605 doubles) are dead
+//     once M and the bias exist -- the constraint Jacobian rows are written over them;
+//   * frames, joint axes and collision spheres (402 doubles) are read while the rows are built and dead afterwards -- A is written
+//     over them (and over the pad behind the by-products);
+//   * A = J M^-1 J' + R is symmetric and kept as a packed upper triangle: entry (i, j) = A[tri(min) + max].  A lane reads column
+//     entries (K, lane) for a wave-uniform K: `a_at` picks tri(K) + lane or tri(lane) + K (four integer instructions per read).
 template <int MR>
 struct Smem3 {
+  static constexpr int NBY = 4 * NL * 3 + 3 * NL * 3 + NL * 6 + NV * 10;       // doubles of the by-products
+  static constexpr int KPAD = MR * NV > NBY ? MR * NV - NBY : 0;               // frames start behind rowJ
+  __host__ __device__ static constexpr int tri(int lo) { return lo * MR - lo * (lo + 1) / 2; }   // (lo, hi >= lo) -> tri(lo) + hi
   double q[22], v[NV], ws[NV], qs[NV];
   double minv[NV][NV];  // M^-1 (row d is lane d's scratch for M before the inversion)
-  double rowJ[MR][NV];                 // constraint Jacobian rows
   union {
     struct {
-      double xpos[NL][3], xmat[NL][9];
-      double anchor[NV][3], axis[NV][3];
-      double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
       // velocity / inertia by-products, dead once M and bias exist
       double w[NL][3], vo[NL][3], al[NL][3], ao[NL][3];
       double com[NL][3], F[NL][3], N[NL][3], Iw[NL][6];
       double comp[NV][10];
+      double kpad_[KPAD ? KPAD : 1];
+      // read while the constraint rows are built
+      double xpos[NL][3], xmat[NL][9];
+      double anchor[NV][3], axis[NV][3];
+      double sphc[NSPH][3], sphdist[NSPH], spht1[NSPH][2];
     };
-    double A[MR][MR];  // A[c][i] read by lane i (A is symmetric)
+    struct {
+      double rowJ[MR][NV];                 // constraint Jacobian rows (from the row build to the end of the substep)
+      double A[MR * (MR + 1) / 2];         // packed upper triangle (from the A build to the end of the solve)
+    };
   };
+  // A(K, l) for a wave-uniform row K and this lane's column l (trl = tri(l))
+  __device__ __forceinline__ double a_at(int K, int l, int trl) const { return A[l >= K ? tri(K) + l : trl + K]; }
 };
 
 __device__ __forceinline__ void cross3(const double* a, const double* b, double* r) {
@@ -450,7 +464,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     double a = 0.0;
     static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; a += X[Jx] * sm.rowJ[c][Jx]; });
     if (c == lane) { a += R; Adiag = a; }
-    if (inrow) sm.A[c][lane] = active ? a : 0.0;
+    if (inrow && c <= lane) sm.A[Smem3<MR>::tri(c) + lane] = active ? a : 0.0;   // upper triangle: (c, lane), c <= lane
   }
   lds_sync();
   const double Ainv = 1.0 / Adiag;
@@ -478,7 +492,8 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
     }
   }
   double res = 0.0;
-  for (int c = 0; c < nrows; c++) res += sm.A[c][rl] * rdlane_dyn(f, c);
+  const int trl = Smem3<MR>::tri(rl);
+  for (int c = 0; c < nrows; c++) res += sm.a_at(c, rl, trl) * rdlane_dyn(f, c);
   {
     const double cost = wave_sum(active ? f * (0.5 * res + b) : 0.0);
     if (cost > 0) { f = 0.0; res = 0.0; }
@@ -504,14 +519,15 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
         dOwn = keep ? dOwn : 0.0;
         acc += (keep && lane == K) ? chg : 0.0;
         const double dK = rdlane_dyn(dOwn, K);
-        res += sm.A[K][rl] * dK;
+        res += sm.a_at(K, rl, trl) * dK;
         if (lane == K) f += dK;
       } else {  // contact: rows K (normal), K+1, K+2 (tangents)
         const double o0 = rdlane_dyn(f, K), o1 = rdlane_dyn(f, K + 1), o2 = rdlane_dyn(f, K + 2);
         const double r0 = rdlane_dyn(res, K), r1 = rdlane_dyn(res, K + 1), r2 = rdlane_dyn(res, K + 2);
         // symmetric 3x3 diagonal block of A (the mirrored entries agree to rounding; one of each pair is read)
-        const double A00 = sm.A[K][K], A01 = sm.A[K][K + 1], A02 = sm.A[K][K + 2];
-        const double A11 = sm.A[K + 1][K + 1], A12 = sm.A[K + 1][K + 2], A22 = sm.A[K + 2][K + 2];
+        const int t0 = Smem3<MR>::tri(K), t1 = Smem3<MR>::tri(K + 1), t2 = Smem3<MR>::tri(K + 2);
+        const double A00 = sm.A[t0 + K], A01 = sm.A[t0 + K + 1], A02 = sm.A[t0 + K + 2];
+        const double A11 = sm.A[t1 + K + 1], A12 = sm.A[t1 + K + 2], A22 = sm.A[t2 + K + 2];
         // Straight-line selects instead of branches: every value here is wave-uniform, but the compiler cannot know that and
         // would emit exec-mask branches (VALU compare -> SALU -> taken branch) on the critical path of the solver.
         // normal-only update (taken when the normal force is ~0)
@@ -568,7 +584,7 @@ __device__ void substep3(Smem3<MR>& sm, int lane, double ctrl_l /* dof lane: com
         const bool keep = chg <= 1e-10;
         d0 = keep ? d0 : 0.0; d1 = keep ? d1 : 0.0; d2 = keep ? d2 : 0.0;
         improvement -= keep ? chg : 0.0;
-        res += sm.A[K][rl] * d0 + sm.A[K + 1][rl] * d1 + sm.A[K + 2][rl] * d2;
+        res += sm.a_at(K, rl, trl) * d0 + sm.a_at(K + 1, rl, trl) * d1 + sm.a_at(K + 2, rl, trl) * d2;
         if (lane == K) f += d0;
         if (lane == K + 1) f += d1;
         if (lane == K + 2) f += d2;

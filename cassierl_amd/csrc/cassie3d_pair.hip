@@ -239,7 +239,7 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
     double a = 0.0;
     static_for<0, NV>([&](auto jj) { constexpr int Jx = decltype(jj)::value; a += X[Jx] * sm.rowJ[c < 32 ? c : 0][Jx]; });
     if (c == hl && active) { a += R; Adiag = a; }
-    sm.A[c][hl] = (active && go && c < nrows) ? a : 0.0;   // rows / columns of pad rows and of an idle half: exact zeros
+    if (c <= hl) sm.A[Smem3<32>::tri(c) + hl] = (active && go && c < nrows) ? a : 0.0;   // upper triangle; pad rows / an idle half: exact zeros
   }
   lds_sync();
   const double Ainv = 1.0 / Adiag;
@@ -268,7 +268,8 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
     }
   }
   double res = 0.0;
-  for (int c = 0; c < nrows_w; c++) res += sm.A[c][hl] * hbc(f, c < 32 ? c : 0, upper);
+  const int trl = Smem3<32>::tri(hl);
+  for (int c = 0; c < nrows_w; c++) res += sm.a_at(c, hl, trl) * hbc(f, c < 32 ? c : 0, upper);
   {
     const double cost = hsum(active ? f * (0.5 * res + b) : 0.0);
     if (cost > 0) { f = 0.0; res = 0.0; }
@@ -300,7 +301,7 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
           dOwn = keep ? dOwn : 0.0;
           acc += (keep && hl == K + j) ? chg : 0.0;
           const double dK = hbc(dOwn, K + j, upper);
-          res += sm.A[K + j][hl] * dK;
+          res += sm.a_at(K + j, hl, trl) * dK;
           if (hl == K + j) f += dK;
         }
       }
@@ -308,8 +309,9 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
         const double o0 = hbc(f, K, upper), o1 = hbc(f, K + 1, upper), o2 = hbc(f, K + 2, upper);
         const double r0 = hbc(res, K, upper), r1 = hbc(res, K + 1, upper), r2 = hbc(res, K + 2, upper);
         // symmetric 3x3 diagonal block of A (the mirrored entries agree to rounding; one of each pair is read)
-        const double A00 = sm.A[K][K], A01 = sm.A[K][K + 1], A02 = sm.A[K][K + 2];
-        const double A11 = sm.A[K + 1][K + 1], A12 = sm.A[K + 1][K + 2], A22 = sm.A[K + 2][K + 2];
+        const int t0 = Smem3<32>::tri(K), t1 = Smem3<32>::tri(K + 1), t2 = Smem3<32>::tri(K + 2);
+        const double A00 = sm.A[t0 + K], A01 = sm.A[t0 + K + 1], A02 = sm.A[t0 + K + 2];
+        const double A11 = sm.A[t1 + K + 1], A12 = sm.A[t1 + K + 2], A22 = sm.A[t2 + K + 2];
         // normal-only update (taken when the normal force is ~0)
         const double fn_n = fmax(o0 - r0 * hbc(Ainv, K, upper), 0.0);
         // ray update: scale the force vector by (1 + x), x clamped so that the normal force stays >= 0
@@ -369,7 +371,7 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
         const bool keep = tripC && chg <= 1e-10;   // (false for a half that is not at a contact block: NaN-safe, chg may be anything there)
         d0 = keep ? d0 : 0.0; d1 = keep ? d1 : 0.0; d2 = keep ? d2 : 0.0;
         improvement -= keep ? chg : 0.0;
-        res += sm.A[K][hl] * d0 + sm.A[K + 1][hl] * d1 + sm.A[K + 2][hl] * d2;
+        res += sm.a_at(K, hl, trl) * d0 + sm.a_at(K + 1, hl, trl) * d1 + sm.a_at(K + 2, hl, trl) * d2;
         if (hl == K) f += d0;
         if (hl == K + 1) f += d1;
         if (hl == K + 2) f += d2;

@@ -601,7 +601,7 @@ struct Cassie3dVec {
   hipStream_t stream = nullptr, own_stream = nullptr;  // kernels run on `stream`; `own_stream` is the one this handle created
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
   int* pending = nullptr;
-  bool pair = true;   // first pass: two environments per wavefront (CASSIE3D_PAIR=0: the one-environment <= 32-row kernel, A/B and cross-check)
+  bool pair = false;  // CASSIE3D_PAIR=1: first pass with TWO environments per wavefront (cassie3d_pair.hip; parity-green, measured slower: kept as cross-check)
   unsigned long long* stats = nullptr;
   unsigned long long substeps_requested = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -652,7 +652,7 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
-  { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '0') h->pair = false; }
+  { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '1') h->pair = true; }
   if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
   return CASSIE_OK;

@@ -4,13 +4,17 @@
 #include "cassie3d_pair.hip"
 #include "cassie_launch.h"
 
+#ifndef C3_FAST_WPS
+#define C3_FAST_WPS 3   // wavefronts per SIMD the <= 32-row kernel's register budget is sized for (LDS allows 12 per CU)
+#endif
+
 namespace cassie3d {
 namespace launch {
 
 void step3d(int variant, int n_envs, hipStream_t s, const Params3& p) {
   dim3 grid(n_envs), block(64);
   if (variant == 2) hipLaunchKernelGGL(env_step3d_pair_kernel, dim3((n_envs + 1) / 2), block, 0, s, p);   // two environments per wavefront
-  else if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, 2>), grid, block, 0, s, p);
+  else if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, C3_FAST_WPS>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((env_step3d_kernel<MAXR, 1>), grid, block, 0, s, p);
 }
 void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const double* qvel) {

@@ -198,6 +198,51 @@ def test_many_contacts_hand_over_to_the_general_kernel(V3, kat):
     env.close()
 
 
+def test_two_environments_per_wavefront_kernel_agrees_with_the_default(V3, kat, monkeypatch):
+    """cassie3d_pair.hip (CASSIE3D_PAIR=1: two environments per wavefront on 32-lane halves, aligned row triples) against the default
+    one-environment-per-wavefront kernel and the oracle: an odd batch (one half idle) of robots dropped from different heights and
+    attitudes -- standing, falling, on the ground with limits active and > 30 rows (handed over from one half while the neighbour
+    carries on) -- 400 substeps with random torques.  The two kernels evaluate the same arithmetic per environment (pad rows add
+    exact zeros), so they stay together far below the oracle tolerance."""
+    import oracle_py
+    import torch
+    rng = np.random.default_rng(11)
+    n = 33
+    recs, starts = [], []
+    o = oracle_py.Oracle3D()
+    for i in range(n):
+        q, v = random_state(rng, kat, spread=0.25 if i % 3 else 0.05, height=None if i % 4 else 0.25)
+        if i % 5 == 4:   # lying on its side: many contacts, handed over to the general kernel
+            q[2] = 0.12; q[3:7] = [np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]
+        o.reset(q, v)
+        recs.append(V3.state_record(q, v, o.warmstart())); starts.append((q, v))
+    recs = np.array(recs)
+    env_a = V3.Cassie3dVec(n)
+    monkeypatch.setenv("CASSIE3D_PAIR", "1")
+    env_b = V3.Cassie3dVec(n)
+    monkeypatch.delenv("CASSIE3D_PAIR")
+    env_a.set_state_host(recs); env_b.set_state_host(recs)
+    us = rng.uniform(-0.5, 0.5, (40, n, 10)) * CTRL
+    for t in range(40):
+        u = torch.as_tensor(us[t], device="cuda")
+        env_a.step(u, 10); env_b.step(u, 10)
+    env_a.synchronize(); env_b.synchronize()
+    sa, sb = env_a.get_state_host(), env_b.get_state_host()
+    assert np.isfinite(sa).all() and np.isfinite(sb).all()
+    assert np.array_equal(sa[:, 71], sb[:, 71])                       # env clocks: every substep was done exactly once
+    np.testing.assert_allclose(sb[:, :41], sa[:, :41], atol=1e-8)
+    assert env_b.counters()["general_kernel_substeps"] > 0            # some halves were handed over while their neighbours went on
+    # and one environment of the batch against the oracle (teacher-free, 400 substeps)
+    q, v = starts[1]
+    o.reset(q, v)
+    for t in range(40):
+        for _ in range(10):
+            o.step_torque(us[t, 1])
+    q1, v1 = o.state()
+    assert np.abs(sb[1, :21] - q1).max() / (1.0 + np.abs(q1).max()) < 1e-5
+    env_a.close(); env_b.close()
+
+
 def test_row_cap_beyond_64_rows_matches_the_capped_oracle(V3, kat):
     """The model's worst case is 69 rows (6 connect + 12 limits + 17 contacts x 3); the 64-row kernel then leaves the last
     contacts out for that substep instead of freezing the environment.  A pressed-down, folded-up robot reaches
