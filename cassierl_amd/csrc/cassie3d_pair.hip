@@ -446,7 +446,7 @@ __device__ void substep3_pair(Smem3<32>& sm, int lane, double ctrl_l, bool integ
 // ---------------------------------------------------------------- n_sub torque-mode substeps, two environments per wavefront
 // First pass of Cassie3dVecStep: every environment that needs at most MAXR_PAIR (padded) rows; the others are handed to
 // env_step3d_kernel<MAXR, 1> through `pending_out` (substeps left, state saved at that point).
-__global__ void __launch_bounds__(64, 1) env_step3d_pair_kernel(Params3 p) {
+__global__ void __launch_bounds__(64, 2) env_step3d_pair_kernel(Params3 p) {
   __shared__ Smem3<32> sm2[2];
   const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
   const int env = blockIdx.x * 2 + h;
