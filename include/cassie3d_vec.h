@@ -38,6 +38,8 @@ extern "C" {
 
 typedef struct Cassie3dVec Cassie3dVec;
 
+/* Environment switch read at create time (A/B and cross-check, not part of the contract): CASSIE3D_PAIR=1 runs the first pass with
+ * two environments per wavefront (csrc/cassie3d_pair.hip) instead of one; same results to rounding, measured slower. */
 int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device);
 void Cassie3dVecFree(Cassie3dVec* h);
 const char* Cassie3dVecLastError(const Cassie3dVec* h);
