@@ -11,5 +11,9 @@ src=gpurun_out/$tag
 [ -f $src/trpo_65536.jsonl ] && cp $src/trpo_65536.jsonl profiles/${tag}_trpo_65536.jsonl
 ks=$(find $src/stats -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$ks" ] && grep -v "at::native\|__amd_rocclr" "$ks" > profiles/${tag}_kernel_stats.csv
+for w in osc fallen; do
+  ks=$(find $src/stats_$w -name "*kernel_stats.csv" 2>/dev/null | head -1)
+  [ -n "$ks" ] && grep -v "at::native\|__amd_rocclr" "$ks" > profiles/${tag}_kernel_stats_$w.csv
+done
 [ -d $src/pmc_pd_sq1 ] && python3 profiles/summarize_pmc.py $tag
 ls -la profiles/${tag}_*
