@@ -54,6 +54,7 @@ struct CassieVec {
   int* deep_hint = nullptr;                  // pinned host word the first tier writes (launch serial of the last deep hand-over)
   int* deep_hint_dev = nullptr;              // ... its device address
   int serial = 64;                           // launches of the physics tiers so far (starts past the hint window)
+  int side_mode = -1;                        // CASSIE2D_SIDE_BY_SIDE=0/1 (tests): never / always run the lower tiers side by side; -1: by the hint
   std::string err;
 };
 
@@ -124,7 +125,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   // of the last 32 launches (a word in pinned host memory it writes, read here without synchronisation: a stale value changes the
   // schedule, never a result -- in the one-stream order the middle tier looks at the deep environments first, finds them too
   // large at the same substep, and passes them on untouched).
-  const bool side_by_side = h->leg && h->deep_hint && h->serial - *(volatile int*)h->deep_hint <= 32;
+  const bool side_by_side = h->leg && (h->side_mode >= 0 ? h->side_mode == 1 : (h->deep_hint && h->serial - *(volatile int*)h->deep_hint <= 32));
   if (!side_by_side) {
     if (h->leg) {
       L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
@@ -288,6 +289,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
+  { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
   if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
   *h->deep_hint = 0;
   if (hipHostGetDevicePointer((void**)&h->deep_hint_dev, h->deep_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);

@@ -543,3 +543,33 @@ def test_leg_tier_results_do_not_depend_on_wavefront_neighbours(vec, traj, mode)
         assert np.array_equal(oa[perm], ob) and np.array_equal(ra[perm], rb) and np.array_equal(da[perm], db)
     record(test="leg_permutation_invariance", mode=mode, n=n, steps=T, **a_env.counters())
     a_env.close(); b_env.close()
+
+
+def test_lower_tiers_side_by_side_or_one_after_the_other_give_the_same_bits(vec, monkeypatch):
+    """launch_physics_tiers (cassie_cabi.hip) picks the order of the two lower kernel tiers from a hint it reads without
+    synchronising: one after the other (the middle tier looks at every handed-down environment first) or side by side on two streams
+    (a small kernel routes the environments the middle tier could not hold straight to the wave-per-environment kernel).  The order
+    must not change a single bit: 16 384 robots driven to the ground with random torques (hand-overs to both lower tiers in every
+    step), once with each order forced, and once with the automatic choice."""
+    from cassierl_amd.vec_env import LEG_TIER_ON
+    n, T = 16384, 120
+    rng = np.random.default_rng(77)
+    acts = rng.uniform(-TQ * 1.5, TQ * 1.5, (T, n, 6))
+    finals, counters = [], []
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("CASSIE2D_SIDE_BY_SIDE", raising=False)
+        else:
+            monkeypatch.setenv("CASSIE2D_SIDE_BY_SIDE", mode)
+        e = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False, flags=LEG_TIER_ON)
+        e.reset_host()
+        for t in range(T):
+            e.step_host(acts[t])
+        finals.append(e.get_full_state_host())
+        counters.append(e.counters())
+        e.close()
+    monkeypatch.delenv("CASSIE2D_SIDE_BY_SIDE", raising=False)
+    assert np.isfinite(finals[0]).all()
+    assert counters[0]["cleanup_substeps"] > 0 and counters[0]["k1_substeps"] > 0, counters[0]   # both lower tiers had work
+    assert np.array_equal(finals[0], finals[1]) and np.array_equal(finals[0], finals[2])
+    assert counters[0]["cleanup_substeps"] == counters[1]["cleanup_substeps"] == counters[2]["cleanup_substeps"]
