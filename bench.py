@@ -217,12 +217,14 @@ def cpu_legs_other_configs(budget_s=4.0):
 
 
 # ------------------------------------------------------------------------------------------------ extra workloads (N=1)
-def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn, note, auto_reset=True):
+def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn, note, auto_reset=True, heightfield=None):
     import torch
     from cassierl_amd.vec_env import CassieVecEnv
     env = CassieVecEnv(n, kind=kind, control_mode=mode, n_substeps=10, flags=flags, auto_reset=auto_reset, device=0)
     if kind == "walk":
         env.set_trajectory(traj["time"], traj["qpos"])
+    if heightfield is not None:
+        env.set_heightfield(heightfield, 10.0, 10.0)
     env.use_torch_stream()
     out = env.alloc()
     env.reset(out)
@@ -278,6 +280,12 @@ def extra_workloads(traj, n):
     rows.append(run_env_workload("torque_random_no_reset_fallen", n, "stand", "Torque", 0, traj, 200, 20,
                                  lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
                                  "random torques, auto_reset off: robots on the ground (throughput floor of the PD/torque path)", auto_reset=False))
+    # (b'') N4: the same random-PD rollout on a height field (terrain_random.py's <hfield>: here 3 cm rolling relief, 20 m x 20 m)
+    xs = np.linspace(-10.0, 10.0, 2001)
+    relief = np.tile(0.015 * (1.0 - np.cos(2.0 * np.pi * xs / 1.5)), (64, 1))
+    rows.append(run_env_workload("terrain_stand_pd_random", n, "stand", "PD", 0, traj, 150, 40,
+                                 lambda t: R.random_actions(2, ids, t, pd_box.low, pd_box.high),
+                                 "stand env on a height field (N4), StepPd with random joint targets", heightfield=relief))
     # (c) configs[2]: OSC controller (QP) in every substep, cassie_stand2d Env.step with small random OSC targets
     osc_lo, osc_hi = np.array([-2.0, -2.0, -2.0, 0.0, -2.0, 0.0, -2.0]), np.full(7, 2.0)
     rows.append(run_env_workload("configs[2]_stand_osc_in_loop", n, "stand", "OSC", 0, traj, 20, 30,

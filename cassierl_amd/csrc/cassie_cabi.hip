@@ -149,6 +149,18 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   hipStreamWaitEvent(h->stream, h->ev_join, 0);
 }
 
+// The same tiers on the height field (one stream: robots on terrain have not been profiled lying down).
+void launch_physics_tiers_hf(CassieVec* h, int mode, const cassie::VecParams& p) {
+  cassie::VecParams p2 = p, p3 = p;
+  if (h->leg) {
+    L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
+    p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
+  }
+  L2::step_g16_hf(mode, h->n, h->stream, p2, h->pending);
+  p3.pending = h->pending; p3.pending_pick = cassie::PICK_ALL;
+  L2::step_k1_hf(mode, h->n, h->stream, p3);
+}
+
 // controller-in-the-loop modes; zpos/zvel != null selects the scripted standing controllers
 int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const double* zpos, const double* zvel) {
   const bool scripted = zpos != nullptr;
@@ -168,10 +180,7 @@ int launch_ctrl_step(CassieVec* h, int mode, const cassie::VecParams& p, const d
       if (sub != p.n_sub - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
       L2::ctrl_g16(ctrl, scripted, h->n, h->stream, ps, zpos, zvel);
       if (h->hf.h) {
-        L2::step_g16_hf(2, h->n, h->stream, ps, h->pending);
-        cassie::VecParams pc = ps;
-        pc.pending = h->pending;
-        L2::step_k1_hf(2, h->n, h->stream, pc);
+        launch_physics_tiers_hf(h, 2, ps);
       } else {
         launch_physics_tiers(h, 2, ps);
       }
@@ -199,10 +208,7 @@ int launch_step(CassieVec* h, int mode, const cassie::VecParams& p) {
     if (!pdtq) return launch_ctrl_step(h, mode, p, nullptr, nullptr);
     if (p.debug) return fail(h, CASSIE_EINVAL, "the debug substep has no height-field variant");
     if (h->g16) {
-      L2::step_g16_hf(mode, h->n, h->stream, p, h->pending);
-      cassie::VecParams pc = p;
-      pc.pending = h->pending;
-      L2::step_k1_hf(mode, h->n, h->stream, pc);
+      launch_physics_tiers_hf(h, mode, p);
     } else {
       L2::step_k1_hf(mode, h->n, h->stream, p);
     }

@@ -162,6 +162,55 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   }
 }
 
+#ifdef CASSIE_LEG_HF
+// ---------------------------------------------------------------- height-field instantiation (tu_hf.hip)
+// The same core with the terrain collision stage (`terrain_sphere`, cassie_kernels.hip, which the including translation unit
+// provides): per contact pair one more per-lane LDS slot (the x component of the local terrain normal; nz = sqrt(1 - nx^2) > 0 for
+// a height field) -- 40.7 KB per wavefront, still four per CU.  A separate backend and kernel so that the flat-floor kernel above is
+// byte-for-byte what it was.
+struct DevBHF : DevB {
+  struct Lds : DevB::Lds {
+    double nrm[3][64];
+    LEG_FN void st_nrm(int slot, double nx, bool m) { if (m) nrm[slot][threadIdx.x] = nx; }
+    LEG_FN double ld_nrm(int s) const { return nrm[s][threadIdx.x]; }
+  };
+  static LEG_FN void hf_sphere(const Terrain& t, double wx, double wy, double wz, double radius, double& dist, double& nx, double& nz) {
+    cassie::terrain_sphere(t, wx, wy, wz, radius, dist, nx, nz);
+  }
+};
+typedef Core<DevBHF> DCoreHF;
+
+template <int MODE>
+__global__ void __launch_bounds__(64, 1) env_step_leg_hf_kernel(VecParams p, int* pending) {
+  __shared__ DevBHF::Lds lds;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x * 32 + (lane >> 1);
+  const bool valid = env < p.n_envs;
+  const size_t e = valid ? (size_t)env : 0;
+  EnvCfg cfg;
+  cfg.n_sub = p.n_sub; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
+  cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
+  DCoreHF::Io io;
+  io.rec = p.state + e * ENV_STRIDE;
+  io.has_act = p.actions != nullptr;
+  io.act = const_cast<double*>(p.actions) + (io.has_act ? e * p.adim : 0);
+  io.obs = p.obs + (cfg.want_obs ? e * 26 : 0);
+  io.has_tobs = p.terminal_obs != nullptr;
+  io.tobs = p.terminal_obs + (io.has_tobs ? e * 26 : 0);
+  io.rew = p.reward + (cfg.want_obs ? e : 0);
+  io.done = p.done + (cfg.want_obs ? e : 0);
+  DCoreHF::Out o;
+  DCoreHF::env_step<MODE, true>(cfg, lds, io, valid, o, &p.hf);
+  if (valid && (lane & 1) == 0) {
+    pending[e] = o.pend;
+    if (p.stats) {
+      if (o.pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o.pend);
+      if (o.bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+    }
+  }
+}
+#endif
+
 }  // namespace leg
 }  // namespace cassie
 #endif

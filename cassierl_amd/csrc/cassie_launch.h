@@ -35,6 +35,7 @@ void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tags the pending environments the 4-envs-per-wave kernel could not hold either (PENDING_DEEP): they go straight to step_k1
 void classify_pending(int n_envs, hipStream_t s, const VecParams& p, int* pending);
+void step_leg_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);   // ... on the height field (p.hf)
 // tu_ctrl.hip / tu_ctrl_g16.hip: controllers (ctrl: 2 OSC, 3 Jacobian): they write the motor commands into the state record
 void ctrl_k4(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParams& p, const double* zpos, const double* zvel);
 // (the packed controller kernel only writes the motor commands; step_g16 / step_k1 with mode 2 then do the mj_step)

@@ -363,8 +363,8 @@ template <class B> struct Core {
   // commands are the record's ctrl (MODE 2, and Reset's mj_forward with the stale ctrl); otherwise MODE 0 = PD law on the step's
   // action, MODE 1 = the action itself.  Bookkeeping of a substep that is carried out (cold LDS slots): setState snapshot of the
   // pre-step state, mj_data->ctrl, env clock.
-  template <int MODE>
-  static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out) {
+  template <int MODE, bool HF = false>
+  static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, const Terrain* hf = nullptr) {
     // Model constants are re-read from the constant tables in every substep through indices the optimiser cannot see through
     // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
     // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
@@ -413,12 +413,27 @@ template <class B> struct Core {
           constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
           D cx, cz;
           link_point<Lk>(k, kc(K, LK_SPH_D + 2 * Cc), kc(K, LK_SPH_D + 2 * Cc + 1), cx, cz);
+          if constexpr (HF) {
+            // height field (terrain_sphere, cassie_kernels.hip): the sphere against the local plane of the cell under its centre;
+            // contact frame = (normal (nx, nz), tangent (nz, -nx)), contact point half-way into the penetration along the normal
+            const D basex = st.qb[0] - cp_qpos0[0] + cp_link_off[0][0][0];
+            const D rad = kc(K, LK_SPH_R + Cc);
+            D dist, nx, nz;
+            B::hf_sphere(*hf, basex + cx, kc(K, LK_SPH_Y + Cc), basez + cz, rad, dist, nx, nz);
+            M act = dist < 0.0;
+            if constexpr (Cc == 0) act = act & (leg == 0);
+            const D back = rad + 0.5 * dist;
+            lds.st_pair(ncon, cx - nx * back, cz - nz * back, dist, kc(K, LK_SPH_INVWEIGHT + Cc), I(Lk), act & (ncon < 3));
+            lds.st_nrm(ncon, nx, act & (ncon < 3));
+            ncon = ncon + B::toI(act);
+          } else {
           const D dist = basez + cz - kc(K, LK_SPH_R + Cc);
           M act = dist < 0.0;
           if constexpr (Cc == 0) act = act & (leg == 0);
           // contact point: half-way into the penetration, on the vertical through the sphere centre
           lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, kc(K, LK_SPH_INVWEIGHT + Cc), I(Lk), act & (ncon < 3));
           ncon = ncon + B::toI(act);
+          }
         });
         // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
         link_point<5>(k, kc(K, LK_EQ_D1), kc(K, LK_EQ_D1 + 1), p1x, p1z);
@@ -523,12 +538,26 @@ template <class B> struct Core {
           D px, pz, dist, cinvw; I depth;
           lds.ld_pair(P, px, pz, dist, cinvw, depth);
           D cjl[4];
+          D cj0 = ODD ? 1.0 : 0.0, cj1 = ODD ? 0.0 : 1.0, cj2;
+          if constexpr (HF) {
+            // row direction: the normal (nx, nz) or the tangent (nz, -nx) of the local terrain plane
+            const D nx = lds.ld_nrm(P), nz = B::sqrt(1.0 - nx * nx);
+            const D dx = ODD ? nz : nx, dz = ODD ? -nx : nz;
+            lfor<0, 4>([&](auto dd) {
+              constexpr int Dd = decltype(dd)::value;
+              const D val = sgl[Dd] * (dx * (pz - lds.cld(C_OZ + Dd + 1)) - dz * (px - lds.cld(C_OX + Dd + 1)));
+              cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
+            });
+            cj0 = dx; cj1 = dz;
+            cj2 = cp_dof_sigma[2] * (dx * pz - dz * px);
+          } else {
           lfor<0, 4>([&](auto dd) {
             constexpr int Dd = decltype(dd)::value;
             const D val = sgl[Dd] * (ODD ? pz - lds.cld(C_OZ + Dd + 1) : -(px - lds.cld(C_OX + Dd + 1)));
             cjl[Dd] = B::sel(depth > Dd, val, D(0.0));
           });
-          const D cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
+          cj2 = cp_dof_sigma[2] * (ODD ? pz : -px);
+          }
           // limit
           D lpos = 0.0, lsgn = 0.0, linvw = 0.0; I lj = 0;
           if constexpr (LJ < 4) lds.ld_lim(LJ, lpos, lsgn, linvw, lj);
@@ -536,8 +565,8 @@ template <class B> struct Core {
             constexpr int Dd = decltype(dd)::value;
             jl[Dd] = B::sel(isc, cjl[Dd], B::sel(isl & (lj == Dd), lsgn, D(0.0)));
           });
-          jb[0] = B::sel(isc, D(ODD ? 1.0 : 0.0), D(0.0));
-          jb[1] = B::sel(isc, D(ODD ? 0.0 : 1.0), D(0.0));
+          jb[0] = B::sel(isc, cj0, D(0.0));
+          jb[1] = B::sel(isc, cj1, D(0.0));
           jb[2] = B::sel(isc, cj2, D(0.0));
           pos = B::sel(isc, dist, lpos);
           invw = B::sel(isc, cinvw, linvw);
@@ -823,7 +852,12 @@ template <class B> struct Core {
         D px, pz, dist, cinvw; I depth;
         lds.ld_pair(P, px, pz, dist, cinvw, depth);
         const M isc = kind[N] == K_CN;
-        const D cfx = B::sel(isc, f[T], D(0.0)), cfz = B::sel(isc, f[N], D(0.0));
+        D cfx = B::sel(isc, f[T], D(0.0)), cfz = B::sel(isc, f[N], D(0.0));
+        if constexpr (HF) {   // (tangent, normal) forces -> world (x, z)
+          const D nx = B::sel(isc, lds.ld_nrm(P), D(0.0)), nz = B::sqrt(1.0 - nx * nx);   // (an unused slot holds whatever LDS held)
+          const D ft_ = cfx, fn_ = cfz;
+          cfx = ft_ * nz + fn_ * nx; cfz = fn_ * nz - ft_ * nx;
+        }
         px = B::sel(isc, px, D(0.0)); pz = B::sel(isc, pz, D(0.0));
         lfor<0, 4>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
@@ -927,8 +961,8 @@ template <class B> struct Core {
   // 0..n_sub-1 are the physics substeps; the end-of-step section computes observation / reward / termination and stores them; if
   // any environment of the wave terminated, one more pass (mj_forward only, on the reset pose, for those environments) leaves
   // the reset observation.  On return `o` says what the caller still has to do (pending count, failure-guard counter).
-  template <int MODE>
-  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o) {
+  template <int MODE, bool HF = false>
+  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o, const Terrain* hf = nullptr) {
     const I leg = B::leg();
     const I lo = leg * 5 + 3, ao = leg * 3;
     const M left = leg == 0;
@@ -967,7 +1001,7 @@ template <class B> struct Core {
     int sub = 0;
     SubOut so;
     while (true) {
-      substep<MODE>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so);
+      substep<MODE, HF>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so, hf);
       if (!reset_pass) {
         const M ovf = live & so.overflow;
         o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);   // hand the rest of this environment to the next kernel tier

@@ -3,6 +3,8 @@
 // kernels (the headline) are byte-for-byte what they were and everything builds in parallel.
 #include "cassie_kernels.hip"
 #include "cassie_kernels_g16.hip"
+#define CASSIE_LEG_HF
+#include "cassie_kernels_leg.hip"
 #include "cassie_launch.h"
 
 namespace cassie {
@@ -19,6 +21,12 @@ void step_g16_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* p
   if (mode == 0) hipLaunchKernelGGL((g16::env_step_g16_kernel<0, true>), grid, block, 0, s, p, pending);
   else if (mode == 1) hipLaunchKernelGGL((g16::env_step_g16_kernel<1, true>), grid, block, 0, s, p, pending);
   else hipLaunchKernelGGL((g16::env_step_g16_kernel<2, true>), grid, block, 0, s, p, pending);
+}
+void step_leg_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending) {
+  dim3 grid((n_envs + 31) / 32), block(64);
+  if (mode == 0) hipLaunchKernelGGL((leg::env_step_leg_hf_kernel<0>), grid, block, 0, s, p, pending);
+  else if (mode == 1) hipLaunchKernelGGL((leg::env_step_leg_hf_kernel<1>), grid, block, 0, s, p, pending);
+  else hipLaunchKernelGGL((leg::env_step_leg_hf_kernel<2>), grid, block, 0, s, p, pending);
 }
 void reset_hf(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel) {
   hipLaunchKernelGGL(env_reset_kernel<true>, dim3(n_envs), dim3(64), 0, s, p, mask, qpos, qvel);
