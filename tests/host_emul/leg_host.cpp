@@ -117,6 +117,38 @@ struct HostB {
 
 typedef cassie::leg::Core<HostB> HCore;
 
+// Height-field instantiation (the counterpart of DevBHF in cassie_kernels_leg.hip): one more per-lane slot per contact pair and the
+// terrain test.  `hf_sphere` restates terrain_sphere of cassie_kernels.hip line by line (that one is __device__ code).
+struct HostBHF : HostB {
+  struct Lds : HostB::Lds {
+    double nrm[3][2];
+    void st_nrm(VI slot, VD nx, VM m) { for (int l = 0; l < 2; l++) if (m.v[l]) nrm[slot.v[l]][l] = nx.v[l]; }
+    VD ld_nrm(int s) const { VD r; r.v[0] = nrm[s][0]; r.v[1] = nrm[s][1]; return r; }
+  };
+  static void hf_sphere(const cassie::Terrain& t, VD wx, VD wy, VD wz, VD radius, VD& dist, VD& nx, VD& nz) {
+    for (int l = 0; l < 2; l++) {
+      const int nr = t.nrow, nc = t.ncol;
+      const double dx = 2.0 * t.sx / (nc - 1), dy = 2.0 * t.sy / (nr - 1);
+      const double gx = (wx.v[l] + t.sx) / dx, gy = (wy.v[l] + t.sy) / dy;
+      nx.v[l] = 0.0; nz.v[l] = 1.0; dist.v[l] = wz.v[l] - radius.v[l];
+      if (!(gx >= 0.0 && gx <= (double)(nc - 1) && gy >= 0.0 && gy <= (double)(nr - 1))) continue;
+      int ci = (int)gx, ri = (int)gy;
+      ci = ci > nc - 2 ? nc - 2 : ci;
+      ri = ri > nr - 2 ? nr - 2 : ri;
+      const double fx = gx - ci, fy = gy - ri;
+      const double* h0 = t.h + (size_t)ri * nc + ci;
+      const double z00 = h0[0], z10 = h0[1], z01 = h0[nc], z11 = h0[nc + 1];
+      double a, b;
+      if (fy <= fx) { a = (z10 - z00) / dx; b = (z11 - z10) / dy; }
+      else { a = (z11 - z01) / dx; b = (z01 - z00) / dy; }
+      const double zs = z00 + a * (fx * dx) + b * (fy * dy);
+      nz.v[l] = 1.0 / std::sqrt(1.0 + a * a); nx.v[l] = -a * nz.v[l];
+      dist.v[l] = (wz.v[l] - zs) * nz.v[l] - radius.v[l];
+    }
+  }
+};
+typedef cassie::leg::Core<HostBHF> HCoreHF;
+
 HostB::P both(double* p) { HostB::P r; r.p[0] = r.p[1] = p; return r; }
 
 }  // namespace
@@ -150,6 +182,39 @@ int leg_host_step(double* state, const double* actions, int n, int adim, int mod
     if (mode == 0) HCore::env_step<0>(cfg, lds, io, valid, o);
     else if (mode == 1) HCore::env_step<1>(cfg, lds, io, valid, o);
     else HCore::env_step<2>(cfg, lds, io, valid, o);
+    if (pending) pending[e] = o.pend.v[0];
+    if (nonfinite && o.bad.v[0]) (*nonfinite)++;
+  }
+  return 0;
+}
+
+// The same on a height field (heights[nrow][ncol] metres over [-sx, sx] x [-sy, sy]): cassie_leg_core.h with HF = true.
+int leg_host_step_hf(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
+                     const double* heights, int nrow, int ncol, double sx, double sy, double* obs, double* reward, uint8_t* done, int* pending, int* nonfinite) {
+  cassie::leg::EnvCfg cfg;
+  cfg.n_sub = n_sub; cfg.flags = flags; cfg.env_kind = env_kind; cfg.auto_reset = auto_reset; cfg.adim = adim;
+  cfg.want_obs = obs != nullptr; cfg.traj_qpos = nullptr; cfg.traj_tmax = 0.0; cfg.traj_n = 0;
+  cassie::Terrain hf; hf.h = heights; hf.nrow = nrow; hf.ncol = ncol; hf.sx = sx; hf.sy = sy;
+  double dummy[32] = {0};
+  uint8_t dummy8 = 0;
+  for (int e = 0; e < n; e++) {
+    HostBHF::Lds lds;
+    std::memset(&lds, 0, sizeof lds);
+    for (int s = 0; s < 3; s++) lds.nrm[s][0] = lds.nrm[s][1] = std::nan("");   // an unused slot holds anything (r03: a NaN there leaked once)
+    HCoreHF::Io io;
+    io.rec = both(state + (size_t)e * cassie::ENV_STRIDE);
+    io.has_act = actions != nullptr;
+    io.act = both(actions ? const_cast<double*>(actions) + (size_t)e * adim : dummy);
+    io.obs = both(obs ? obs + (size_t)e * 26 : dummy);
+    io.has_tobs = false;
+    io.tobs = both(dummy);
+    io.rew = both(reward ? reward + e : dummy);
+    io.done.p[0] = io.done.p[1] = done ? done + e : &dummy8;
+    VM valid; valid.v[0] = valid.v[1] = true;
+    HCoreHF::Out o;
+    if (mode == 0) HCoreHF::env_step<0, true>(cfg, lds, io, valid, o, &hf);
+    else if (mode == 1) HCoreHF::env_step<1, true>(cfg, lds, io, valid, o, &hf);
+    else HCoreHF::env_step<2, true>(cfg, lds, io, valid, o, &hf);
     if (pending) pending[e] = o.pend.v[0];
     if (nonfinite && o.bad.v[0]) (*nonfinite)++;
   }

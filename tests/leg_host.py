@@ -46,6 +46,9 @@ class LegHostEnv:
         self.traj_q = np.ascontiguousarray(qpos, dtype=np.float64)
         self.traj_tmax, self.traj_n = float(time[-1]), len(time)
 
+    def set_heightfield(self, heights_m, size_x=10.0, size_y=10.0):
+        self.hf = None if heights_m is None else (np.ascontiguousarray(heights_m, dtype=np.float64), float(size_x), float(size_y))
+
     def set_full_state_host(self, s):
         self.state = np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(self.n, 88)).copy()
 
@@ -58,6 +61,14 @@ class LegHostEnv:
         rew = np.zeros(self.n) if want_obs else None
         done = np.zeros(self.n, dtype=np.uint8)
         bad = ct.c_int(0)
+        if getattr(self, "hf", None) is not None:
+            hm, sx, sy = self.hf
+            lib().leg_host_step_hf(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
+                                   0 if self.kind == "walk" else 1, int(self.auto_reset), _p(hm), hm.shape[0], hm.shape[1], ct.c_double(sx), ct.c_double(sy),
+                                   _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None,
+                                   self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad))
+            self.nonfinite += bad.value
+            return obs, rew, done.astype(bool)
         lib().leg_host_step(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
                             0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
                             _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,

@@ -114,3 +114,42 @@ def test_limits_contacts_and_the_capacity_hand_over(oracle_mod):
         else:
             o.step_torque(a)
     assert done_in > 100 and handed > 0 and maxlim >= 2 and maxcon >= 4, (done_in, handed, maxlim, maxcon)
+
+
+@pytest.mark.parametrize("mode", ["Torque", "PD"])
+def test_height_field_ramp_teacher_forced(oracle_mod, mode):
+    """The height-field instantiation of the kernel source (cassie_leg_core.h with HF = true: terrain collision stage, contact
+    frame from the local plane) on the CPU against the oracle's hfield_sphere: robots on the flat part of a ramp, across its kink
+    and on the 10 % slope, 200 teacher-forced substeps (the GPU twin is tests/test_gpu_terrain.py).  The emulation fills unused
+    contact slots with NaN normals: nothing may leak from them."""
+    from cassierl_amd import terrain as T
+    hm = T.ramp(nrow=64, ncol=2001, size_x=10.0, slope=0.1, x0=0.5)
+    shifts = [(-1.0, 0.0), (0.45, 0.002), (1.0, 0.05), (3.3, 0.28)]
+    os_ = []
+    for dx, dz in shifts:
+        o = oracle_mod.Oracle()
+        o.set_hfield(hm, 10.0, 10.0)
+        q, v = o.state()
+        q[0] += dx; q[1] += dz
+        o.set_state_raw(q, v, np.zeros(13))
+        os_.append(o)
+    n = len(os_)
+    env = LegHostEnv(n, n_substeps=1, auto_reset=False)
+    env.set_heightfield(hm, 10.0, 10.0)
+    rng = np.random.default_rng(12)
+    worst, sloped = 0.0, 0
+    for t in range(200):
+        if t % 10 == 0:
+            a = rng.uniform(-1, 1, (n, 6)) * TQ if mode == "Torque" else rng.uniform(PD_LO, PD_HI, (n, 6))
+        env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in os_]))
+        env.substep_host(mode, a, 1)
+        assert (env.pending == 0).all() and env.nonfinite == 0
+        sg = env.get_full_state_host()
+        for i, o in enumerate(os_):
+            (o.step_torque if mode == "Torque" else o.step_pd)(a[i])
+            q1, v1 = o.state()
+            worst = max(worst, np.abs(sg[i, :13] - q1).max(), np.abs(sg[i, 13:26] - v1).max() / (1 + np.abs(v1).max()))
+            if o.ncon and np.abs(o.contacts()["frame"][:, 0]).max() > 0.05:
+                sloped += 1
+    assert worst < 1e-9, worst
+    assert sloped > 100   # contacts with a tilted frame were really exercised
