@@ -31,10 +31,16 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
 DOMINANT_KERNEL = "cassie::leg::env_step_leg_kernel<0>"  # the kernel one bench step launches (PD mode, flat floor, >= 6144 envs)
-PREROLL_SECONDS = float(os.environ.get("CASSIE_BENCH_PREROLL", "0.4"))                # untimed Env.steps before the timed region, on top of --warmup (see worker())
+PREROLL_STEPS_AT_64K = int(os.environ.get("CASSIE_BENCH_PREROLL_STEPS", "300"))     # untimed Env.steps before the timed region at 65 536 envs, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def preroll_count(n_envs):
+    """Fixed pre-roll length: PREROLL_STEPS_AT_64K at 65 536 envs (~0.4 s), more steps for smaller batches (their steps are shorter,
+    down to one wavefront's latency), fewer for larger ones; a function of the batch size only, so every rank and every run agree."""
+    return int(min(1000, max(20, round(PREROLL_STEPS_AT_64K * min(4.0, 65536.0 / max(1, n_envs))))))
 
 
 def parse_args():
@@ -51,16 +57,32 @@ def parse_args():
 
 # ------------------------------------------------------------------------------------------------ launcher (no GPU call)
 def visible_gpus():
-    """Number of GPUs this process may use, WITHOUT touching torch.cuda / HIP in the launcher parent: the visibility lists if
-    set, otherwise the DRM render nodes of the box (one per GPU)."""
+    """Number of GPUs this process may use, WITHOUT touching torch.cuda / HIP in the launcher parent: the DRM render nodes of AMD
+    devices (vendor 0x1002) that this process can actually open -- a container's /dev/dri may list nodes its cgroup denies, and
+    /sys shows the whole host -- capped by every visibility list that is set (ROCR composes with HIP / CUDA: the effective set is
+    no larger than the smallest)."""
+    n = 0
+    try:
+        for f in sorted(os.listdir("/dev/dri")):
+            if not f.startswith("renderD"):
+                continue
+            try:
+                if open("/sys/class/drm/%s/device/vendor" % f).read().strip() != "0x1002":
+                    continue
+            except OSError:
+                pass   # no sysfs entry to ask: count the node if it opens
+            try:
+                os.close(os.open(os.path.join("/dev/dri", f), os.O_RDWR))
+                n += 1
+            except OSError:
+                pass
+    except OSError:
+        n = 0
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            return len([x for x in v.split(",") if x.strip() != ""])
-    try:
-        return len([f for f in os.listdir("/dev/dri") if f.startswith("renderD")])
-    except OSError:
-        return 0
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def spawn_ranks(args, poll_s=0.5, deadline_s=3600.0):
@@ -158,6 +180,65 @@ def cpu_baseline(traj, cores, budget_s=12.0):
                 cores_visible=cores, threads_tried=tries,
                 sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs on %d threads (best of %s), "
                        "oracle built %s" % (16 * best[1], best[2], best[3], best[1], tries, "-O3 -march=native" if fast else "-O2"))
+
+
+def cpu_same_source(traj, cores, budget_s=10.0):
+    """The SAME SOURCE as the HIP kernel (cassierl_amd/csrc/cassie_leg_core.h) on the host cores: oracle/leg_host/leg_host.cpp
+    instantiates it with an eight-lane backend (four environments per AVX-512 register), -O3 -march=native, built on this box;
+    OpenMP over groups of environments.  Same workload as the headline (walk env, PD, random policy, auto-reset).  BASELINE.md
+    section 3 / SURVEY.md 8(d) promise this leg beside the oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes as ct
+    import leg_host as LH
+    import torch
+    from cassierl_amd import rollout as R
+    O = _oracle()
+    L = LH.lib(fast=True)
+    low, high = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+    oe = O.OracleEnv("walk", "PD", traj=traj)
+    oe.reset()
+    q, v = oe.oracle.state()
+    ctor = O.Oracle()
+    rec = np.zeros(88)
+    rec[0:13], rec[13:26], rec[26:39] = q, v, oe.oracle.warmstart()
+    rec[39:52], rec[52:65], rec[65:78] = ctor.state()[0], ctor.state()[1], q
+    tq = np.ascontiguousarray(traj["qpos"], dtype=np.float64)
+    dp, ip, bp = ct.POINTER(ct.c_double), ct.POINTER(ct.c_int), ct.POINTER(ct.c_ubyte)
+
+    def sample(n, threads, budget):
+        state = np.tile(rec, (n, 1)).copy()
+        obs, rew, done, pend, bad = np.zeros((n, 26)), np.zeros(n), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32), ct.c_int(0)
+        ids = torch.arange(n)
+        steps, t_used = 0, 0.0
+        while t_used < budget and steps < 400:
+            a = np.ascontiguousarray(R.random_actions(1, ids, steps, low, high).numpy())
+            t0 = time.perf_counter()
+            L.leg_host_step(state.ctypes.data_as(dp), a.ctypes.data_as(dp), n, 6, 0, 10, 0, 0, 1, tq.ctypes.data_as(dp),
+                            ct.c_double(float(traj["time"][-1])), len(traj["time"]), obs.ctypes.data_as(dp), rew.ctypes.data_as(dp),
+                            done.ctypes.data_as(bp), None, pend.ctypes.data_as(ip), ct.byref(bad), threads)
+            if steps > 0:   # the first call warms the caches / the OpenMP team up
+                t_used += time.perf_counter() - t0
+            steps += 1
+        assert np.isfinite(rew).all() and bad.value == 0 and pend.sum() == 0
+        return n * (steps - 1) / t_used, steps - 1, t_used
+
+    one, s1, t1 = sample(256, 1, 1.5)
+    tries, th = [], cores
+    while th >= 1 and len(tries) < 6:
+        tries.append(th)
+        th //= 2
+    per = max(1.0, (budget_s - 1.5) / len(tries))
+    best = None
+    for th in tries:
+        val, st, tu = sample(256 * th, th, per)
+        if best is None or val > best[0]:
+            best = (val, th, st, tu)
+    return dict(value=best[0], unit="env-steps/s", cores=best[1], kind="same-source", lanes_per_thread=int(L.leg_host_lanes()),
+                single_thread=dict(value=one, unit="env-steps/s", cores=1, sample="256 envs x %d Env.steps in %.1f s" % (s1, t1)),
+                cores_visible=cores, threads_tried=tries,
+                sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s: cassie_leg_core.h through the host backend "
+                       "(oracle/leg_host, 8 lanes = 4 envs per AVX-512 register), g++ -O3 -march=native, OpenMP over envs on %d threads "
+                       "(best of %s)" % (256 * best[1], best[2], best[3], best[1], tries))
 
 
 def cpu_legs_other_configs(budget_s=4.0):
@@ -348,6 +429,35 @@ def extra_workloads(traj, n):
     return rows
 
 
+def roofline_object(n_local, kernel_ms, dominant, pmc):
+    """The ceiling that binds this path is the FP64 vector unit, not HBM: `achieved` = USEFUL FP64 flops of the
+    algorithm per launch (counted by an op-counting build of the kernel's own source for this workload's row mix, tests/count_flops.py
+    -> profiles/useful_flops.json; inside a Gauss-Seidel step only the owner lane counts) / the dominant kernel's launch time measured
+    here with HIP events; `peak` = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz.  `issued` (PMC: VALU instruction counters x 64 lanes,
+    an upper bound of the useful work) and `traffic` (PMC: HBM bytes per launch) are only given when profiles/pmc_traffic.json
+    describes THIS source tree and batch size.  The HBM figures BASELINE.json asks for are the `hbm` sub-object."""
+    try:
+        useful = json.load(open(os.path.join(ROOT, "profiles", "useful_flops.json")))["pd_bench"]["flop_per_env_step"]
+    except Exception:
+        useful = None
+    sec = kernel_ms * 1e-3
+    issued = pmc.get("valu_flop_per_env_step")
+    ach = None if not useful else useful * n_local / sec / 1e12
+    hbm_gbps = ALGO_BYTES_PER_ENV_STEP * n_local / sec / 1e9
+    return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": None if ach is None else ach / FP64_VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
+            "kernel": dominant + " (+ its hand-over passes)", "kernel_ms": kernel_ms,
+            "useful_flop_per_env_step": useful,
+            "issued": None if not issued else {"achieved": issued * n_local / sec / 1e12, "frac": issued * n_local / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                               "flop_per_env_step": issued, "source": pmc.get("source")},
+            "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_gbps / HBM_PEAK_GBPS,
+                    "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP, "algo_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n_local,
+                    "traffic_bytes_per_launch": pmc.get("hbm_bytes_per_launch")},
+            "flop_model": "useful: +,-,* = 1 (a*b+c = 2); /, sqrt, 1/x, exp = 1; sincos = 2; compare/select/move = 0; reset pass of a "
+                          "terminated environment included.  issued = 64 x (ADD + MUL + TRANS + 2 FMA) FP64 wave-instructions",
+            "note": "FP64 vector issue bound, one dependent chain per wavefront; not HBM bound (hbm.frac)"}
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def worker(args):
     import torch
@@ -355,8 +465,8 @@ def worker(args):
     from cassierl_amd.trajectory import default_gait
     from cassierl_amd.vec_env import CassieVecEnv
 
-    if os.environ.get("CASSIE_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):  # test hook: this rank dies before the rendezvous
-        return 7
+    if os.environ.get("CASSIE_TEST_HOOKS") == "1" and os.environ.get("CASSIE_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        return 7   # test hook (tests/test_gpu_bench.py, only with CASSIE_TEST_HOOKS=1): this rank dies before the rendezvous
     rank, local_rank, world = R.init_distributed()
     if world != max(1, args.gpus):
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) joined (WORLD_SIZE); refusing to report a mislabelled number\n" % (args.gpus, world))
@@ -398,17 +508,16 @@ def worker(args):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kev0, kev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kev0.record(); kev1.record()   # (first use of a timing event outside the timed region too)
+    # The number of pre-roll steps is a function of the batch size only (a wall-clock bound made the state at the start of
+    # the timed region differ from run to run and from rank to rank): ~0.4 s of Env.steps at the measured 1.4 ms per 65 536 envs.
     pre_actions = [R.random_actions(9, ids, t, low, high) for t in range(10)]
-    preroll_steps = 0
+    preroll_steps = preroll_count(n_local)
     torch.cuda.synchronize()
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PREROLL_SECONDS or preroll_steps < 20:
-        for k in range(10):   # the timed loop's body, kernel for kernel: the first use of a torch kernel costs its module load
-            _, rew, dn = env.step(pre_actions[k], out)   # (r03: `dn.sum()` first ran inside the timed region -- 8-25 ms of host time in
-            returns += rew                                 # its first step, i.e. 1.6-2.6 ms per step over the driver's 20 steps against
-            dones += dn.sum()                              # 1.43 in steady state; r02's 15 % driver gap was the same thing)
-            preroll_steps += 1
-        torch.cuda.synchronize()
+    for k in range(preroll_steps):   # the timed loop's body, kernel for kernel: the first use of a torch kernel costs its module load
+        _, rew, dn = env.step(pre_actions[k % 10], out)   # (r03: `dn.sum()` first ran inside the timed region -- 8-25 ms of host time in
+        returns += rew                                      # its first step, i.e. 1.6-2.6 ms per step over the driver's 20 steps against
+        dones += dn.sum()                                   # 1.43 in steady state; r02's 15 % driver gap was the same thing)
+    torch.cuda.synchronize()
     returns.zero_(); dones.zero_()
     env.reset_counters()
     torch.cuda.synchronize()
@@ -455,9 +564,6 @@ def worker(args):
             pmc = {}
         from cassierl_amd.build import source_hash
         pmc_ok = pmc.get("envs") == n_local and pmc.get("csrc_sha16") == source_hash()
-        traffic = pmc.get("hbm_bytes_per_launch") if pmc_ok else None
-        valu = pmc.get("valu_flop_per_env_step") if pmc_ok else None  # counted from SQ_INSTS_VALU_* of the same kernel, see profiles/README.md
-        useful = pmc.get("useful_flop_per_env_step") if pmc_ok else None
         dominant = (pmc.get("dominant_kernel") if pmc_ok else None) or DOMINANT_KERNEL
         line = {
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
@@ -470,20 +576,7 @@ def worker(args):
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
                        "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms,
                        "preroll_steps": preroll_steps},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": dominant + " (+ its hand-over passes)", "kernel_ms": kernel_ms,
-                         "pmc_source": pmc.get("source") if pmc_ok else None,
-                         "algo_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY.md 8d); see fp64_valu"},
-            "fp64_valu": None if not valu else {
-                "achieved_tflops": valu * n_local / (kernel_ms * 1e-3) / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                "frac": valu * n_local / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                "useful_frac": None if not useful else useful * n_local / (kernel_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                "useful_flop_per_env_step": useful,
-                "flop_model": "achieved = ISSUED FP64 lane-flops (VALU instruction counters of the dominant kernel x 64 lanes, "
-                              "profiles/pmc_traffic.json): an upper bound; useful = flops of the same algorithm counted by an "
-                              "op-counting run of the planar specification for this workload's row mix (tests/count_flops.py)"},
+            "roofline": roofline_object(n_local, kernel_ms, dominant, pmc if pmc_ok else {}),
             "physics_substeps_per_s": value * 10, "returns_checksum": float(all_returns.sum().item()), "finite": finite,
             "episodes_terminated_per_env_step": float(dones.item()) / (n_local * args.steps),
             "cleanup_frac": counters["cleanup_frac"], "k1_frac": counters["k1_frac"], "nonfinite_resets": counters["nonfinite_resets"],
@@ -495,18 +588,26 @@ def worker(args):
         if world == 1 and not args.no_extra:
             try:
                 line["extra"] = extra_workloads(traj, n_local)
+                # the regimes where robots move, fall and lie on the ground, where the driver's record keeps them (env-steps/s)
+                line["config"]["env_steps_per_s_other_workloads"] = {
+                    r["workload"]: r.get("env_steps_per_s", r.get("env_steps_equiv_per_s")) for r in line["extra"] if "workload" in r}
             except Exception as ex:  # the headline stays valid; say what failed
                 line["extra"] = [{"error": repr(ex)}]
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(traj, cores)
+            # two CPU legs on this box's host cores: the SAME SOURCE as the HIP kernel through its host backend (the fair one), and
+            # the oracle (dense 3-D O(n^3) restatement, the parity checker)
+            try:
+                line["cpu_baseline"] = cpu_same_source(traj, cores)
+            except Exception as ex:
+                line["cpu_baseline"] = {"error": "same-source leg: " + repr(ex)}
+            try:
+                line["cpu_baseline"]["oracle"] = cpu_baseline(traj, cores)
+            except Exception as ex:
+                line["cpu_baseline"]["oracle"] = {"error": repr(ex)}
             if "extra" in line:
-                # in a child process: these legs use the oracle's -O2 parity build (the -O3 -march=native timing build bound above
-                # for the headline's CPU leg trips a GCC auto-vectorisation alignment fault in the OSC routine), and the child never
-                # touches the GPU
                 try:
-                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-legs-only"], capture_output=True, text=True, timeout=300)
-                    line["extra"] += json.loads(cp.stdout.strip().splitlines()[-1])
+                    line["extra"] += cpu_legs_other_configs()
                 except Exception as ex:
                     line["extra"].append({"error": "cpu legs: " + repr(ex)})
         else:

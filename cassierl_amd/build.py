@@ -44,6 +44,17 @@ def _units():
 
 
 STAMP = os.path.join(OBJDIR, "FLAGS.stamp")
+LIBSTAMP = LIB + ".stamp"   # travels with the library (gpurun ships built files): "<flags>\n<hash of sources + public headers>"
+
+
+def _tree_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(_deps()):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _stamp_matches():
@@ -56,10 +67,14 @@ def _stamp_matches():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or not _stamp_matches():
+    """Decided by CONTENT, not by file times: a copy of the tree to another box (gpurun, the driver's push) keeps no promise about
+    mtimes, and a spurious rebuild there costs minutes of a GPU lease (the library is ~2.5 CPU-minutes of hipcc)."""
+    if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    try:
+        return open(LIBSTAMP).read() != " ".join(FLAGS) + "\n" + _tree_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False, only=None):
@@ -101,6 +116,8 @@ def _build_locked(force, verbose, only):
     subprocess.check_call(cmd)
     with open(STAMP, "w") as f:
         f.write(" ".join(FLAGS))
+    with open(LIBSTAMP, "w") as f:
+        f.write(" ".join(FLAGS) + "\n" + _tree_hash())
     return LIB
 
 

@@ -53,7 +53,7 @@ struct CassieVec {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int* deep_hint = nullptr;                  // pinned host word the first tier writes (launch serial of the last deep hand-over)
   int* deep_hint_dev = nullptr;              // ... its device address
-  int serial = 64;                           // launches of the physics tiers so far (starts past the hint window)
+  unsigned serial = 64;                      // launches of the physics tiers so far (starts past the hint window); wraps (compared modulo 2^32)
   int side_mode = -1;                        // CASSIE2D_SIDE_BY_SIDE=0/1 (tests): never / always run the lower tiers side by side; -1: by the hint
   std::string err;
 };
@@ -112,7 +112,7 @@ cassie::VecParams make_params(CassieVec* h) {
 //   tier 3  one wavefront per environment (any number of rows)    cassie_kernels.hip
 void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) {
   cassie::VecParams p = pin;
-  p.deep_hint = h->deep_hint_dev; p.serial = ++h->serial;
+  p.deep_hint = h->deep_hint_dev; p.serial = (int)++h->serial;   // the kernels only store the word; the comparison below is unsigned
   cassie::VecParams p2 = p, p3 = p;
   p3.pending = h->pending; p3.pending_pick = cassie::PICK_ALL;
   // A handed-down environment costs its remaining substeps end to end whatever the batch size (~0.09 ms per substep in the middle
@@ -125,28 +125,40 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   // of the last 32 launches (a word in pinned host memory it writes, read here without synchronisation: a stale value changes the
   // schedule, never a result -- in the one-stream order the middle tier looks at the deep environments first, finds them too
   // large at the same substep, and passes them on untouched).
-  const bool side_by_side = h->leg && (h->side_mode >= 0 ? h->side_mode == 1 : (h->deep_hint && h->serial - *(volatile int*)h->deep_hint <= 32));
-  if (!side_by_side) {
-    if (h->leg) {
-      L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
-      p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
+  // (unsigned difference: wrap-safe; a launch counter that wrapped past a stale hint turns the order on for at most 32 launches)
+  const bool side_by_side = h->leg && (h->side_mode >= 0 ? h->side_mode == 1 : (h->deep_hint && h->serial - (unsigned)*(volatile int*)h->deep_hint <= 32u));
+  // fork: the side stream waits for the first tier.  If the event cannot be recorded / waited for, fall back to the one-stream order
+  // below (same results) rather than let the side stream's kernel run concurrently with the first tier on the same records.
+  if (side_by_side) {
+    L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    L2::classify_pending(h->n, h->stream, p, h->pending_leg);
+    const bool forked = hipEventRecord(h->ev_fork, h->stream) == hipSuccess && hipStreamWaitEvent(h->side, h->ev_fork, 0) == hipSuccess;
+    if (forked) {
+      cassie::VecParams pd = p;
+      pd.pending = h->pending_leg; pd.pending_pick = cassie::PICK_DEEP;
+      L2::step_k1(mode, L2::K1_DEEP, h->n, h->side, pd, L2::K1_HANDOVER_SPLIT);
+      const bool joined = hipEventRecord(h->ev_join, h->side) == hipSuccess;
+      p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_SHALLOW;
+      L2::step_g16(mode, h->n, h->stream, p2, h->pending);
+      L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3, L2::K1_HANDOVER_SPLIT);
+      if (!joined || hipStreamWaitEvent(h->stream, h->ev_join, 0) != hipSuccess) hipStreamSynchronize(h->side);   // join the hard way
+      return;
     }
+    // no fork: the tagged environments are finished on the caller's stream (the deep ones first, then the others)
+    cassie::VecParams pd = p;
+    pd.pending = h->pending_leg; pd.pending_pick = cassie::PICK_DEEP;
+    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, pd, L2::K1_HANDOVER_SPLIT);
+    p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_SHALLOW;
     L2::step_g16(mode, h->n, h->stream, p2, h->pending);
-    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3);
+    L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3, L2::K1_HANDOVER_SPLIT);
     return;
   }
-  L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
-  L2::classify_pending(h->n, h->stream, p, h->pending_leg);
-  hipEventRecord(h->ev_fork, h->stream);
-  hipStreamWaitEvent(h->side, h->ev_fork, 0);
-  cassie::VecParams pd = p;
-  pd.pending = h->pending_leg; pd.pending_pick = cassie::PICK_DEEP;
-  L2::step_k1(mode, L2::K1_DEEP, h->n, h->side, pd, L2::K1_HANDOVER_SPLIT);
-  hipEventRecord(h->ev_join, h->side);
-  p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_SHALLOW;
+  if (h->leg) {
+    L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
+  }
   L2::step_g16(mode, h->n, h->stream, p2, h->pending);
-  L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3, L2::K1_HANDOVER_SPLIT);
-  hipStreamWaitEvent(h->stream, h->ev_join, 0);
+  L2::step_k1(mode, L2::K1_DEEP, h->n, h->stream, p3);
 }
 
 // The same tiers on the height field (one stream: robots on terrain have not been profiled lying down).

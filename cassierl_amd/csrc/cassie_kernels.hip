@@ -28,6 +28,7 @@
 
 #include "cassie2d_planar.h"
 #include "cassie_vec_layout.h"
+#include "cassie_terrain.h"
 
 namespace cassie {
 
@@ -173,31 +174,8 @@ __device__ __forceinline__ double impedance(double d0, double d1, double width, 
   return d0 + y * (d1 - d0);
 }
 
-// ---------------------------------------------------------------- height-field terrain (N4)
-// Sphere (world centre wx, wy, wz) against the terrain: the cell under the centre is split along its (c,r)-(c+1,r+1) diagonal,
-// the triangle under the centre gives the local plane z = z00 + a X + b Y, and the sphere is tested against that plane's
-// slice at its own y (the mechanism lives in the sagittal plane): normal (-a, 1)/sqrt(1 + a^2) in (x, z), distance measured in
-// that plane.  Outside the field: the floor plane z = 0.  Same arithmetic, in the same order, as the CPU restatement the
-// parity tests check against (a restatement; MuJoCo's own prism/convex test has no closed form -- see DESIGN.md).
-__device__ __forceinline__ void terrain_sphere(const Terrain& t, double wx, double wy, double wz, double radius, double& dist, double& nx, double& nz) {
-  const int nr = t.nrow, nc = t.ncol;
-  const double dx = 2.0 * t.sx / (nc - 1), dy = 2.0 * t.sy / (nr - 1);
-  const double gx = (wx + t.sx) / dx, gy = (wy + t.sy) / dy;
-  nx = 0.0; nz = 1.0; dist = wz - radius;
-  if (!(gx >= 0.0 && gx <= (double)(nc - 1) && gy >= 0.0 && gy <= (double)(nr - 1))) return;
-  int ci = (int)gx, ri = (int)gy;
-  ci = ci > nc - 2 ? nc - 2 : ci;
-  ri = ri > nr - 2 ? nr - 2 : ri;
-  const double fx = gx - ci, fy = gy - ri;
-  const double* h0 = t.h + (size_t)ri * nc + ci;
-  const double z00 = h0[0], z10 = h0[1], z01 = h0[nc], z11 = h0[nc + 1];
-  double a, b;
-  if (fy <= fx) { a = (z10 - z00) / dx; b = (z11 - z10) / dy; }
-  else { a = (z11 - z01) / dx; b = (z01 - z00) / dy; }
-  const double zs = z00 + a * (fx * dx) + b * (fy * dy);
-  nz = 1.0 / sqrt(1.0 + a * a); nx = -a * nz;
-  dist = (wz - zs) * nz - radius;
-}
+// height-field terrain (N4): terrain_sphere() -- the sphere against the closest feature of the terrain's sagittal section -- lives in
+// cassie_terrain.h (shared with the other kernel families and the CPU instantiation of the two-lanes-per-environment core)
 
 // ---------------------------------------------------------------- planar forward kinematics on the link lanes
 // Reads sm.q/sm.v-like arrays (qsrc, vsrc), writes link arrays.  SEM selects the model semantics table.

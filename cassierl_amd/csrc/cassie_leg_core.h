@@ -29,7 +29,7 @@
 //
 // The code is written against a small "backend" B (per-lane types D/I/M, lane-pair exchange, table gathers, per-lane LDS
 // slots) so that the SAME source is compiled (a) by hipcc with B = the gfx950 backend of cassie_kernels_leg.hip -- the
-// product -- and (b) by g++ with a two-lane emulation (tests/host_emul/) that the CPU test-suite checks against the oracle.
+// product -- and (b) by g++ with a lane emulation (oracle/leg_host/) that the CPU test-suite checks against the oracle.
 // (b) is test infrastructure: the library has no CPU path.
 #ifndef CASSIE_LEG_CORE_H_
 #define CASSIE_LEG_CORE_H_
@@ -37,6 +37,7 @@
 #include "cassie2d_planar.h"
 #include "cassie2d_legk.h"
 #include "cassie_vec_layout.h"
+#include "cassie_terrain.h"
 
 #ifndef LEG_FN
 #define LEG_FN __device__ __forceinline__
@@ -52,6 +53,7 @@ constexpr int LNV = CP_NV;
 constexpr double LH = CP_TIMESTEP;
 constexpr double LMINVAL = 1e-15;
 constexpr int CAP = 8;  // constraint rows per leg
+#define LEG_NPAIR_SLOTS 3   // contact-pair descriptor slots per lane
 #ifndef LEG_ITERS
 #define LEG_ITERS CP_ITERATIONS   // (timing experiments only: -DLEG_ITERS=n)
 #endif

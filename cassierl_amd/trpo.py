@@ -432,9 +432,19 @@ class TRPO:
     def save(self, path, extra=None):
         """Tensors and plain Python values only (loaded with weights_only=True), written to `path.tmp` and renamed into place so
         that a crash during the write never corrupts the one snapshot_mode='last' file."""
+        import io
         import os
         env = getattr(self, "env", None)
-        ck = dict(policy={k: v.detach().cpu() for k, v in self.policy.state_dict().items()},
+        if extra is not None:   # `extra` must survive the weights_only load of load(): refuse at save time what could not be read back
+            buf = io.BytesIO()
+            torch.save(dict(extra=extra), buf)
+            buf.seek(0)
+            try:
+                torch.load(buf, map_location="cpu", weights_only=True)
+            except Exception as ex:
+                raise TypeError("TRPO.save: `extra` must be tensors / plain Python values (weights_only round trip failed: %r)" % (ex,))
+        n_global = self.n_envs * (dist.get_world_size() if dist.is_initialized() else 1)
+        ck = dict(n_envs_global=int(n_global), policy={k: v.detach().cpu() for k, v in self.policy.state_dict().items()},
                   baseline=None if self.baseline.coeffs is None else self.baseline.coeffs.detach().cpu(), itr=int(self.itr), extra=extra,
                   noise_step=int(self.noise_step), noise_seed=int(self.seed), gen_state=self.gen.get_state(), obs=None if self.obs is None else self.obs.cpu(),
                   path_t=self.path_t.cpu(), path_ret=self.path_ret.cpu(), steps_to_trunc=int(self._steps_to_trunc),
@@ -456,7 +466,12 @@ class TRPO:
         self.itr = ck["itr"]
         env = getattr(self, "env", None)
         restored = False
-        if restore_sampler and os.path.exists(mine) and ck.get("env_state") is not None and env is not None \
+        n_global = self.n_envs * (dist.get_world_size() if dist.is_initialized() else 1)
+        # the sampler comes back only if the snapshot carries all of it and was written by a job of the same shape: the noise stream is
+        # drawn over the job's GLOBAL env range, so a different world size would silently change it (snapshots written before the
+        # noise counter existed have no "noise_step": policy / baseline only, restored = False)
+        complete = all(k in ck for k in ("noise_step", "obs", "path_t", "path_ret")) and ck.get("n_envs_global", n_global) == n_global
+        if restore_sampler and complete and os.path.exists(mine) and ck.get("env_state") is not None and env is not None \
                 and tuple(ck["env_state"].shape) == (self.n_envs, 88):
             env.set_full_state_host(ck["env_state"].numpy())
             self.noise_step, self.seed = ck["noise_step"], ck.get("noise_seed", self.seed)

@@ -112,8 +112,20 @@ class CassieVecEnv:
 
     @property
     def observation_space(self):
-        high = np.full((26,), 1e20)  # cassie2d.py:337-341
+        """cassie2d.py:337-341 declares Box(26) (17 op-space values + 9 reference-gait joints); cassie_stand2d.py:241-244 declares
+        Box(17): its step() returns the 17 op-space values only.  The batched ABI always fills [n_envs, 26] (SURVEY Q5: "return 26;
+        expose 17-view"): for kind="stand" the declared space is the 17-wide one and `obs_view()` gives the matching view."""
+        high = np.full((self.obs_dim,), 1e20)
         return Box(-high, high)
+
+    @property
+    def obs_dim(self):
+        return 17 if self.kind == "stand" else 26
+
+    def obs_view(self, obs):
+        """The observation as the reference's env of this kind returns it: [..., :17] for cassie_stand2d.py, all 26 for cassie2d.py
+        (a view of the [n_envs, 26] tensor / array the step wrote; no copy)."""
+        return obs[..., :self.obs_dim]
 
     @property
     def action_space(self):

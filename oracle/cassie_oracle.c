@@ -345,12 +345,15 @@ static int plane_sphere(Contact* c, const double* center, double radius) {
 
 /* Sphere against the terrain of a <geom type="hfield"> (terrain_random.py:38-76 adds one over the floor plane).
  * RESTATEMENT, not MuJoCo's algorithm: MuJoCo collides the sphere with the triangular prisms of the grid cells under it
- * through its general convex solver (mjc_ConvexHField), which has no closed form.  Here the test is the planar analogue the
- * judge's review asked for: the cell under the sphere centre is split along its (c,r)-(c+1,r+1) diagonal like MuJoCo's prisms,
- * the triangle under the centre gives the local plane z = z00 + a X + b Y, and because the mechanism lives in the sagittal
- * plane the sphere is tested against that plane's SLICE at the sphere's own y (a line of slope a in x-z): normal
- * (-a, 0, 1)/sqrt(1 + a^2), distance measured in the x-z plane, contact point half-way into the penetration as for
- * plane-sphere.  Outside the field's extent the floor plane z = 0 is the ground.  One contact per sphere. */
+ * through its general convex solver (mjc_ConvexHField), which has no closed form.  What is kept of it: the triangulation (every
+ * cell split along its (c,r)-(c+1,r+1) diagonal) and the closest-feature semantics (face, edge or vertex, with that feature's
+ * normal).  What is dropped: the mechanism lives in the sagittal plane, so the surface is met through its SECTION at the sphere's
+ * own y -- a polyline in x-z whose vertices are the crossings of the cell edges (x = c dx) and of the cell diagonals
+ * (x = (c + fy) dx) -- and the y-slope of the relief is ignored.  The sphere centre is compared with every section segment of
+ * the cells that overlap [x - radius, x + radius]; the closest point gives distance and normal (r04; r03 only knew the extended
+ * line under the centre).  MuJoCo may return one contact per prism; this keeps the closest feature only.
+ * Outside the field's extent the floor plane z = 0 is the ground.  One contact per sphere, contact point half-way into the
+ * penetration as for plane-sphere. */
 static int hfield_sphere(const Oracle* o, Contact* c, const double* center, double radius) {
   const int nr = o->hf_nrow, nc = o->hf_ncol;
   const double dx = 2.0 * o->hf_sx / (nc - 1), dy = 2.0 * o->hf_sy / (nr - 1);
@@ -360,13 +363,44 @@ static int hfield_sphere(const Oracle* o, Contact* c, const double* center, doub
   if (ci > nc - 2) ci = nc - 2;
   if (ri > nr - 2) ri = nr - 2;
   const double fx = gx - ci, fy = gy - ri;
+  /* cells whose x-extent overlaps [x - radius, x + radius] */
+  int c0 = (int)floor(gx - radius / dx), c1 = (int)floor(gx + radius / dx);
+  if (c0 < 0) c0 = 0;
+  if (c1 > nc - 2) c1 = nc - 2;
+  /* closest point of the section polyline (world x): per cell the segments E(c)-Dg(c) and Dg(c)-E(c+1) */
+  double best = 1e300, bq[2] = {0, 0};
+  for (int col = c0; col <= c1; col++) {
+    double px[3], pz[3];
+    const double h00 = o->hf[ri * nc + col], h01 = o->hf[(ri + 1) * nc + col];
+    const double h10 = o->hf[ri * nc + col + 1], h11 = o->hf[(ri + 1) * nc + col + 1];
+    px[0] = -o->hf_sx + col * dx;        pz[0] = (1.0 - fy) * h00 + fy * h01;
+    px[1] = -o->hf_sx + (col + fy) * dx; pz[1] = (1.0 - fy) * h00 + fy * h11;
+    px[2] = -o->hf_sx + (col + 1) * dx;  pz[2] = (1.0 - fy) * h10 + fy * h11;
+    for (int s = 0; s < 2; s++) {
+      const double ux = px[s + 1] - px[s], uz = pz[s + 1] - pz[s];
+      const double len2 = ux * ux + uz * uz;
+      double tt = len2 > 0 ? ((center[0] - px[s]) * ux + (center[2] - pz[s]) * uz) / len2 : 0.0;
+      if (tt < 0) tt = 0;
+      if (tt > 1) tt = 1;
+      const double qx = px[s] + tt * ux, qz = pz[s] + tt * uz;
+      const double dd = hypot(center[0] - qx, center[2] - qz);
+      if (dd < best) { best = dd; bq[0] = qx; bq[1] = qz; }
+    }
+  }
+  /* the face under the centre (triangle of cell ci chosen by the diagonal): side of the surface, fallback normal */
   const double z00 = o->hf[ri * nc + ci], z10 = o->hf[ri * nc + ci + 1], z01 = o->hf[(ri + 1) * nc + ci], z11 = o->hf[(ri + 1) * nc + ci + 1];
   double a, b;
   if (fy <= fx) { a = (z10 - z00) / dx; b = (z11 - z10) / dy; }
   else { a = (z11 - z01) / dx; b = (z01 - z00) / dy; }
   const double zs = z00 + a * (fx * dx) + b * (fy * dy);
-  const double nz = 1.0 / sqrt(1.0 + a * a), nx = -a * nz;
-  const double dist = (center[2] - zs) * nz - radius;
+  const double fnz = 1.0 / sqrt(1.0 + a * a), fnx = -a * fnz;
+  const double above_face = (center[2] - zs) * fnz;
+  double nx, nz, dist;
+  if (above_face > 0 && best > 1e-12 && center[2] > bq[1]) {
+    nx = (center[0] - bq[0]) / best; nz = (center[2] - bq[1]) / best; dist = best - radius;
+  } else { /* centre at or under the surface: the face under it (not reached by the 20 mm spheres of this model) */
+    nx = fnx; nz = fnz; dist = above_face - radius;
+  }
   if (dist >= 0) return 0;
   const double back = radius + 0.5 * dist;
   c->dist = dist;

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE: ctypes view of tests/host_emul/leg_host.cpp -- the source of the two-lanes-per-environment HIP kernel
+"""CHECKER / CPU-BASELINE INFRASTRUCTURE: ctypes view of oracle/leg_host/leg_host.cpp -- the source of the two-lanes-per-environment HIP kernel
 (cassierl_amd/csrc/cassie_leg_core.h) compiled for the CPU with a lane-pair emulation -- behind the subset of the
 CassieVecEnv interface the parity tests use, so that the same test bodies run against it without a GPU."""
 import ctypes as ct
@@ -9,22 +9,30 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-BUILD = os.path.join(HERE, "_build")
 MODES = {"PD": 0, "Torque": 1, "Record": 2}
 _LIB = None
+_FAST = None
 dp = ct.POINTER(ct.c_double)
 
 
-def lib():
-    global _LIB
+def _srcs():
+    c = os.path.join(ROOT, "cassierl_amd", "csrc")
+    return [os.path.join(HERE, "leg_host", "leg_host.cpp")] + [os.path.join(c, f) for f in (
+        "cassie_leg_core.h", "cassie2d_planar.h", "cassie2d_legk.h", "cassie_vec_layout.h", "cassie_terrain.h")]
+
+
+def lib(fast=False):
+    """libleg_host.so (parity / op-counting build) or, fast=True, libleg_host_fast.so (bench.py's same-source CPU leg, made on this
+    box with -march=native)."""
+    global _LIB, _FAST
+    if fast:
+        if _FAST is None:
+            subprocess.check_call(["make", "-s", "-B", "-C", HERE, "libleg_host_fast.so"])
+            _FAST = ct.CDLL(os.path.join(HERE, "libleg_host_fast.so"))
+        return _FAST
     if _LIB is None:
-        os.makedirs(BUILD, exist_ok=True)
-        so = os.path.join(BUILD, "libleg_host.so")
-        srcs = [os.path.join(HERE, "host_emul", "leg_host.cpp")] + [os.path.join(ROOT, "cassierl_amd", "csrc", f)
-                                                                    for f in ("cassie_leg_core.h", "cassie2d_planar.h", "cassie_vec_layout.h")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
-        _LIB = ct.CDLL(so)
+        import oracle_py
+        _LIB = ct.CDLL(oracle_py.make("libleg_host.so", _srcs()))
         _LIB.leg_host_ops.restype = ct.c_double
     return _LIB
 
@@ -66,13 +74,13 @@ class LegHostEnv:
             lib().leg_host_step_hf(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
                                    0 if self.kind == "walk" else 1, int(self.auto_reset), _p(hm), hm.shape[0], hm.shape[1], ct.c_double(sx), ct.c_double(sy),
                                    _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None,
-                                   self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad))
+                                   self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)
             self.nonfinite += bad.value
             return obs, rew, done.astype(bool)
         lib().leg_host_step(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
                             0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
                             _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,
-                            self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad))
+                            self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)
         self.nonfinite += bad.value
         return obs, rew, done.astype(bool)
 

@@ -15,13 +15,37 @@ NV, NU = 13, 6
 dp = ct.POINTER(ct.c_double)
 
 
-def build(force=False):
-    so = os.path.join(HERE, "liboracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("cassie_oracle.c", "cassie_oracle_ctrl.inc", "cassie_oracle_env.inc",
-                                            "cassie_oracle.h", "cassie2d_model.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+def content_hash(srcs, tag=""):
+    import hashlib
+    h = hashlib.sha256(tag.encode())
+    for f in srcs:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def make(target, srcs, force=False):
+    """`make <target>` in oracle/ when the library is missing or its sources changed -- decided by the CONTENT of the sources (a stamp
+    file beside the library), not by file times: a copy of the tree to a GPU box keeps no promise about mtimes."""
+    so = os.path.join(HERE, target)
+    want = content_hash(srcs + [os.path.join(HERE, "Makefile")], target)
+    try:
+        fresh = os.path.exists(so) and open(so + ".stamp").read() == want
+    except OSError:
+        fresh = False
+    if force or not fresh:
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, target])
+        with open(so + ".stamp", "w") as f:
+            f.write(want)
     return so
+
+
+ORACLE_SRCS = [os.path.join(HERE, f) for f in ("cassie_oracle.c", "cassie_oracle_ctrl.inc", "cassie_oracle_env.inc", "cassie_oracle.h",
+                                               "cassie2d_model.h")]
+
+
+def build(force=False):
+    return make("liboracle.so", ORACLE_SRCS, force)
 
 
 _FAST = False
@@ -33,7 +57,7 @@ def use_fast_build():
     global _FAST
     assert _LIB is None, "use_fast_build() must come before the oracle library is first used"
     try:
-        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "liboracle_fast.so"])
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "liboracle_fast.so"])   # -march=native: always made on the box that runs it
         _FAST = True
     except Exception:
         _FAST = False
@@ -273,11 +297,7 @@ _LIB3 = None
 
 
 def build3d(force=False):
-    so = os.path.join(HERE, "liboracle3d.so")
-    srcs = [os.path.join(HERE, f) for f in ("cassie_oracle.c", "cassie_oracle.h", "cassie3d_model.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle3d.so"])
-    return so
+    return make("liboracle3d.so", [os.path.join(HERE, f) for f in ("cassie_oracle.c", "cassie_oracle.h", "cassie3d_model.h")], force)
 
 
 def lib3d():

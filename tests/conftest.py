@@ -14,6 +14,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # always print the slowest tests: the driver's log of `pytest -m gpu` then says where a slow box spent its time
+    if getattr(config.option, "durations", None) is None:
+        config.option.durations = 20
+        config.option.durations_min = 1.0
+
+
+@pytest.fixture(params=["g16", "leg"])
+def vec_tier(request):
+    """CassieVecEnv with the FIRST physics tier pinned: "g16" = four environments per wavefront (what a small batch gets by the
+    size rule), "leg" = the two-lanes-per-environment kernel (`env_step_leg_kernel`, the kernel behind the bench headline, which
+    the size rule only selects from 6144 environments up).  The oracle / golden-stream tests take this fixture so that the
+    driver's plain `pytest -m gpu` run pins BOTH against the oracle, whatever the batch size of the test."""
+    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_OFF, LEG_TIER_ON
+    add = LEG_TIER_ON if request.param == "leg" else LEG_TIER_OFF
+
+    def make(*a, flags=0, **k):
+        return CassieVecEnv(*a, flags=flags | add, **k)
+    make.tier = request.param
+    return make
 
 
 @pytest.fixture(scope="session")

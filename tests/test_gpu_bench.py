@@ -44,7 +44,9 @@ def test_bench_line_contract_small():
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["config"]["envs_per_gpu"] == 2048 and line["finite"]
     assert line["unit"] == "env-steps/s" and line["dtype"] == "f64" and line["scaling"] == "weak"
     r = line["roofline"]
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["hbm"]["unit"] == "GB/s" and abs(r["hbm"]["frac"] - r["hbm"]["achieved"] / r["hbm"]["peak"]) < 1e-12
+    assert abs(r["hbm"]["achieved"] - 905 * 2048 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-9 * r["hbm"]["achieved"]
     assert abs(line["value"] - 2048 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]
     assert line["episodes_terminated_per_env_step"] == 1.0  # quirk Q3: the reference-faithful walk env ends every step
 
@@ -118,7 +120,7 @@ def test_launcher_stops_all_ranks_when_one_dies():
     """a rank that dies must take the run down at once (the survivors would otherwise wait in a collective until a
     watchdog fires).  Rank 1 is made to exit before the rendezvous; the launcher must return non-zero within seconds."""
     import time
-    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_FAIL_RANK="1")
+    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_HOOKS="1", CASSIE_TEST_FAIL_RANK="1")
     t0 = time.time()
     rc, out, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline"], env, timeout=600)
     assert rc != 0 and "rank 1 exited" in err and time.time() - t0 < 300

@@ -28,7 +28,8 @@ def jac_action(rng):
 
 
 @pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
-def test_teacher_forced_controller_substeps(vec, oracle_mod, mode):
+def test_teacher_forced_controller_substeps(vec_tier, oracle_mod, mode):
+    vec = vec_tier
     rng = np.random.default_rng(21)
     n = 2
     env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
@@ -51,7 +52,8 @@ def test_teacher_forced_controller_substeps(vec, oracle_mod, mode):
     env.close()
 
 
-def test_env_step_osc_golden_stream(vec, streams, traj):
+def test_env_step_osc_golden_stream(vec_tier, streams, traj):
+    vec = vec_tier
     n = 2
     env = vec(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
     obs0 = env.reset_host()
@@ -65,14 +67,15 @@ def test_env_step_osc_golden_stream(vec, streams, traj):
     env.close()
 
 
-@pytest.mark.parametrize("wave_per_env", [False, True])
+@pytest.mark.parametrize("wave_per_env", [False, True, "leg"])
 def test_walk_env_with_osc_control_golden_stream(vec, streams, traj, wave_per_env):
     """cassie2d.py with control_mode = 'OSC' (the walk env accepts it, cassie2d.py:53,104-105): reference-gait reward, r < 0.6
     termination, gait joints in obs[17:26] -- recorded from the reference's own class (tests/golden/make_env_streams.py).
     r01 computed the stand reward here."""
-    from cassierl_amd.vec_env import WAVE_PER_ENV
+    from cassierl_amd.vec_env import LEG_TIER_ON, WAVE_PER_ENV
     n = 3
-    env = vec(n, kind="walk", control_mode="OSC", n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV if wave_per_env else 0)
+    flags = LEG_TIER_ON if wave_per_env == "leg" else (WAVE_PER_ENV if wave_per_env else 0)   # "leg": mj_step in env_step_leg_kernel<2>
+    env = vec(n, kind="walk", control_mode="OSC", n_substeps=10, auto_reset=True, flags=flags)
     env.set_trajectory(traj["time"], traj["qpos"])
     obs0 = env.reset_host()
     np.testing.assert_allclose(obs0, np.tile(streams["walk_osc_obs0"], (n, 1)), atol=1e-12)
@@ -109,8 +112,9 @@ def _py_standing_jac(o, zpos, zvel):
     o.step_jacobian(np.array([fx, fz, my, fx, fz, my]))
 
 
-def test_standing_controller_osc_free_running(vec, oracle_mod):
+def test_standing_controller_osc_free_running(vec_tier, oracle_mod):
     """config 3 building block: standing_controller_osc(0.9, 0) in the loop, closed loop is stable -> free-running parity."""
+    vec = vec_tier
     n = 3
     env = vec(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
     env.reset_host()
@@ -130,8 +134,9 @@ def test_standing_controller_osc_free_running(vec, oracle_mod):
     env.close()
 
 
-def test_squatting_jacobian_controller(vec, oracle_mod):
+def test_squatting_jacobian_controller(vec_tier, oracle_mod):
     """config 1 (squatting.py): z target 0.7 + 0.25 sin(w t), w = 0.5*3.1415, via standing_controller_jacobian."""
+    vec = vec_tier
     env = vec(1, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False)
     env.reset_host()
     o = oracle_mod.Oracle()

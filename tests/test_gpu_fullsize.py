@@ -30,15 +30,15 @@ def vec():
 
 
 # ------------------------------------------------------------------------------------------------ configs[1]
+@pytest.mark.parametrize("n", [4096, 8192])   # 8192: the default size rule makes env_step_leg_kernel the first tier (>= 6144 envs)
 @pytest.mark.parametrize("flags,steps,tol", [(0, 20, 1e-8), (FIXQ, 8, 1e-6)])
-def test_configs1_4096_walk_pd_sampled_envs_follow_the_oracle(vec, oracle_mod, traj, flags, steps, tol):
+def test_configs1_4096_walk_pd_sampled_envs_follow_the_oracle(vec, oracle_mod, traj, flags, steps, tol, n):
     """configs[1]: 4096 envs, walk env, PD mode, random policy.  64 sampled environments are replayed by the oracle env with
     the same actions.  flags=0 is the reference-faithful regime (quirk Q3: every step terminates and auto-resets, so the
     comparison holds for any number of steps); with CASSIE_FIX_STALE_QSTATE the robots run free, so the window is the
     first 80 substeps (PD is chaotic beyond ~100, see test_gpu_parity.py)."""
     import torch
     from cassierl_amd import rollout as R
-    n = 4096
     env = vec(n, kind="walk", control_mode="PD", n_substeps=10, flags=flags, auto_reset=True)
     env.set_trajectory(traj["time"], traj["qpos"])
     sample = np.unique(np.concatenate([np.arange(0, n, 67), [1, 2, 3, n - 1]]))[:64]
@@ -64,7 +64,7 @@ def test_configs1_4096_walk_pd_sampled_envs_follow_the_oracle(vec, oracle_mod, t
     assert worst < tol, worst
     c = env.counters()
     assert c["nonfinite_resets"] == 0
-    record(test="configs1_4096_walk_pd", flags=flags, steps=steps, sampled=len(sample), worst=worst, episodes=ndone, **c)
+    record(test="configs1_%d_walk_pd" % n, first_tier="leg" if n >= 6144 else "g16", flags=flags, steps=steps, sampled=len(sample), worst=worst, episodes=ndone, **c)
     env.close()
 
 

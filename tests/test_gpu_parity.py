@@ -79,7 +79,8 @@ def test_constructor_matches_cassie2d_ctor(vec, oracle_mod):
 
 
 @pytest.mark.parametrize("mode", ["Torque", "PD"])
-def test_teacher_forced_1000_substeps(vec, oracle_mod, mode):
+def test_teacher_forced_1000_substeps(vec_tier, oracle_mod, mode):
+    vec = vec_tier
     rng = np.random.default_rng(1)
     n = 2
     env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False)
@@ -102,7 +103,8 @@ def test_teacher_forced_1000_substeps(vec, oracle_mod, mode):
     env.close()
 
 
-def test_free_running_torque_1000_substeps(vec, oracle_mod):
+def test_free_running_torque_1000_substeps(vec_tier, oracle_mod):
+    vec = vec_tier
     rng = np.random.default_rng(2)
     n = 8
     env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
@@ -135,12 +137,13 @@ def _state_dist(a, q, v):
     return max(np.abs(a[:13] - q).max() / np.abs(q).max(), np.abs(a[13:26] - v).max() / (1e-3 + np.abs(v).max()))
 
 
-def test_pd_1000_substeps_shadowing_bound(vec, oracle_mod):
+def test_pd_1000_substeps_shadowing_bound(vec_tier, oracle_mod):
     """North-star horizon for the mode the bench and TRPO run (Cassie2d::StepPd, Cassie2d.cpp:96-117): 1000 FREE-RUNNING PD
     substeps, 8 envs.  The PD law is chaotic in the reference itself, so agreement is asserted relative to the oracle's own
     sensitivity: E(t) = running max over four 1-ulp perturbations of qpos(0) of ||oracle_perturbed - oracle||(t); the HIP
     trajectory must satisfy ||hip - oracle||(t) <= C * E(t) + floor at every Env.step boundary, i.e. it is
     indistinguishable from an oracle run whose initial state was off by ~C ulp."""
+    vec = vec_tier
     rng = np.random.default_rng(3)
     n, T = 8, 100
     acts = rng.uniform(PD_LO, PD_HI, (T, n, 6))
@@ -232,7 +235,8 @@ def test_pd_env_streams_agree_until_the_oracle_itself_flips(vec, oracle_mod, tra
     env.close()
 
 
-def test_free_running_pd_first_100_substeps(vec, oracle_mod):
+def test_free_running_pd_first_100_substeps(vec_tier, oracle_mod):
+    vec = vec_tier
     rng = np.random.default_rng(3)
     n = 4
     env = vec(n, kind="stand", control_mode="PD", n_substeps=1, auto_reset=False)
@@ -253,8 +257,9 @@ def test_free_running_pd_first_100_substeps(vec, oracle_mod):
 
 @pytest.mark.parametrize("tag,kind,mode", [("walk_pd", "walk", "PD"), ("walk_torque", "walk", "Torque"),
                                           ("stand_torque", "stand", "Torque"), ("stand_pd", "stand", "PD")])
-def test_env_step_against_golden_streams(vec, streams, traj, tag, kind, mode):
+def test_env_step_against_golden_streams(vec_tier, streams, traj, tag, kind, mode):
     """Env.step / reset / auto-reset through the batched ABI against streams recorded from the reference's own Python env."""
+    vec = vec_tier
     n = 3
     env = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True)
     env.set_trajectory(traj["time"], traj["qpos"])
@@ -272,7 +277,8 @@ def test_env_step_against_golden_streams(vec, streams, traj, tag, kind, mode):
     env.close()
 
 
-def test_env_step_vs_oracle_env_with_quirk_fixes(vec, oracle_mod, traj):
+def test_env_step_vs_oracle_env_with_quirk_fixes(vec_tier, oracle_mod, traj):
+    vec = vec_tier
     tr = dict(time=traj["time"], qpos=traj["qpos"])
     rng = np.random.default_rng(5)
     for flags in (0, 1, 3):
@@ -293,7 +299,8 @@ def test_env_step_vs_oracle_env_with_quirk_fixes(vec, oracle_mod, traj):
         env.close()
 
 
-def test_edge_cases_limits_many_contacts_single_env(vec, oracle_mod):
+def test_edge_cases_limits_many_contacts_single_env(vec_tier, oracle_mod):
+    vec = vec_tier
     # (a) n_envs = 1 (b) joint limits active (c) collapsed robot: many simultaneous contacts incl. pelvis/thigh/shin spheres
     env = vec(1, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False)
     o = oracle_mod.Oracle()
@@ -411,10 +418,11 @@ def test_g16_and_wave_per_env_kernels_agree(vec, traj):
     a.close(); b.close()
 
 
-def test_masked_reset_to_states_and_device_getters(vec, oracle_mod):
+def test_masked_reset_to_states_and_device_getters(vec_tier, oracle_mod):
     """CassieVecResetTo (Cassie2d::Reset with caller states, masked), CassieVecGetState and CassieVecGetOpState on device
     tensors against the oracle: Reset = mj_forward without setState, so the op-space state is still the one of the previous
     setState (quirk Q2) while qpos/qvel are the new ones."""
+    vec = vec_tier
     import torch
     n = 11
     rng = np.random.default_rng(23)

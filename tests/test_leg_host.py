@@ -1,5 +1,5 @@
 """The two-lanes-per-environment kernel source (cassierl_amd/csrc/cassie_leg_core.h), compiled for the CPU by
-tests/host_emul/leg_host.cpp, against the oracle: the same checks tests/test_gpu_parity.py runs on the GPU through the C-ABI,
+oracle/leg_host/leg_host.cpp, against the oracle: the same checks tests/test_gpu_parity.py runs on the GPU through the C-ABI,
 here without one -- so that a formulation error (block factorisation, factored A, row slots, sweep order) is found on the CPU."""
 import numpy as np
 import pytest
@@ -153,3 +153,45 @@ def test_height_field_ramp_teacher_forced(oracle_mod, mode):
                 sloped += 1
     assert worst < 1e-9, worst
     assert sloped > 100   # contacts with a tilted frame were really exercised
+
+
+def test_packed_leg_constants_are_in_sync_with_the_planar_tables():
+    """cassie2d_legk.h (what the two-lanes-per-environment kernel reads) is generated from cassie2d_planar.h by
+    cassierl_amd/model/pack_leg_consts.py, by hand, after compile_model.py: regenerate it in memory and compare with the checked-in
+    header, so that a model change cannot leave the kernel on stale constants."""
+    import os
+    from cassierl_amd.model import pack_leg_consts as P
+    assert P.render() == open(P.DST).read()
+
+
+def test_timing_build_equals_the_parity_build_bit_for_bit(oracle_mod):
+    """bench.py's same-source CPU leg (libleg_host_fast.so: eight lanes = four environments per AVX-512 register, -O3 -march=native,
+    OpenMP) computes what the two-lane parity build computes -- the CPU counterpart of the GPU's wavefront-neighbour tests: which
+    environments share a register must not matter.  Falling robots, torque mode, auto-reset, 3 threads over 21 environments."""
+    import ctypes as ct
+    import leg_host as LH
+    rng = np.random.default_rng(5)
+    n = 21   # not a multiple of four: the last group has idle lanes
+    a = LegHostEnv(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
+    o = oracle_mod.Oracle()
+    q, v = o.state()
+    s0 = np.tile(state_vec(q, v, o.warmstart()), (n, 1))
+    s0[:, 1] += rng.uniform(-0.01, 0.01, n)
+    a.set_full_state_host(s0)
+    fast = LH.lib(fast=True)
+    assert fast.leg_host_lanes() == 8
+    sb = s0.copy()
+    dp = ct.POINTER(ct.c_double)
+    for t in range(40):
+        acts = np.ascontiguousarray(rng.uniform(-1, 1, (n, 6)) * TQ)
+        oa, ra, da = a.step_host(acts)
+        ob, rb, db = np.zeros((n, 26)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        pend, bad = np.zeros(n, dtype=np.int32), ct.c_int(0)
+        fast.leg_host_step(sb.ctypes.data_as(dp), acts.ctypes.data_as(dp), n, 6, 1, 10, 0, 1, 1, None, ct.c_double(0.0), 0, ob.ctypes.data_as(dp),
+                           rb.ctypes.data_as(dp), db.ctypes.data_as(ct.POINTER(ct.c_ubyte)), None, pend.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 3)
+        # an environment over the rows-per-leg capacity is left untouched by both builds (the GPU hands it to the next tier): skip it from then on
+        keep = (a.pending == 0) & (pend == 0)
+        assert np.array_equal(a.pending, pend)
+        assert np.array_equal(a.state[keep], sb[keep]) and np.array_equal(ra[keep], rb[keep]) and np.array_equal(da[keep], db[keep].astype(bool))
+        if not keep.all():
+            a.state[~keep] = s0[~keep]; sb[~keep] = s0[~keep]

@@ -162,17 +162,9 @@ def test_robot_settles_on_real_terrain(oracle_mod, png):
     assert q[1] < 0.8 + T.height_at(hm, 10, 10, q[0], 0.0)  # it fell
 
 
-def test_ridge_counter_example_where_the_slice_restatement_differs_from_a_closest_feature_test(oracle_mod):
-    """What the sagittal-slice restatement of the hfield collision gets WRONG, pinned by hand arithmetic.
-    MuJoCo collides a sphere with the prisms under it by its convex solver (mjc_ConvexHField): the contact refers to the
-    CLOSEST FEATURE of the surface -- a face, an edge or a vertex.  The restatement (oracle hfield_sphere = kernel terrain_sphere)
-    only ever tests the plane of the triangle under the sphere's CENTRE, extended without bound.  Counter-example: a convex ridge,
-    flat up to x0 and falling with slope -0.5 beyond it.  A toe sphere (r = 0.02) whose centre sits 2 mm past the ridge and
-    20.5 mm above the flat part is nearest to the ridge EDGE at (x0, 0): distance sqrt(0.002^2 + 0.0205^2) - 0.02 = +0.597 mm,
-    no contact.  The restatement measures the distance to the extended downhill plane, (0.0205 + 0.5 * 0.002) / sqrt(1.25)
-    - 0.02 = -0.770 mm: it reports a contact 1.37 mm early, with the face normal (0.5, 0, 1)/sqrt(1.25) instead of the
-    edge-to-centre direction.  (At a concave kink the error has the other sign: the neighbouring uphill face is touched before
-    the plane under the centre is.)  Both deviations are confined to a band of ~r sin(kink angle) around an edge of the relief."""
+def _front_toe_over(oracle_mod, slope, past, height):
+    """An oracle whose front toe spheres (r = 0.02) sit `past` metres beyond a kink of the terrain (flat up to x0, then `slope`)
+    and `height` metres above the flat part.  Returns (oracle, x0 - centre_x offset is `past` by construction)."""
     flat = oracle_mod.Oracle()
     q0, _ = flat.state()
     flat.set_state_raw(q0 - np.array([0, 0.002] + [0] * 11), np.zeros(13), np.zeros(13))   # dip the feet 2 mm into the floor plane
@@ -184,23 +176,44 @@ def test_ridge_counter_example_where_the_slice_restatement_differs_from_a_closes
     cz = centres[np.argmax(centres[:, 0]), 2] + 0.002            # centre height of the front toe sphere in the nominal pose
     ncol = 4001                                                   # dx = 5 mm
     xg = np.linspace(-10.0, 10.0, ncol)
-    x0 = xg[np.searchsorted(xg, front - 0.002) - 1]               # a grid line just behind the sphere centre ...
-    shift = (x0 + 0.002) - front                                  # ... and the robot moved so that the centre is 2 mm past it
-    hm = T.ramp(nrow=8, ncol=ncol, size_x=10.0, slope=-0.5, x0=x0)
+    x0 = xg[np.searchsorted(xg, front - past) - 1]               # a grid line just behind the sphere centre ...
+    shift = (x0 + past) - front                                   # ... and the robot moved so that the centre is `past` beyond it
+    hm = T.ramp(nrow=8, ncol=ncol, size_x=10.0, slope=slope, x0=x0)
     o = oracle_mod.Oracle()
     o.set_hfield(hm, 10.0, 10.0)
     q = q0.copy()
     q[0] += shift
-    q[1] += 0.0205 - cz
+    q[1] += height - cz
     o.set_state_raw(q, np.zeros(13), np.zeros(13))
     o.forward()
+    return o
+
+
+def test_ridge_and_valley_are_met_through_their_closest_feature(oracle_mod):
+    """The terrain test is a CLOSEST-FEATURE test on the sagittal section (oracle hfield_sphere = kernel terrain_sphere, r04), pinned by
+    hand arithmetic on the counter-example that r03 documented as wrong.  A convex ridge: flat up to x0, falling with slope -0.5
+    beyond it.  A toe sphere (r = 0.02) whose centre sits 2 mm past the ridge and 20.5 mm above the flat part is nearest to the ridge
+    EDGE at (x0, 0): distance sqrt(0.002^2 + 0.0205^2) - 0.02 = +0.597 mm -- NO contact (r03's extended downhill plane said
+    (0.0205 + 0.5 * 0.002) / sqrt(1.25) - 0.02 = -0.770 mm: a contact 1.37 mm early with the face normal).  Lowered by 0.8 mm the sphere
+    touches the edge: dist = sqrt(0.002^2 + 0.0197^2) - 0.02 = -0.199 mm along the edge-to-centre direction.  At a concave kink (slope
+    +0.5) a sphere 2 mm BEFORE the kink touches the uphill face first: its distance to that face, (h - 0.5 * (-0.002)) / sqrt(1.25) - r,
+    is smaller than the one to the flat part under its centre."""
+    o = _front_toe_over(oracle_mod, -0.5, 0.002, 0.0205)
+    assert o.ncon == 0 and np.hypot(0.002, 0.0205) - 0.02 > 5.9e-4
+    o = _front_toe_over(oracle_mod, -0.5, 0.002, 0.0197)
     con = o.contacts()
-    # the restatement: both front toe spheres "touch" the extended downhill plane
+    assert o.ncon == 4                                             # the rear spheres stand 0.3 mm into the flat part
+    assert np.abs(con["frame"][np.argsort(con["pos"][:, 0])[:2], :3] - np.array([0, 0, 1.0])).max() == 0
+    n_edge = np.array([0.002, 0.0, 0.0197]) / np.hypot(0.002, 0.0197)
+    for i in np.argsort(con["pos"][:, 0])[2:]:                     # the two front toe spheres: on the ridge edge
+        assert np.abs(con["frame"][i].reshape(3, 3)[0] - n_edge).max() < 5e-6      # the placement is good to ~3e-8 m of the 2 mm offset
+        assert abs(con["dist"][i] - (np.hypot(0.002, 0.0197) - 0.02)) < 1e-7
+    # concave kink: centre 2 mm before the kink, 20.5 mm above the flat part: clear of the flat part (+0.5 mm), but the uphill face
+    # beyond the kink is (0.0205 + 0.5 * 0.002) / sqrt(1.25) - 0.02 = -0.770 mm away: contact with THAT face's normal
+    o = _front_toe_over(oracle_mod, 0.5, -0.002, 0.0205)
+    con = o.contacts()
     assert o.ncon == 2
-    n_face = np.array([0.5, 0.0, 1.0]) / np.sqrt(1.25)
+    n_face = np.array([-0.5, 0.0, 1.0]) / np.sqrt(1.25)
     for i in range(2):
-        assert np.abs(con["frame"][i].reshape(3, 3)[0] - n_face).max() < 1e-12
-        assert abs(con["dist"][i] - ((0.0205 + 0.5 * 0.002) / np.sqrt(1.25) - 0.02)) < 1e-7   # the placement above is good to ~1e-8 m
-    # the closest-feature answer for the same sphere: the ridge edge, 0.597 mm away -- no contact
-    true_dist = np.hypot(0.002, 0.0205) - 0.02
-    assert true_dist > 5e-4 and con["dist"][0] < -7e-4
+        assert np.abs(con["frame"][i].reshape(3, 3)[0] - n_face).max() < 1e-9
+        assert abs(con["dist"][i] - ((0.0205 + 0.5 * 0.002) / np.sqrt(1.25) - 0.02)) < 1e-7
