@@ -598,13 +598,14 @@ def worker(args):
             # two CPU legs on this box's host cores: the SAME SOURCE as the HIP kernel through its host backend (the fair one), and
             # the oracle (dense 3-D O(n^3) restatement, the parity checker)
             try:
+                orc = cpu_baseline(traj, cores)   # first: it binds the oracle's -O3 -march=native build before anything loads the library
+            except Exception as ex:
+                orc = {"error": repr(ex)}
+            try:
                 line["cpu_baseline"] = cpu_same_source(traj, cores)
             except Exception as ex:
                 line["cpu_baseline"] = {"error": "same-source leg: " + repr(ex)}
-            try:
-                line["cpu_baseline"]["oracle"] = cpu_baseline(traj, cores)
-            except Exception as ex:
-                line["cpu_baseline"]["oracle"] = {"error": repr(ex)}
+            line["cpu_baseline"]["oracle"] = orc
             if "extra" in line:
                 try:
                     line["extra"] += cpu_legs_other_configs()

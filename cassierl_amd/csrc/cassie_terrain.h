@@ -48,6 +48,7 @@ CASSIE_TERRAIN_FN void terrain_sphere(const Terrain& t, double wx, double wy, do
   const double gx = (wx + t.sx) / dx, gy = (wy + t.sy) / dy;
   nx = 0.0; nz = 1.0; dist = wz - radius;
   if (!(gx >= 0.0 && gx <= (double)(nc - 1) && gy >= 0.0 && gy <= (double)(nr - 1))) return;
+  if (dist > t.hmax) { dist = dist - t.hmax; return; }   // clear of the highest point of the field (most spheres of a standing robot): a lower bound, > 0
   int ci = (int)gx, ri = (int)gy;
   ci = ci > nc - 2 ? nc - 2 : ci;
   ri = ri > nr - 2 ? nr - 2 : ri;
