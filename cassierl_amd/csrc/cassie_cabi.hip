@@ -41,7 +41,6 @@ struct CassieVec {
   double *d_act = nullptr, *d_obs = nullptr, *d_rew = nullptr, *d_q = nullptr, *d_v = nullptr, *d_dbg = nullptr;
   double *ovf = nullptr, *ovf_dbg = nullptr;  // workspace for constraint columns beyond the register-resident ones
   int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
-  double* wide = nullptr;                    // scratch rows of the two-lanes-per-environment kernel's wide substep, one block per wavefront
   int* pending_leg = nullptr;                // substeps left per env after the two-lanes-per-env kernel (input of the 4-envs-per-wave kernel)
   bool leg = true;                           // first tier = the two-lanes-per-environment kernel (CASSIE2D_LEG=0/1 overrides the size rule)
   unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
@@ -100,7 +99,6 @@ cassie::VecParams make_params(CassieVec* h) {
   p.ovf = h->ovf;
   p.ovf_stride = OVF_STRIDE;
   p.stats = h->stats;
-  p.wide = h->wide;
   p.hf = h->hf;
   p.phase = h->phase;
   return p;
@@ -307,9 +305,6 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   { const char* e = getenv("CASSIE2D_LEG"); if (e && (e[0] == '0' || e[0] == '1')) h->leg = h->g16 && e[0] == '1'; }
   if (h->cfg.flags & CASSIE_LEG_TIER_OFF) h->leg = false;
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
-  // rows of the wide substep (environments with more than 8 rows on a leg): 270 KB per wavefront, touched only by the wavefronts that
-  // hold such an environment (fallen robots); 0.55 GB of the 288 GB at 65 536 envs
-  if (h->leg && hipMalloc(&h->wide, (size_t)((n_envs + 31) / 32) * L2::LEG_WIDE_BLOCK_BYTES) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
@@ -329,7 +324,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->wide); hipFree(h->stats); hipFree(h->phase);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->stats); hipFree(h->phase);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);

@@ -36,7 +36,7 @@ struct DevB {
   struct Lds {
     double pr[3][4][64];
     double lm[4][3][64];
-    double cold[LEG_COLD_SLOTS][64];   // Core::C_* slots
+    double cold[49][64];   // Core::C_* slots
     int pdepth[3][64];
     int lmj[4][64];
 #ifdef CASSIE_PHASE_TIMING
@@ -73,12 +73,6 @@ struct DevB {
       const int l = threadIdx.x;
       pos = lm[s][0][l]; sgn = lm[s][1][l]; invw = lm[s][2][l]; j = lmj[s][l];
     }
-  };
-  // wide substep: the wavefront's scratch block in HBM/L2, [row][field][lane] (a row's field = one coalesced 512-byte line)
-  struct Wide {
-    double* base;
-    LEG_FN void st(int row, int field, double v, bool m) { if (m) base[(row * LEG_W_NF + field) * 64 + (int)threadIdx.x] = v; }
-    LEG_FN double ld(int row, int field) const { return base[(row * LEG_W_NF + field) * 64 + (int)threadIdx.x]; }
   };
   static LEG_FN int leg() { return (int)threadIdx.x & 1; }
 #ifdef LEG_NO_FENCE
@@ -127,7 +121,6 @@ struct DevB {
 };
 
 typedef Core<DevB> DCore;
-constexpr size_t WIDE_BLOCK_DOUBLES = (size_t)LEG_W_ROWS * LEG_W_NF * 64;   // per wavefront (270 KB): touched by substep_wide only
 
 // MODE: 0 PD, 1 torque, 2 motor commands from the state record.  pending[env] = substeps this kernel did NOT do because the
 // environment needed more than 8 constraint rows on a leg (0 normally); the packed 16-row kernel / the wave-per-environment
@@ -155,9 +148,7 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   if (lane == 0) { for (int i = 0; i < 16; i++) lds.acc[i] = 0; lds.t_last = __builtin_readcyclecounter(); }
 #endif
   DCore::Out o;
-  DevB::Wide wd;
-  wd.base = p.wide + (size_t)blockIdx.x * WIDE_BLOCK_DOUBLES;
-  DCore::env_step<MODE>(cfg, lds, wd, io, valid, o);
+  DCore::env_step<MODE>(cfg, lds, io, valid, o);
 #ifdef CASSIE_PHASE_TIMING
   lds.mark(0);
   if (lane == 0 && p.phase) for (int i = 0; i < 16; i++) atomicAdd(p.phase + i, lds.acc[i]);
@@ -165,7 +156,7 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   if (valid && (lane & 1) == 0) {
     pending[e] = o.pend;
     if (p.stats) {
-      if (o.pend + o.wide > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)(o.pend + o.wide));   // left the 8-row fast path
+      if (o.pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o.pend);
       if (o.bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
     }
   }
@@ -209,13 +200,11 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_hf_kernel(VecParams p, int
   io.rew = p.reward + (cfg.want_obs ? e : 0);
   io.done = p.done + (cfg.want_obs ? e : 0);
   DCoreHF::Out o;
-  DevBHF::Wide wd;
-  wd.base = p.wide + (size_t)blockIdx.x * WIDE_BLOCK_DOUBLES;
-  DCoreHF::env_step<MODE, true>(cfg, lds, wd, io, valid, o, &p.hf);
+  DCoreHF::env_step<MODE, true>(cfg, lds, io, valid, o, &p.hf);
   if (valid && (lane & 1) == 0) {
     pending[e] = o.pend;
     if (p.stats) {
-      if (o.pend + o.wide > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)(o.pend + o.wide));
+      if (o.pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o.pend);
       if (o.bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
     }
   }

@@ -16,7 +16,6 @@ namespace launch {
 // while the 168-register build it replaced spilled 608 B per lane (r01/r02 PMC).
 enum K1Variant { K1_DEEP = 0 /* <.,1,32> */, K1_DEBUG = 2 /* <.,2,8>: forces the workspace path */ };
 constexpr int K1_MAXACT = 32, K1_MAXACT_DBG = 8;
-constexpr size_t LEG_WIDE_BLOCK_BYTES = (size_t)24 * 22 * 64 * sizeof(double);   // = LEG_W_ROWS x LEG_W_NF x 64 lanes (cassie_leg_core.h; checked in tu_leg.hip)
 constexpr int K1_HANDOVER_SPLIT = 8;  // workgroups that share the pending environments of one 64-environment block (hand-over pass while robots are down)
 
 // tu_base.hip: wave-per-environment kernels (mode: 0 PD, 1 torque, 2 motor commands from the state record; K1_DEBUG: modes 0, 1)

@@ -42,9 +42,6 @@
 #ifndef LEG_FN
 #define LEG_FN __device__ __forceinline__
 #endif
-#ifndef LEG_WIDE_FN   // the wide substep is a real function on the device: its registers are saved where IT runs, not in the kernel's fast path
-#define LEG_WIDE_FN __device__ __attribute__((noinline))
-#endif
 #ifndef LEG_FP_CONTRACT_OFF
 #define LEG_FP_CONTRACT_OFF _Pragma("clang fp contract(off)")
 #endif
@@ -57,9 +54,6 @@ constexpr double LH = CP_TIMESTEP;
 constexpr double LMINVAL = 1e-15;
 constexpr int CAP = 8;  // constraint rows per leg
 #define LEG_NPAIR_SLOTS 3   // contact-pair descriptor slots per lane
-// wide substep (substep_wide): rows per leg and fields per row of the per-wavefront scratch block B::Wide ([row][field][lane])
-constexpr int LEG_W_ROWS = 24, LEG_W_NF = 22;
-constexpr int LEG_COLD_SLOTS = 49;   // = Core::C_N (per-lane cold slots; a backend sizes its storage with this)
 #ifndef LEG_ITERS
 #define LEG_ITERS CP_ITERATIONS   // (timing experiments only: -DLEG_ITERS=n)
 #endif
@@ -110,10 +104,9 @@ template <class B> struct Core {
     C_OZ = 43,    // 6: ... z
     C_N = 49
   };
-  static_assert(C_N == LEG_COLD_SLOTS, "cold slots");
   struct Out {
     M do_reset, bad, set_state;
-    I pend, niter, wide;   // wide: substeps this environment did in substep_wide (more than 8 rows on a leg)
+    I pend, niter;
   };
 
   // kinematics of one leg (+ pelvis): index 0 pelvis, 1 thigh, 2 shin, 3 tarsus, 4 toe, 5 achilles rod
@@ -931,412 +924,6 @@ template <class B> struct Core {
     lds.mark(9);
   }
 
-  // ------------------------------------------------------------------------------------------------ the WIDE substep (r04)
-  // One mj_forward + Euler for the environments whose active set does not fit the 8 row slots per leg of `substep` -- falling and
-  // fallen robots: joint limits together with several contact pairs.  r03 left such an environment untouched and handed it to the
-  // next kernel tier, where it finished its remaining substeps ALONE, latency-bound, behind the main launch (0.02 % of the
-  // env-substeps cost 1.4 ms per step).  Here the wavefront that holds it carries it along: after the fast substep of the others,
-  // the lanes of the overflowing environments run this function; only that wavefront slows down, and nothing leaves the kernel.
-  //   * Capacity: everything the model can produce on a leg -- 2 connect rows, 4 limits, 9 collision spheres x 2 rows (24 rows).
-  //   * Rows live in a per-wavefront scratch block in HBM/L2 (B::Wide: [row][field][lane], lanes of a row contiguous), in three
-  //     fixed regions (connect 0-1, limits 2-5, contact pairs from 6), compacted inside a region: every loop below is ROLLED over
-  //     a wave-uniform row index, so the code is small and the run-time indices never touch a register array.
-  //   * Matrix-free Gauss-Seidel: with z_i = L^-1 jl_i and u~_i = G (jb_i - Y' jl_i), (A f)_i = jl_i . c + u~_i . a~ + R_i f_i where
-  //     c = sum_j z_j f_j (own leg, 5 numbers, lane-local) and a~ = sum_j u~_j f_j (3 numbers, shared by the pair as in `substep`);
-  //     a step reads its row (read-only but for f) and moves c and a~ by its delta -- no A is stored.  Same update rules, same row
-  //     order (connect L, R; limits L, R; contacts L, R) and same stopping rule as `substep`; the roundings differ (an environment
-  //     is either here or there as a function of its own state, never both).
-  enum { W_JB = 0, W_JL = 3, W_Z = 8, W_UT = 13, W_R = 16, W_B = 17, W_AD = 18, W_AI = 19, W_F = 20, W_ANT = 21, W_NF = LEG_W_NF,
-         W_POS = W_R, W_INVW = W_B,   // raw rows carry position and inverse weight where R and b go later
-         W_EQ0 = 0, W_LIM0 = 2, W_CON0 = 6, W_ROWS = LEG_W_ROWS };
-  static_assert(W_ANT + 1 == W_NF && W_CON0 + 18 == W_ROWS, "wide row layout");
-
-  template <int MODE, bool HF = false>
-  static LEG_WIDE_FN void substep_wide(typename B::Lds& lds, typename B::Wide& wd, Lane& st, bool from_rec, M live, SubOut& out, const Terrain* hf = nullptr) {
-    const I leg = B::opq(B::leg());
-    const KP_ K = B::kbase(leg);
-    Fact fc;
-    D qsb[3], qsl[5];
-    I nlim = 0, ncon = 0;
-    const M go = live;
-    auto put_raw = [&](I row, const D (&jb)[3], const D (&jl)[5], D pos, D invw, M m) {
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; wd.st(row, W_JB + Bc, jb[Bc], m); });
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; wd.st(row, W_JL + Dd, jl[Dd], m); });
-      wd.st(row, W_POS, pos, m); wd.st(row, W_INVW, invw, m);
-    };
-    {
-      Mass mm;
-      {
-        Kin k;
-        fk<0>(st.qb, st.ql, st.vb, st.vl, leg, K, k);
-        mass_bias<0>(k, leg, K, mm);
-        D sgl[5];
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sgl[Dd] = kc(K, LK_DOF_SIGMA + Dd); });
-        // ---- raw rows.  Connect: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3), rows x and z
-        {
-          D p1x, p1z, p2x, p2z;
-          link_point<5>(k, kc(K, LK_EQ_D1), kc(K, LK_EQ_D1 + 1), p1x, p1z);
-          link_point<3>(k, kc(K, LK_EQ_D2), kc(K, LK_EQ_D2 + 1), p2x, p2z);
-          lfor<0, 2>([&](auto ss) {
-            constexpr int S = decltype(ss)::value;
-            auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - k.oz[Jl] : -(px - k.ox[Jl]); };
-            D jb[3], jl[5];
-            jb[0] = 0.0; jb[1] = 0.0;
-            jb[2] = cp_dof_sigma[2] * (ent(p1x, p1z, LI<0>{}) - ent(p2x, p2z, LI<0>{}));
-            jl[0] = sgl[0] * ent(p1x, p1z, LI<1>{}) - sgl[0] * ent(p2x, p2z, LI<1>{});
-            jl[1] = -(sgl[1] * ent(p2x, p2z, LI<2>{}));
-            jl[2] = -(sgl[2] * ent(p2x, p2z, LI<3>{}));
-            jl[3] = 0.0;
-            jl[4] = sgl[4] * ent(p1x, p1z, LI<5>{});
-            put_raw(I(W_EQ0 + S), jb, jl, S == 0 ? p1x - p2x : p1z - p2z, kc(K, LK_EQ_INVWEIGHT), go);
-          });
-        }
-        // limits: leg dofs 0..3 (the rod is unlimited)
-        lfor<0, 4>([&](auto jj) {
-          constexpr int Jj = decltype(jj)::value;
-          const D qd = st.ql[Jj];
-          const D dlo = qd - kc(K, LK_JNT_RANGE + 2 * Jj), dhi = kc(K, LK_JNT_RANGE + 2 * Jj + 1) - qd;
-          const M act = go & ((dlo < 0.0) | (dhi < 0.0));
-          if (B::any(act)) {
-            D jb[3] = {D(0.0), D(0.0), D(0.0)}, jl[5];
-            lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = Dd == Jj ? B::sel(dlo < 0.0, D(1.0), D(-1.0)) : D(0.0); });
-            put_raw(nlim + W_LIM0, jb, jl, B::sel(dlo < 0.0, dlo, dhi), kc(K, LK_DOF_INVWEIGHT + Jj), act);
-          }
-          nlim = nlim + B::toI(act);
-        });
-        // contacts: pelvis sphere (left lane only) + the leg's eight spheres; normal row then tangent row
-        const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
-        lfor<0, 9>([&](auto cc) {
-          constexpr int Cc = decltype(cc)::value;
-          constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;
-          D cx, cz;
-          link_point<Lk>(k, kc(K, LK_SPH_D + 2 * Cc), kc(K, LK_SPH_D + 2 * Cc + 1), cx, cz);
-          D dist, nx = 0.0, nz = 1.0, px, pz;
-          if constexpr (HF) {
-            const D basex = st.qb[0] - cp_qpos0[0] + cp_link_off[0][0][0];
-            const D rad = kc(K, LK_SPH_R + Cc);
-            B::hf_sphere(*hf, basex + cx, kc(K, LK_SPH_Y + Cc), basez + cz, rad, dist, nx, nz);
-            const D back = rad + 0.5 * dist;
-            px = cx - nx * back; pz = cz - nz * back;
-          } else {
-            dist = basez + cz - kc(K, LK_SPH_R + Cc);
-            px = cx; pz = 0.5 * dist - basez;   // half-way into the penetration, on the vertical through the sphere centre
-          }
-          M act = go & (dist < 0.0);
-          if constexpr (Cc == 0) act = act & (leg == 0);
-          if (B::any(act)) {
-            lfor<0, 2>([&](auto oo) {
-              constexpr int ODD = decltype(oo)::value;   // 0 normal row, 1 tangent row
-              const D dx = ODD ? nz : nx, dz = ODD ? -nx : nz;   // flat floor: normal (0, 1), tangent (1, 0)
-              D jb[3], jl[5];
-              jb[0] = dx; jb[1] = dz; jb[2] = cp_dof_sigma[2] * (dx * pz - dz * px);
-              lfor<0, 5>([&](auto dd) {
-                constexpr int Dd = decltype(dd)::value;
-                if constexpr (Dd < 4 && Dd < Lk) jl[Dd] = sgl[Dd] * (dx * (pz - k.oz[Dd + 1]) - dz * (px - k.ox[Dd + 1]));
-                else jl[Dd] = 0.0;
-              });
-              put_raw(ncon * 2 + (W_CON0 + ODD), jb, jl, dist, kc(K, LK_SPH_INVWEIGHT + Cc), act);
-            });
-          }
-          ncon = ncon + B::toI(act);
-        });
-      }
-      B::fence();
-      {
-        // motor commands, setState / ctrl / clock bookkeeping and the smooth force: as in `substep`
-        D cu[3];
-        lfor<0, 3>([&](auto aa) {
-          constexpr int A_ = decltype(aa)::value;
-          constexpr int Dd = A_ == 2 ? 3 : A_;
-          if (from_rec) cu[A_] = lds.cld(C_CTRL + A_);
-          else if constexpr (MODE == 0) cu[A_] = 10.0 * (lds.cld(C_ACT + A_) - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
-          else cu[A_] = lds.cld(C_ACT + A_);
-        });
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.cst(C_KQ + Bc, st.qb[Bc], go); lds.cst(C_KV + Bc, st.vb[Bc], go); });
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.cst(C_KQ + 3 + Dd, st.ql[Dd], go); lds.cst(C_KV + 3 + Dd, st.vl[Dd], go); });
-        if (!from_rec) lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; lds.cst(C_CTRL + A_, cu[A_], go); });
-        lds.cst(C_TIME, lds.cld(C_TIME) + 0.0005, go);
-        D taub[3], taul[5];
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; lds.cst(C_TAUB + Bc, taub[Bc], go); });
-        lfor<0, 5>([&](auto dd) {
-          constexpr int Dd = decltype(dd)::value;
-          D t = -kc(K, LK_DOF_DAMPING + Dd) * st.vl[Dd] - mm.biasl[Dd];
-          if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
-            constexpr int A_ = Dd == 3 ? 2 : Dd;
-            const D lo = kc(K, LK_ACT_RANGE + 2 * A_), hi = kc(K, LK_ACT_RANGE + 2 * A_ + 1);
-            const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
-            t = t + kc(K, LK_ACT_GEAR + A_) * u;
-          }
-          taul[Dd] = t;
-          lds.cst(C_TAUL + Dd, t, go);
-        });
-        B::fence();
-        factor(mm, fc);
-        B::fence();
-        minv_apply(fc, taub, taul, qsb, qsl);
-      }
-    }
-    B::fence();
-    // ---- finish the rows (rolled): impedance, R, reference acceleration, z, u~, diagonal, warm start; c and a~ of the warm start
-    const D mu = CP_CONTACT_MU;
-    struct KindPar { D kk, bb, d0, d1, w, imp0; };
-    auto kind_par = [&](D solref0, D solref1, D d0, D d1, D w) {
-      KindPar k_;
-      const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
-      k_.kk = 1.0 / (d1 * d1 * tc * tc * solref1 * solref1); k_.bb = 2.0 / (d1 * tc);
-      k_.d0 = d0; k_.d1 = d1; k_.w = w; k_.imp0 = impedance(d0, d1, w, D(0.0));
-      return k_;
-    };
-    const KindPar kp_eq = kind_par(kc(K, LK_EQ_SOLREF), kc(K, LK_EQ_SOLREF + 1), kc(K, LK_EQ_SOLIMP), kc(K, LK_EQ_SOLIMP + 1), kc(K, LK_EQ_SOLIMP + 2));
-    const KindPar kp_lim = kind_par(D(cp_limit_solref[0]), D(cp_limit_solref[1]), D(cp_limit_solimp[0]), D(cp_limit_solimp[1]), D(cp_limit_solimp[2]));
-    const KindPar kp_con = kind_par(D(cp_contact_solref[0]), D(cp_contact_solref[1]), D(cp_contact_solimp[0]), D(cp_contact_solimp[1]), D(cp_contact_solimp[2]));
-    auto row_valid = [&](int s) { return go & (s < W_LIM0 ? M(true) : (s < W_CON0 ? (nlim > s - W_LIM0) : (ncon * 2 > s - W_CON0))); };
-    D c[5] = {D(0.0), D(0.0), D(0.0), D(0.0), D(0.0)};
-    D at[3] = {D(0.0), D(0.0), D(0.0)};
-    {
-      D jar_prev = 0.0, Rr_prev = 1.0, jlp[5], zp[5], utp[3];   // the previous row (a pair's normal row while its tangent row is finished)
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jlp[Dd] = 0.0; zp[Dd] = 0.0; });
-      utp[0] = 0.0; utp[1] = 0.0; utp[2] = 0.0;
-      for (int s = 0; s < W_ROWS; s++) {
-        const M valid = row_valid(s);
-        if (!B::any(valid)) continue;
-        const bool is_eq = s < W_LIM0, is_lim = !is_eq && s < W_CON0, is_t = s >= W_CON0 && ((s - W_CON0) & 1);
-        const KindPar& kp = is_eq ? kp_eq : (is_lim ? kp_lim : kp_con);
-        D jb[3], jl[5];
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = B::sel(valid, wd.ld(s, W_JB + Bc), D(0.0)); });
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = B::sel(valid, wd.ld(s, W_JL + Dd), D(0.0)); });
-        const D pos = B::sel(valid, wd.ld(s, W_POS), D(0.0)), invw = B::sel(valid, wd.ld(s, W_INVW), D(1.0));
-        D vel = jb[0] * st.vb[0] + jb[1] * st.vb[1] + jb[2] * st.vb[2];
-        D bq = jb[0] * qsb[0] + jb[1] * qsb[1] + jb[2] * qsb[2];
-        D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd]; });
-        const D imp = impedance(kp.d0, kp.d1, kp.w, pos);
-        D R = (1.0 - imp) / imp * invw;
-        R = B::sel(R > LMINVAL, R, D(LMINVAL));
-        // a tangent row's own position is 0 (its R comes from the pair's penetration)
-        const D aref = is_t ? -kp.bb * vel : -kp.bb * vel - kp.kk * imp * pos;
-        const D bv = bq - aref, jar = jw - aref;
-        D z[5], u[3], ut[3];
-        lfor<0, 5>([&](auto ii) {
-          constexpr int Ii = decltype(ii)::value;
-          D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * jl[Jj]; });
-          z[Ii] = a;
-        });
-        lfor<0, 3>([&](auto bb) {
-          constexpr int Bc = decltype(bb)::value;
-          D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Y[Jj][Bc] * jl[Jj]; });
-          u[Bc] = jb[Bc] - a;
-        });
-        Gmul(fc, u, ut);
-        D ad = R + (ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ad += jl[Dd] * z[Dd]; });
-        // warm start (mj_constraintUpdate from qacc_warmstart): single rows here, a contact pair when its tangent row is complete
-        const D Dd_ = B::rcp(R);
-        D fv = 0.0, fn_prev = 0.0;
-        if (is_eq) fv = -Dd_ * jar;
-        else if (is_lim) fv = B::sel(jar < 0.0, -Dd_ * jar, D(0.0));
-        else if (is_t) {
-          const D jn = jar_prev, jt = jar;
-          const D Dn_ = B::rcp(Rr_prev);
-          const D Nn = jn * mu, U1 = jt * mu, Tt = B::fabs(U1);
-          const M top = (Nn >= mu * Tt) | ((Tt <= 0.0) & (Nn >= 0.0));
-          const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
-          const D NmT = Nn - mu * Tt;
-          const D fnm_n = -(Dn_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
-          const D fnm_t = -(Dd_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
-          const D ftm = -fnm_t / Tt * U1 * mu;
-          fn_prev = B::sel(top, D(0.0), B::sel(bot, -Dn_ * jn, fnm_n));
-          fv = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jt, ftm));
-          D ant = ut[0] * utp[0] + ut[1] * utp[1] + ut[2] * utp[2];
-          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ant += jlp[Dd] * z[Dd]; });
-          wd.st(I(s - 1), W_ANT, ant, valid);
-          wd.st(I(s - 1), W_F, fn_prev, valid);
-          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] += B::sel(valid, zp[Dd] * fn_prev, D(0.0)); });
-          lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += B::sel(valid, utp[Bc] * fn_prev, D(0.0)); });
-        }
-        fv = B::sel(valid, fv, D(0.0));
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; wd.st(I(s), W_Z + Dd, z[Dd], valid); c[Dd] += z[Dd] * fv; });
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; wd.st(I(s), W_UT + Bc, ut[Bc], valid); at[Bc] += ut[Bc] * fv; });
-        wd.st(I(s), W_R, R, valid); wd.st(I(s), W_B, bv, valid); wd.st(I(s), W_AD, ad, valid); wd.st(I(s), W_AI, B::rcp(ad), valid);
-        wd.st(I(s), W_F, fv, valid);
-        jar_prev = jar; Rr_prev = R;
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jlp[Dd] = jl[Dd]; zp[Dd] = z[Dd]; });
-        utp[0] = ut[0]; utp[1] = ut[1]; utp[2] = ut[2];
-      }
-    }
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
-    // cost of the warm start, 1/2 f'Af + f'b: kept only if negative
-    {
-      D cost = 0.0;
-      for (int s = 0; s < W_ROWS; s++) {
-        const M valid = row_valid(s);
-        if (!B::any(valid)) continue;
-        const D f = B::sel(valid, wd.ld(s, W_F), D(0.0));
-        D full = wd.ld(s, W_R) * f + (wd.ld(s, W_UT) * at[0] + wd.ld(s, W_UT + 1) * at[1] + wd.ld(s, W_UT + 2) * at[2]);
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; full += wd.ld(s, W_JL + Dd) * c[Dd]; });
-        cost += B::sel(valid, f * (0.5 * full + wd.ld(s, W_B)), D(0.0));
-      }
-      cost = cost + B::swap(cost);
-      const M drop = cost > 0.0;
-      if (B::any(drop)) for (int s = 0; s < W_ROWS; s++) wd.st(I(s), W_F, D(0.0), drop & row_valid(s));
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::sel(drop, D(0.0), c[Dd]); });
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::sel(drop, D(0.0), at[Bc]); });
-    }
-    // ---- PGS sweeps (mj_solPGS, elliptic cones), MuJoCo's row order
-    D a0 = at[0], a1 = at[1], a2 = at[2];
-    I niter = 0;
-    {
-      LEG_FP_CONTRACT_OFF
-      const D scale = 1.0 / (CP_MEANINERTIA * LNV);
-      M sweeping = go;
-      const M isL = leg == 0;
-      D acc = 0.0;
-      auto sync = [&](int w) {
-        if (w == 0) { a0 = B::template pair_bcast<0>(a0); a1 = B::template pair_bcast<0>(a1); a2 = B::template pair_bcast<0>(a2); }
-        else { a0 = B::template pair_bcast<1>(a0); a1 = B::template pair_bcast<1>(a1); a2 = B::template pair_bcast<1>(a2); }
-      };
-      struct Row { D jl[5], z[5], ut[3], R, b, ad, ai, f; };
-      auto load = [&](int s, Row& r) {
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.jl[Dd] = wd.ld(s, W_JL + Dd); r.z[Dd] = wd.ld(s, W_Z + Dd); });
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = wd.ld(s, W_UT + Bc); });
-        r.R = wd.ld(s, W_R); r.b = wd.ld(s, W_B); r.ad = wd.ld(s, W_AD); r.ai = wd.ld(s, W_AI); r.f = wd.ld(s, W_F);
-      };
-      auto resid = [&](const Row& r) {
-        D x = B::fma(r.R, r.f, r.b);
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; x = B::fma(r.jl[Dd], c[Dd], x); });
-        return B::fma(r.ut[2], a2, B::fma(r.ut[1], a1, B::fma(r.ut[0], a0, x)));
-      };
-      auto apply = [&](const Row& r, D d) {
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::fma(r.z[Dd], d, c[Dd]); });
-        a0 = B::fma(r.ut[0], d, a0); a1 = B::fma(r.ut[1], d, a1); a2 = B::fma(r.ut[2], d, a2);
-      };
-      for (int iter = 0; iter < LEG_ITERS; iter++) {
-        if (!B::any(sweeping)) break;
-        acc = 0.0;
-        for (int w = 0; w < 2; w++) {   // connect rows: unclamped, the change of cost is never positive (see eq_step)
-          const M owner = (w == 0 ? isL : !isL) & sweeping;
-          for (int s = W_EQ0; s < W_LIM0; s++) {
-            Row r; load(s, r);
-            const D res = resid(r);
-            D d = -(res * r.ai);
-            D chg = d * B::fma(0.5 * r.ad, d, res);
-            d = B::sel(owner, d, D(0.0)); chg = B::sel(owner, chg, D(0.0));
-            apply(r, d);
-            acc = acc + chg;
-            wd.st(I(s), W_F, r.f + d, owner);
-          }
-          sync(w);
-        }
-        for (int w = 0; w < 2; w++) {
-          const M side = (w == 0 ? isL : !isL) & sweeping;
-          if (!B::any(side & (nlim > 0))) continue;
-          for (int j = 0; j < 4; j++) {
-            const M mine = side & (nlim > j);
-            if (!B::any(mine)) break;   // limit j exists only if limit j - 1 does
-            Row r; load(W_LIM0 + j, r);
-            const D res = resid(r);
-            const D cand = B::fmax(B::fma(-res, r.ai, r.f), D(0.0));
-            D d = cand - r.f;
-            D chg = d * B::fma(0.5 * r.ad, d, res);
-            const M keep = mine & (chg <= 1e-10);
-            d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-            apply(r, d);
-            acc = acc + chg;
-            wd.st(I(W_LIM0 + j), W_F, r.f + d, keep);
-          }
-          sync(w);
-        }
-        for (int w = 0; w < 2; w++) {
-          const M side = (w == 0 ? isL : !isL) & sweeping;
-          if (!B::any(side & (ncon > 0))) continue;
-          for (int p = 0; p < 9; p++) {
-            const M mine = side & (ncon > p);
-            if (!B::any(mine)) break;
-            const int sn = W_CON0 + 2 * p, stt = sn + 1;
-            Row rn, rt; load(sn, rn); load(stt, rt);
-            const D Ant_ = wd.ld(sn, W_ANT);
-            const D rnv = resid(rn), rtv = resid(rt);
-            const D on = rn.f, ot = rt.f;
-            const D Ann = rn.ad, Att = rt.ad;
-            const D denom = B::fma(ot, B::fma(Att, ot, Ant_ * on), on * B::fma(Ant_, ot, Ann * on));
-            const D rden = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
-            const D fn_n = B::fmax(B::fma(-rnv, rn.ai, on), D(0.0));
-            D x = -B::fma(ot, rtv, on * rnv) * rden;
-            x = B::fmax(x, D(-1.0));
-            const M use_n = on < LMINVAL;
-            D fn = B::sel(use_n, fn_n, B::fma(x, on, on));
-            D ft = B::sel(use_n, D(0.0), B::fma(x, ot, ot));
-            const D bc = B::fma(Ant_, fn - on, B::fma(-Att, ot, rtv));
-            const D x0 = -bc * rt.ai;
-            const D v1 = x0 * (1.0 / mu);
-            const D val = B::fma(v1, v1, -(fn * fn));
-            const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
-            const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
-            ft = B::sel(fn >= LMINVAL, ftc, ft);
-            D dn = fn - on, dt = ft - ot;
-            D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rtv)), dn * B::fma(0.5 * Ann, dn, rnv));
-            const M keep = mine & (chg <= 1e-10);
-            dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-            apply(rn, dn); apply(rt, dt);
-            acc = acc + chg;
-            wd.st(I(sn), W_F, on + dn, keep); wd.st(I(stt), W_F, ot + dt, keep);
-          }
-          sync(w);
-        }
-        const D improvement = -(acc + B::swap(acc));
-        niter = niter + B::toI(sweeping);
-        sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
-      }
-    }
-    out.niter = niter; out.go = go; out.overflow = go & !go;
-    B::fence();
-    // ---- g = tau + J' f from the stored rows, qacc = M^-1 g, implicit joint damping and Euler: as in `substep`
-    D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
-    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] = lds.cld(C_TAUL + Dd); });
-    for (int s = 0; s < W_ROWS; s++) {
-      const M valid = row_valid(s);
-      if (!B::any(valid)) continue;
-      const D f = B::sel(valid, wd.ld(s, W_F), D(0.0));
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; sb[Bc] += B::sel(valid, wd.ld(s, W_JB + Bc), D(0.0)) * f; });
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gl[Dd] += B::sel(valid, wd.ld(s, W_JL + Dd), D(0.0)) * f; });
-    }
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; gb[Bc] = lds.cld(C_TAUB + Bc) + (sb[Bc] + B::swap(sb[Bc])); });
-    D xb[3], xl[5];
-    minv_apply(fc, gb, gl, xb, xl);
-    B::fence();
-    D hb[3], hl[5];
-    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; hb[Bc] = xb[Bc]; });
-    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd]; });
-    {
-      const D zb[3] = {D(0.0), D(0.0), D(0.0)};
-      D hdamp[5];
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hdamp[Dd] = LH * kc(K, LK_DOF_DAMPING + Dd); });
-      for (int it = 0; it < DAMPING_SWEEPS; it++) {
-        D dl[5], eb[3], el[5];
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; dl[Dd] = hdamp[Dd] * hl[Dd]; });
-        minv_apply(fc, zb, dl, eb, el);
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; hb[Bc] = xb[Bc] - eb[Bc]; });
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; hl[Dd] = xl[Dd] - el[Dd]; });
-      }
-    }
-    lfor<0, 3>([&](auto bb) {
-      constexpr int Bc = decltype(bb)::value;
-      st.wb[Bc] = B::sel(go, xb[Bc], st.wb[Bc]);
-      const D vn = st.vb[Bc] + LH * hb[Bc];
-      st.vb[Bc] = B::sel(go, vn, st.vb[Bc]);
-      st.qb[Bc] = B::sel(go, st.qb[Bc] + LH * vn, st.qb[Bc]);
-    });
-    lfor<0, 5>([&](auto dd) {
-      constexpr int Dd = decltype(dd)::value;
-      st.wl[Dd] = B::sel(go, xl[Dd], st.wl[Dd]);
-      const D vn = st.vl[Dd] + LH * hl[Dd];
-      st.vl[Dd] = B::sel(go, vn, st.vl[Dd]);
-      st.ql[Dd] = B::sel(go, st.ql[Dd] + LH * vn, st.ql[Dd]);
-    });
-  }
-
   // ------------------------------------------------------------------------------------------------ operational-space state
   // Cassie2d::GetOperationalSpaceState (Cassie2d.cpp:218-237) with the RBDL-semantics tables from the kinematics of the last
   // setState (quirks Q1/Q2): body site on both lanes, the own foot (mean of the two toe sites) per lane.
@@ -1377,7 +964,7 @@ template <class B> struct Core {
   // any environment of the wave terminated, one more pass (mj_forward only, on the reset pose, for those environments) leaves
   // the reset observation.  On return `o` says what the caller still has to do (pending count, failure-guard counter).
   template <int MODE, bool HF = false>
-  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, typename B::Wide& wd, const Io& io, M valid, Out& o, const Terrain* hf = nullptr) {
+  static LEG_FN void env_step(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M valid, Out& o, const Terrain* hf = nullptr) {
     const I leg = B::leg();
     const I lo = leg * 5 + 3, ao = leg * 3;
     const M left = leg == 0;
@@ -1409,7 +996,7 @@ template <class B> struct Core {
     }
     M live = valid;
     o.set_state = (valid & !valid);
-    o.pend = 0; o.niter = 0; o.wide = 0;
+    o.pend = 0; o.niter = 0;
     o.do_reset = o.set_state; o.bad = o.set_state;
     const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
     bool reset_pass = false;
@@ -1418,17 +1005,9 @@ template <class B> struct Core {
     while (true) {
       substep<MODE, HF>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so, hf);
       if (!reset_pass) {
-        // environments over the 8 row slots per leg: the wide substep carries them through THIS substep (r04; r03 handed the rest of
-        // such an environment to the next kernel tier through o.pend, which therefore stays 0 now)
         const M ovf = live & so.overflow;
-        if (B::any(ovf)) {
-          SubOut sw;
-          Lane tmp = st;   // (a copy: the address of `st` itself must not escape into the call, or the whole kernel keeps it in memory)
-          substep_wide<MODE, HF>(lds, wd, tmp, MODE == 2, ovf, sw, hf);
-          st = tmp;
-          so.niter = B::seli(ovf, sw.niter, so.niter);
-          o.wide = o.wide + B::toI(ovf);
-        }
+        o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);   // hand the rest of this environment to the next kernel tier
+        live = live & !ovf;
         o.niter = o.niter + B::seli(live, so.niter, I(0));
         o.set_state = o.set_state | live;
         sub++;

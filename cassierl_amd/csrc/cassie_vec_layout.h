@@ -72,7 +72,6 @@ struct VecParams {
   int pending_pick;       // which entries of `pending` this launch takes: PICK_ALL, PICK_DEEP (flagged PENDING_DEEP only), PICK_SHALLOW
   int* deep_hint;         // host-visible word or null: `serial` is stored there whenever an environment needs the wave-per-environment kernel
   int serial;             // launch counter of the handle (scheduling hint only, see launch_physics_tiers)
-  double* wide;           // two-lanes-per-environment kernel: [n_waves][LEG_W_ROWS * LEG_W_NF * 64] scratch rows of its wide substep (cassie_leg_core.h)
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*

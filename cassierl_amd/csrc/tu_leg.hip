@@ -4,7 +4,6 @@
 
 namespace cassie {
 namespace launch {
-static_assert(LEG_WIDE_BLOCK_BYTES == leg::WIDE_BLOCK_DOUBLES * sizeof(double), "scratch block of the wide substep");
 
 void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending) {
   dim3 grid((n_envs + 31) / 32), block(64);

@@ -48,7 +48,6 @@ class LegHostEnv:
         self.state = np.zeros((n, 88))
         self.traj_q, self.traj_tmax, self.traj_n = None, 0.0, 0
         self.pending = np.zeros(n, dtype=np.int32)
-        self.wide = np.zeros(n, dtype=np.int32)   # substeps per environment done by the wide substep (more than 8 rows on a leg)
         self.nonfinite = 0
 
     def set_trajectory(self, time, qpos):
@@ -78,11 +77,10 @@ class LegHostEnv:
                                    self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)
             self.nonfinite += bad.value
             return obs, rew, done.astype(bool)
-        lib().leg_host_step_counting(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
-                                     0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
-                                     _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,
-                                     self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1,
-                                     self.wide.ctypes.data_as(ct.POINTER(ct.c_int)))
+        lib().leg_host_step(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
+                            0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
+                            _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,
+                            self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)
         self.nonfinite += bad.value
         return obs, rew, done.astype(bool)
 

@@ -15,7 +15,6 @@
 #define __constant__
 #define __forceinline__ inline
 #define LEG_FN inline
-#define LEG_WIDE_FN inline
 #define LEG_FP_CONTRACT_OFF   /* the whole file is compiled with -ffp-contract=off; the step functions write their FMAs out */
 #include "../../cassierl_amd/csrc/cassie_leg_core.h"
 
@@ -102,7 +101,7 @@ struct HostB {
   struct Lds {
     double pr[LEG_NPAIR_SLOTS][4][NL]; i64 pdepth[LEG_NPAIR_SLOTS][NL];
     double lm[4][3][NL]; i64 lmj[4][NL];
-    double cold[cassie::leg::LEG_COLD_SLOTS][NL];
+    double cold[cassie::leg::Core<HostB>::C_N][NL];
     void mark(int) {}
     VD cld(int i) const { VD r; LANES r.v[l] = cold[i][l]; return r; }
     void cst(int i, VD v, VM m) { LANES if (m.v[l]) cold[i][l] = v.v[l]; }
@@ -118,11 +117,6 @@ struct HostB {
     void ld_lim(int s, VD& pos, VD& sgn, VD& invw, VI& j) {
       LANES { pos.v[l] = lm[s][0][l]; sgn.v[l] = lm[s][1][l]; invw.v[l] = lm[s][2][l]; j.v[l] = lmj[s][l]; }
     }
-  };
-  struct Wide {   // rows of the wide substep: [row][field][lane]
-    double a[cassie::leg::LEG_W_ROWS][cassie::leg::LEG_W_NF][NL];
-    void st(VI row, int field, VD v, VM m) { LANES if (m.v[l]) a[row.v[l]][field][l] = v.v[l]; }
-    VD ld(int row, int field) const { VD r; LANES r.v[l] = a[row][field][l]; return r; }
   };
   static VI leg() { VI r; LANES r.v[l] = l & 1; return r; }
   static VI opq(VI x) { return x; }
@@ -181,7 +175,7 @@ template <class T> void point(T& io_p, double* base, size_t stride, int e0, int 
 template <class C, class LdsT, bool HF>
 int run(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
         const double* traj_qpos, double traj_tmax, int traj_n, const cassie::Terrain* hf, double* obs, double* reward, uint8_t* done,
-        double* terminal_obs, int* pending, int* nonfinite, int threads, int* wide_count = nullptr) {
+        double* terminal_obs, int* pending, int* nonfinite, int threads) {
   cassie::leg::EnvCfg cfg;
   cfg.n_sub = n_sub; cfg.flags = flags; cfg.env_kind = env_kind; cfg.auto_reset = auto_reset; cfg.adim = adim;
   cfg.want_obs = obs != nullptr; cfg.traj_qpos = traj_qpos; cfg.traj_tmax = traj_tmax; cfg.traj_n = traj_n;
@@ -210,21 +204,17 @@ int run(double* state, const double* actions, int n, int adim, int mode, int n_s
     LANES { const int e = e0 + (l >> 1); io.done.p[l] = done && e < n ? done + e : &dummy8; }
     VM valid; LANES valid.v[l] = e0 + (l >> 1) < n ? -1 : 0;
     typename C::Out o;
-    static thread_local HostB::Wide wd;   // (poisoned once: a row that was never written must not be read)
-    static thread_local bool wd_init = false;
-    if (!wd_init) { for (auto& r : wd.a) for (auto& f : r) LANES f[l] = std::nan(""); wd_init = true; }
 #ifdef LEG_HOST_FAST   // the timing build only carries what bench.py times: PD and torque mode on the flat floor
-    if (mode == 0) C::template env_step<0, HF>(cfg, lds, wd, io, valid, o, hf);
-    else C::template env_step<1, HF>(cfg, lds, wd, io, valid, o, hf);
+    if (mode == 0) C::template env_step<0, HF>(cfg, lds, io, valid, o, hf);
+    else C::template env_step<1, HF>(cfg, lds, io, valid, o, hf);
 #else
-    if (mode == 0) C::template env_step<0, HF>(cfg, lds, wd, io, valid, o, hf);
-    else if (mode == 1) C::template env_step<1, HF>(cfg, lds, wd, io, valid, o, hf);
-    else C::template env_step<2, HF>(cfg, lds, wd, io, valid, o, hf);
+    if (mode == 0) C::template env_step<0, HF>(cfg, lds, io, valid, o, hf);
+    else if (mode == 1) C::template env_step<1, HF>(cfg, lds, io, valid, o, hf);
+    else C::template env_step<2, HF>(cfg, lds, io, valid, o, hf);
 #endif
     for (int k = 0; k < EPG; k++) {
       if (e0 + k >= n) break;
       if (pending) pending[e0 + k] = (int)o.pend.v[2 * k];
-      if (wide_count) wide_count[e0 + k] += (int)o.wide.v[2 * k];
       if (o.bad.v[2 * k]) bad++;
     }
   }
@@ -260,14 +250,6 @@ int leg_host_step_hf(double* state, const double* actions, int n, int adim, int 
 #endif
 
 int leg_host_lanes(void) { return NL; }
-
-// the same as leg_host_step, also counting per environment the substeps done by the wide substep (more than 8 rows on a leg)
-int leg_host_step_counting(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
-                           const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
-                           int* pending, int* nonfinite, int threads, int* wide_count) {
-  return run<HCore, HostB::Lds, false>(state, actions, n, adim, mode, n_sub, flags, env_kind, auto_reset, traj_qpos, traj_tmax, traj_n, nullptr,
-                                       obs, reward, done, terminal_obs, pending, nonfinite, threads, wide_count);
-}
 
 // arithmetic operations counted since the last call (see the note at g_ops); 0 in the timing build
 double leg_host_ops(void) {

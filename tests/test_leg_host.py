@@ -84,14 +84,13 @@ def test_env_step_against_golden_streams(streams, traj, oracle_mod, tag, kind, m
         assert np.array_equal(env.state[0], env.state[1])
 
 
-def test_limits_many_contacts_and_the_wide_substep(oracle_mod):
-    """A robot driven into its joint limits and collapsing: every substep agrees with the oracle -- where a leg needs at most 8 rows
-    through the fast substep, beyond that through the wide substep (rows in the scratch block, matrix-free Gauss-Seidel: r04; r03
-    handed such an environment over untouched).  Nothing is handed over any more."""
+def test_limits_contacts_and_the_capacity_hand_over(oracle_mod):
+    """A robot driven into its joint limits and collapsing: wherever a leg needs at most 8 rows the step agrees with the oracle;
+    beyond that the environment is handed over untouched (pending = substeps left)."""
     env = LegHostEnv(1, n_substeps=1, auto_reset=False)
     o = oracle_mod.Oracle()
     push = np.array([12.2, -12.2, 0.9, 12.2, -12.2, 0.9])
-    fast, wide, maxlim, maxcon, worst_wide = 0, 0, 0, 0, 0.0
+    done_in, handed, maxlim, maxcon = 0, 0, 0, 0
     for i in range(5000):
         a = push if i < 800 else np.zeros(6)
         if i == 1200:
@@ -100,51 +99,21 @@ def test_limits_many_contacts_and_the_wide_substep(oracle_mod):
             q, v = o.state()
             s0 = state_vec(q, v, o.warmstart())
             env.set_full_state_host(s0[None])
-            w0 = int(env.wide[0])
             env.substep_host("Torque", a[None], 1)
             o.step_torque(a)
             sg = env.get_full_state_host()[0]
-            assert env.pending[0] == 0
-            q1, v1 = o.state()
-            err = max(np.abs(sg[:13] - q1).max() / 1e-10, np.abs(sg[13:26] - v1).max() / (1e-8 * (1 + np.abs(v1).max())))
-            assert err < 1.0, (i, err, int(env.wide[0]) - w0)
-            assert np.abs(sg[26:39] - o.warmstart()).max() < 1e-6 * (1 + np.abs(o.warmstart()).max())
-            if int(env.wide[0]) > w0:
-                wide += 1
-                worst_wide = max(worst_wide, err)
+            if env.pending[0]:
+                handed += 1
+                assert env.pending[0] == 1 and np.array_equal(sg[:39], s0[:39])
             else:
-                fast += 1
-            e = o.efc()
-            maxcon = max(maxcon, o.ncon); maxlim = max(maxlim, int((e["type"] == 1).sum()))
+                done_in += 1
+                q1, v1 = o.state()
+                assert np.abs(sg[:13] - q1).max() < 1e-10 and np.abs(sg[13:26] - v1).max() < 1e-8 * (1 + np.abs(v1).max()), i
+                e = o.efc()
+                maxcon = max(maxcon, o.ncon); maxlim = max(maxlim, int((e["type"] == 1).sum()))
         else:
             o.step_torque(a)
-    assert fast > 100 and wide >= 8 and maxlim >= 6 and maxcon >= 6, (fast, wide, maxlim, maxcon, worst_wide)
-
-
-def test_wide_substep_free_running_fallen_robots(oracle_mod):
-    """Robots driven into their joint limits, then falling and lying on the ground under random torques, 2000 free-running substeps,
-    no reset: the wide substep takes over whenever a leg has more than 8 rows, the trajectories follow the oracle (torque mode is not
-    chaotic: 1e-5, as on the GPU)."""
-    rng = np.random.default_rng(4)
-    n = 4
-    env = LegHostEnv(n, n_substeps=1, auto_reset=False)
-    oracles = [oracle_mod.Oracle() for _ in range(n)]
-    env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in oracles]))
-    worst = 0.0
-    push = np.array([12.2, -12.2, 0.9, 12.2, -12.2, 0.9])
-    scale = np.array([1.0, 0.9, 0.8, 0.7])[:, None]
-    for t in range(200):
-        acts = push * scale if t < 80 else (np.zeros((n, 6)) if t < 150 else rng.uniform(-1, 1, (n, 6)) * TQ)
-        env.substep_host("Torque", acts, 10)
-        assert (env.pending == 0).all()
-        for i, o in enumerate(oracles):
-            for _ in range(10):
-                o.step_torque(acts[i])
-        sg = env.get_full_state_host()
-        for i, o in enumerate(oracles):
-            worst = max(worst, rel_err(sg[i], *o.state()))
-    assert worst < 1e-5, worst
-    assert env.wide.sum() > 20, env.wide
+    assert done_in > 100 and handed > 0 and maxlim >= 2 and maxcon >= 4, (done_in, handed, maxlim, maxcon)
 
 
 @pytest.mark.parametrize("mode", ["Torque", "PD"])
