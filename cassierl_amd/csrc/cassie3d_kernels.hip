@@ -672,8 +672,11 @@ __global__ void __launch_bounds__(64, WPS) env_step3d_kernel(Params3 p) {
   const int env = blockIdx.x, lane = threadIdx.x;
   if (env >= p.n_envs) return;
   const int n_sub = p.pending_in ? p.pending_in[env] : p.n_sub;
-  if (n_sub == 0) return;
-  if (p.pending_in && p.stats && lane == 0) atomicAdd(p.stats + S3_GENERAL_SUBSTEPS, (unsigned long long)n_sub);
+  if (n_sub == 0) {   // nothing left for this environment (a middle tier still has to say so to the tier behind it)
+    if (p.pending_out && lane == 0) p.pending_out[env] = 0;
+    return;
+  }
+  if (CAP && p.pending_in && p.stats && lane == 0) atomicAdd(p.stats + S3_GENERAL_SUBSTEPS, (unsigned long long)n_sub);
   double* st = p.state + (size_t)env * ENV3_STRIDE;
   if (lane < NQ) sm.q[lane] = st[E3_Q + lane];
   if (lane < NV) { sm.v[lane] = st[E3_V + lane]; sm.ws[lane] = st[E3_WS + lane]; }

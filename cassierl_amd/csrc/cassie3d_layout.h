@@ -26,7 +26,8 @@ struct Params3 {
 };
 // S3_GENERAL_SUBSTEPS: env-substeps the 32-row kernel handed to the 64-row kernel; S3_CAPPED_SUBSTEPS: env-substeps in which
 // the 64-row kernel had to leave contacts out (more than 64 constraint rows)
-enum { S3_GENERAL_SUBSTEPS = 0, S3_CAPPED_SUBSTEPS = 1, S3_N = 4 };
+// S3_LEG_HANDOVER_SUBSTEPS: env-substeps the lane-per-leg kernel handed to the wavefront-per-environment kernels (row capacity)
+enum { S3_GENERAL_SUBSTEPS = 0, S3_CAPPED_SUBSTEPS = 1, S3_LEG_HANDOVER_SUBSTEPS = 2, S3_N = 4 };
 
 }  // namespace cassie3d
 #endif

@@ -19,8 +19,9 @@
 //     stored but the 3x3 diagonal block of a contact.  qacc = qacc_smooth + [G' a~ ; c - Y G' a~] needs no second solve.
 //   * PGS in MuJoCo's row order (connect L, R; limits L, R; contacts pelvis + L, R), elliptic cones with the QCQP of mju_QCQP2,
 //     a~ exchanged once per block; every loop over rows is ROLLED (row data is in LDS, so run-time indices are free).
-//   * Capacity: NSLOT3 per-lane LDS slots = 3 connect rows + 25 per joint limit + 81 per contact (2 contacts + 3 limits, 3 contacts).
-//     An environment that needs more is left untouched from that substep on and handed to env_step3d_kernel through `pending`.
+//   * Capacity: the 3 connect rows of a leg in registers + NSLOT3 = 160 per-lane LDS slots at 25 per joint limit and 52 per contact
+//     (3 contacts; 2 contacts + 2 limits; 1 contact + 4 limits): 80 KB per wavefront, two wavefronts per CU.  An environment that
+//     needs more is left untouched from that substep on and handed to env_step3d_kernel through `pending`.
 //
 // The arithmetic restates the same mj_forward / mj_Euler as cassie3d_kernels.hip (kinematics, CRB, RNE bias, plane-sphere and
 // plane-capsule collision, connect / limit / elliptic contact rows, warm start, PGS, implicit joint damping); what differs is the
@@ -44,15 +45,23 @@
 namespace cassie3d {
 namespace leg {
 
-constexpr int NSLOT3 = 320;   // per-lane LDS slots (doubles): 160 KB per wavefront = one wavefront per CU
-// row record (matrix-free): Jacobian of the own leg, z = L^-1 jl, u~, regulariser, b = J qacc_smooth - aref, A_ii, 1 / A_ii, force
+#ifndef LEG3_ITERS
+#define LEG3_ITERS ITERATIONS   // (timing experiments only: -DLEG3_ITERS=n)
+#endif
+constexpr int NSLOT3 = 160;   // per-lane LDS slots (doubles): 80 KB per wavefront = two wavefronts per CU
+// Rows of the matrix-free solver.  The three connect rows of a leg always exist: they stay in REGISTERS (static indices).  Joint
+// limits and contacts are compacted into the per-lane LDS slots, limits first:
+//   limit record   jl(7) z(7) u~(6) R b A_ii 1/A_ii f                                              25 slots
+//   contact record 3 x [jl(7) u~(6) b f] + R + the packed 3x3 diagonal block of A                  52 slots  (no z: a contact step
+//                  applies c += L^-1 (sum_i jl_i d_i) instead -- 49 multiply-adds more per step, 21 slots less per contact)
 enum { R3_JL = 0, R3_Z = 7, R3_UT = 14, R3_R = 20, R3_B = 21, R3_AD = 22, R3_AI = 23, R3_F = 24, R3_N = 25,
-       R3_JB = R3_UT, R3_POS = R3_R, R3_INVW = R3_B,   // raw rows carry the base Jacobian, position and inverse weight there
-       C3_BLK = 3 * R3_N, C3_N = 3 * R3_N + 6,         // a contact: normal + two tangent rows + the packed 3x3 block of A
-       ROW_EQ0 = 0, DYN0 = 3 * R3_N };
+       R3_JB = R3_UT, R3_POS = R3_R, R3_INVW = R3_B,   // raw limit rows carry the base Jacobian, position and inverse weight there
+       C3_JL = 0, C3_UT = 7, C3_B = 13, C3_F = 14, C3_ROW = 15, C3_R = 3 * C3_ROW, C3_BLK = C3_R + 1, C3_N = C3_BLK + 6,
+       C3_JB = C3_UT, C3_POS = C3_B, C3_INVW = C3_F,   // raw contact rows likewise
+       DYN0 = 0 };
 // scratch layout of the first two passes (dead before any row is written): per link h(3) J(6) F(3) T(3); per dof axis(3) anchor(3)
 enum { T3_LINK = 0, T3_DOF = 7 * 15, T3_END = 7 * 15 + 7 * 6 };
-static_assert(T3_END <= NSLOT3 && DYN0 + 2 * C3_N + 3 * R3_N <= NSLOT3, "slot budget");
+static_assert(T3_END <= NSLOT3 && DYN0 + 2 * C3_N + 2 * R3_N <= NSLOT3 && DYN0 + 3 * C3_N <= NSLOT3, "slot budget");
 
 template <int I_> struct LI { static constexpr int value = I_; };
 template <int B_, int E_, class F> LEG_FN void lfor(F&& f) {
@@ -423,29 +432,25 @@ template <class B> struct Core3 {
       minv_apply(fc, taub, taul, qsb, qsl);
     }
     B::fence();
-    // ---- raw rows (Jacobians, position, inverse weight) straight into their LDS records.  Joint limits first (they only need q):
-    // the contacts' records start behind them.
+    // ---- raw rows (Jacobians, position, inverse weight).  Joint limits first (they only need q) and straight into their LDS
+    // records: the contacts' records start behind them.  The connect rows stay in registers.
     I nlim = 0, ncon = 0;
     M ovf = live & !live;
-    auto put_raw = [&](I base, const D (&jb)[6], const D (&jl)[7], D pos, D invw, M m) {
-      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_JL + Dd), jl[Dd], m); });
-      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(base + (R3_JB + Bc), jb[Bc], m); });
-      lds.stv(base + R3_POS, pos, m); lds.stv(base + R3_INVW, invw, m);
-    };
     lfor<0, 6>([&](auto jj) {
       constexpr int Jj = decltype(jj)::value;
       const D qd = st.ql[Jj];
       const D dlo = qd - kc(K, LK3_LIM_RANGE + 2 * Jj), dhi = kc(K, LK3_LIM_RANGE + 2 * Jj + 1) - qd;
       const M act = live & ((dlo < 0.0) | (dhi < 0.0));
       if (B::any(act)) {
-        const D jb[6] = {D(0.0), D(0.0), D(0.0), D(0.0), D(0.0), D(0.0)};
-        D jl[7];
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = Dd == Jj ? B::sel(dlo < 0.0, D(1.0), D(-1.0)) : D(0.0); });
         const I base = nlim * R3_N + DYN0;
-        put_raw(base, jb, jl, B::sel(dlo < 0.0, dlo, dhi), kc(K, LK3_DOF_INVW + Jj), act);   // (<= 6 limits always fit: 75 + 150 < NSLOT3)
+        const M fits = base + R3_N <= NSLOT3;
+        ovf = ovf | (act & !fits);
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_JL + Dd), Dd == Jj ? B::sel(dlo < 0.0, D(1.0), D(-1.0)) : D(0.0), act & fits); });
+        lds.stv(base + R3_POS, B::sel(dlo < 0.0, dlo, dhi), act & fits); lds.stv(base + R3_INVW, kc(K, LK3_DOF_INVW + Jj), act & fits);
       }
       nlim = nlim + B::toI(act);
     });
+    D eq_jb[3][6], eq_jl[3][7], eq_pos[3];
     {
       // second run down the frames (no velocities); hinge axes and anchors stay in registers for the point Jacobians
       Frame f0, fa, fb, f3;
@@ -491,18 +496,20 @@ template <class B> struct Core3 {
             const I base = nlim * R3_N + ncon * C3_N + DYN0;
             const M fits = base + C3_N <= NSLOT3;
             ovf = ovf | (act & !fits);
+            const M wr = act & fits;
             lfor<0, 3>([&](auto oo) {
               constexpr int Cmp = decltype(oo)::value;
               const D dir[3] = {Cmp == 0 ? D(0.0) : (Cmp == 1 ? tx : -ty), Cmp == 0 ? D(0.0) : (Cmp == 1 ? ty : tx), D(Cmp == 0 ? 1.0 : 0.0)};
-              D jb[6], jl[7], c[3];
-              lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = dir[Bc]; cross(a0[Bc], p, c); jb[3 + Bc] = dot(dir, c); });
+              D c[3];
+              const I rb = base + Cmp * C3_ROW;
+              lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(rb + (C3_JB + Bc), dir[Bc], wr); cross(a0[Bc], p, c); lds.stv(rb + (C3_JB + 3 + Bc), dot(dir, c), wr); });
               lfor<0, 7>([&](auto dd) {
                 constexpr int Dd = decltype(dd)::value;
-                if constexpr (Dd < LK && Dd < 6) jl[Dd] = jent(dd, p, dir);
-                else jl[Dd] = 0.0;
+                if constexpr (Dd < LK && Dd < 6) lds.stv(rb + (C3_JL + Dd), jent(dd, p, dir), wr);
+                else lds.stv(rb + (C3_JL + Dd), D(0.0), wr);
               });
-              put_raw(base + Cmp * R3_N, jb, jl, Cmp == 0 ? dist : D(0.0), kc(K, LK3_SPH_INVW + Cc), act & fits);
             });
+            lds.stv(base + C3_POS, dist, wr); lds.stv(base + C3_INVW, kc(K, LK3_SPH_INVW + Cc), wr);
           }
           ncon = ncon + B::toI(act);
         });
@@ -537,11 +544,11 @@ template <class B> struct Core3 {
         constexpr int Cmp = decltype(oo)::value;
         const D dir[3] = {D(Cmp == 0 ? 1.0 : 0.0), D(Cmp == 1 ? 1.0 : 0.0), D(Cmp == 2 ? 1.0 : 0.0)};
         const D dp[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-        D jb[6], jl[7], c[3];
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = 0.0; cross(a0[Bc], dp, c); jb[3 + Bc] = dot(dir, c); });
-        lfor<0, 3>([&](auto dd) { constexpr int Dd = decltype(dd)::value; jl[Dd] = jent(dd, p1, dir) - jent(dd, p2, dir); });
-        jl[3] = -jent(LI<3>{}, p2, dir); jl[4] = -jent(LI<4>{}, p2, dir); jl[5] = 0.0; jl[6] = jent(LI<6>{}, p1, dir);
-        put_raw(I(ROW_EQ0 + Cmp * R3_N), jb, jl, dp[Cmp], kc(K, LK3_EQ_INVW), live);
+        D c[3];
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; eq_jb[Cmp][Bc] = 0.0; cross(a0[Bc], dp, c); eq_jb[Cmp][3 + Bc] = dot(dir, c); });
+        lfor<0, 3>([&](auto dd) { constexpr int Dd = decltype(dd)::value; eq_jl[Cmp][Dd] = jent(dd, p1, dir) - jent(dd, p2, dir); });
+        eq_jl[Cmp][3] = -jent(LI<3>{}, p2, dir); eq_jl[Cmp][4] = -jent(LI<4>{}, p2, dir); eq_jl[Cmp][5] = 0.0; eq_jl[Cmp][6] = jent(LI<6>{}, p1, dir);
+        eq_pos[Cmp] = dp[Cmp];
       });
     }
     ovf = ovf | B::swapm(ovf);
@@ -550,7 +557,7 @@ template <class B> struct Core3 {
     out.nrows = nlim + ncon * 3 + 3;
     out.nrows = out.nrows + B::swapi(out.nrows);
     B::fence();
-    // ---- finish the rows (rolled): impedance, R, reference acceleration, z, u~, diagonal, warm start; c and a~ of the warm start
+    // ---- finish the rows: impedance, R, reference acceleration, z, u~, diagonal, warm start; c and a~ of the warm start
     const D mu = MU;
     struct KindPar { D kk, bb, d0, d1, w; };
     auto kind_par = [&](D solref0, D solref1, D d0, D d1, D w) {
@@ -566,15 +573,11 @@ template <class B> struct Core3 {
     D c[7], at[6];
     lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = 0.0; });
     lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = 0.0; });
-    struct RowW { D jl[7], z[7], ut[6], R, bv, jar, ad; };
-    // loads the raw row at `base`, derives everything but the force; R_in >= 0: the regulariser is given (a contact's tangent rows)
-    auto finish = [&](I base, M valid, const KindPar& kp, bool tangent, D R_in, RowW& w) {
-      D jb[6];
-      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; jb[Bc] = B::sel(valid, lds.ldv(base + (R3_JB + Bc)), D(0.0)); });
-      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = B::sel(valid, lds.ldv(base + (R3_JL + Dd)), D(0.0)); });
-      const D pos = B::sel(valid, lds.ldv(base + R3_POS), D(0.0)), invw = B::sel(valid, lds.ldv(base + R3_INVW), D(1.0));
+    struct RowW { D jb[6], jl[7], z[7], ut[6], R, bv, jar, ad; };
+    // from the raw row (w.jb, w.jl, position, inverse weight) everything but the force; tangent: the regulariser is the normal row's
+    auto finish = [&](D pos, D invw, const KindPar& kp, bool tangent, D R_in, RowW& w) {
       D vel = 0.0, bq = 0.0, jw = 0.0;
-      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; vel += jb[Bc] * st.vb[Bc]; bq += jb[Bc] * qsb[Bc]; jw += jb[Bc] * st.wb[Bc]; });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; vel += w.jb[Bc] * st.vb[Bc]; bq += w.jb[Bc] * qsb[Bc]; jw += w.jb[Bc] * st.wb[Bc]; });
       lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; vel += w.jl[Dd] * st.vl[Dd]; bq += w.jl[Dd] * qsl[Dd]; jw += w.jl[Dd] * st.wl[Dd]; });
       const D imp = impedance(kp.d0, kp.d1, kp.w, pos);
       D R = (1.0 - imp) / imp * invw;
@@ -593,7 +596,7 @@ template <class B> struct Core3 {
         constexpr int Bc = decltype(bb)::value;
         D a = 0.0;
         lfor<0, 7>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Y[Jj][Bc] * w.jl[Jj]; });
-        u[Bc] = jb[Bc] - a;
+        u[Bc] = w.jb[Bc] - a;
       });
       Gmul(fc, u, w.ut);
       D ad = w.R;
@@ -601,43 +604,62 @@ template <class B> struct Core3 {
       lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ad += w.jl[Dd] * w.z[Dd]; });
       w.ad = ad;
     };
-    auto put_row = [&](I base, M valid, const RowW& w, D f) {
-      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_Z + Dd), w.z[Dd], valid); c[Dd] += w.z[Dd] * f; });
-      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(base + (R3_UT + Bc), w.ut[Bc], valid); at[Bc] += w.ut[Bc] * f; });
-      lds.stv(base + R3_R, w.R, valid); lds.stv(base + R3_B, w.bv, valid); lds.stv(base + R3_AD, w.ad, valid); lds.stv(base + R3_AI, B::rcp(w.ad), valid);
-      lds.stv(base + R3_F, f, valid);
+    auto warm = [&](const RowW& w, D f) {   // the row's share of c and a~ for the warm-start force f
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] += w.z[Dd] * f; });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += w.ut[Bc] * f; });
     };
-    for (int s = 0; s < 3; s++) {   // connect rows
+    struct EqRow { D jl[7], z[7], ut[6], R, b, ad, ai, f; };
+    EqRow eq[3];
+    lfor<0, 3>([&](auto ss) {   // connect rows: registers
+      constexpr int S = decltype(ss)::value;
       RowW w;
-      const I base = I(ROW_EQ0 + s * R3_N);
-      finish(base, go, kp_eq, false, D(0.0), w);
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; w.jb[Bc] = eq_jb[S][Bc]; });
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = eq_jl[S][Dd]; });
+      finish(eq_pos[S], kc(K, LK3_EQ_INVW), kp_eq, false, D(0.0), w);
       const D f = B::sel(go, -(B::rcp(w.R) * w.jar), D(0.0));
-      put_row(base, go, w, f);
-    }
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; eq[S].jl[Dd] = w.jl[Dd]; eq[S].z[Dd] = w.z[Dd]; });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; eq[S].ut[Bc] = w.ut[Bc]; });
+      eq[S].R = w.R; eq[S].b = w.bv; eq[S].ad = w.ad; eq[S].ai = B::rcp(w.ad); eq[S].f = f;
+      warm(w, f);
+      B::fence();
+    });
     for (int j = 0; j < 6; j++) {   // joint limits (compacted: limit j exists only if limit j - 1 does)
       const M valid = go & (nlim > j);
       if (!B::any(valid)) break;
       RowW w;
       const I base = I(DYN0 + j * R3_N);
-      finish(base, valid, kp_lim, false, D(0.0), w);
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; w.jb[Bc] = 0.0; });
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = B::sel(valid, lds.ldv(base + (R3_JL + Dd)), D(0.0)); });
+      finish(B::sel(valid, lds.ldv(base + R3_POS), D(0.0)), B::sel(valid, lds.ldv(base + R3_INVW), D(1.0)), kp_lim, false, D(0.0), w);
       const D f = B::sel(valid & (w.jar < 0.0), -(B::rcp(w.R) * w.jar), D(0.0));
-      put_row(base, valid, w, f);
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_Z + Dd), w.z[Dd], valid); });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(base + (R3_UT + Bc), w.ut[Bc], valid); });
+      lds.stv(base + R3_R, w.R, valid); lds.stv(base + R3_B, w.bv, valid); lds.stv(base + R3_AD, w.ad, valid); lds.stv(base + R3_AI, B::rcp(w.ad), valid);
+      lds.stv(base + R3_F, f, valid);
+      warm(w, f);
     }
     for (int p = 0; p < 9; p++) {   // contacts: normal, tangent 1, tangent 2
       const M valid = go & (ncon > p);
       if (!B::any(valid)) break;
       const I base = nlim * R3_N + (DYN0 + p * C3_N);
       RowW wn, w1, w2;
-      finish(base, valid, kp_con, false, D(0.0), wn);
-      finish(base + R3_N, valid, kp_con, true, wn.R, w1);
-      finish(base + 2 * R3_N, valid, kp_con, true, wn.R, w2);
-      // 3x3 diagonal block of A (the R of the pair on its diagonal: already in ad)
+      auto raw = [&](I rb, RowW& w) {
+        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; w.jb[Bc] = B::sel(valid, lds.ldv(rb + (C3_JB + Bc)), D(0.0)); });
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = B::sel(valid, lds.ldv(rb + (C3_JL + Dd)), D(0.0)); });
+      };
+      const D dist = B::sel(valid, lds.ldv(base + C3_POS), D(0.0)), invw = B::sel(valid, lds.ldv(base + C3_INVW), D(1.0));
+      raw(base, wn); raw(base + C3_ROW, w1); raw(base + 2 * C3_ROW, w2);
+      finish(dist, invw, kp_con, false, D(0.0), wn);
+      finish(D(0.0), invw, kp_con, true, wn.R, w1);
+      finish(D(0.0), invw, kp_con, true, wn.R, w2);
+      // 3x3 diagonal block of A (the R of the contact on its diagonal: already in ad)
       auto cross_term = [&](const RowW& a, const RowW& b) {
         D t = 0.0;
         lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; t += a.ut[Bc] * b.ut[Bc]; });
         lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; t += a.jl[Dd] * b.z[Dd]; });
         return t;
       };
+      lds.stv(base + C3_R, wn.R, valid);
       lds.stv(base + (C3_BLK + 0), wn.ad, valid); lds.stv(base + (C3_BLK + 1), cross_term(wn, w1), valid); lds.stv(base + (C3_BLK + 2), cross_term(wn, w2), valid);
       lds.stv(base + (C3_BLK + 3), w1.ad, valid); lds.stv(base + (C3_BLK + 4), cross_term(w1, w2), valid); lds.stv(base + (C3_BLK + 5), w2.ad, valid);
       // warm start of the cone (mj_constraintUpdate): top zone 0, bottom zone -D jar, middle zone on the cone
@@ -647,42 +669,79 @@ template <class B> struct Core3 {
       const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
       const D Dm = Dn / (mu * mu * (1.0 + mu * mu)), NmT = Nn - mu * Tt;
       const D fnm = -Dm * NmT * mu;
-      const D fn = B::sel(top, D(0.0), B::sel(bot, -Dn * wn.jar, fnm));
-      const D f1 = B::sel(top, D(0.0), B::sel(bot, -Dn * w1.jar, -fnm / Tt * U1 * mu));
-      const D f2 = B::sel(top, D(0.0), B::sel(bot, -Dn * w2.jar, -fnm / Tt * U2 * mu));
-      put_row(base, valid, wn, B::sel(valid, fn, D(0.0)));
-      put_row(base + R3_N, valid, w1, B::sel(valid, f1, D(0.0)));
-      put_row(base + 2 * R3_N, valid, w2, B::sel(valid, f2, D(0.0)));
+      const D fn = B::sel(valid, B::sel(top, D(0.0), B::sel(bot, -Dn * wn.jar, fnm)), D(0.0));
+      const D f1 = B::sel(valid, B::sel(top, D(0.0), B::sel(bot, -Dn * w1.jar, -fnm / Tt * U1 * mu)), D(0.0));
+      const D f2 = B::sel(valid, B::sel(top, D(0.0), B::sel(bot, -Dn * w2.jar, -fnm / Tt * U2 * mu)), D(0.0));
+      auto put = [&](I rb, const RowW& w, D f) {
+        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(rb + (C3_UT + Bc), w.ut[Bc], valid); });
+        lds.stv(rb + C3_B, w.bv, valid); lds.stv(rb + C3_F, f, valid);
+        warm(w, f);
+      };
+      put(base, wn, fn); put(base + C3_ROW, w1, f1); put(base + 2 * C3_ROW, w2, f2);
     }
     lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
-    // every row of the own leg, in any order: f(base, valid)
-    auto each_row = [&](auto&& fn) {
-      for (int s = 0; s < 3; s++) fn(I(ROW_EQ0 + s * R3_N), go);
-      for (int j = 0; j < 6; j++) { const M v = go & (nlim > j); if (!B::any(v)) break; fn(I(DYN0 + j * R3_N), v); }
-      for (int p = 0; p < 9; p++) {
-        const M v = go & (ncon > p);
-        if (!B::any(v)) break;
-        const I base = nlim * R3_N + (DYN0 + p * C3_N);
-        fn(base, v); fn(base + R3_N, v); fn(base + 2 * R3_N, v);
-      }
+    // (A f)_i + b_i pieces shared by the cost of the warm start and the sweeps: two accumulation chains instead of one
+    auto dot_c = [&](const D (&jl)[7]) {
+      D x = jl[0] * c[0], y = jl[1] * c[1];
+      x = B::fma(jl[2], c[2], x); y = B::fma(jl[3], c[3], y); x = B::fma(jl[4], c[4], x); y = B::fma(jl[5], c[5], y); x = B::fma(jl[6], c[6], x);
+      return x + y;
+    };
+    auto dot_a = [&](const D (&ut)[6]) {
+      D x = ut[0] * at[0], y = ut[1] * at[1];
+      x = B::fma(ut[2], at[2], x); y = B::fma(ut[3], at[3], y); x = B::fma(ut[4], at[4], x); y = B::fma(ut[5], at[5], y);
+      return x + y;
+    };
+    struct CRow { D jl[7], ut[6], b, f; };
+    auto cload = [&](I rb, CRow& r) {
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.jl[Dd] = lds.ldv(rb + (C3_JL + Dd)); });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(rb + (C3_UT + Bc)); });
+      r.b = lds.ldv(rb + C3_B); r.f = lds.ldv(rb + C3_F);
+    };
+    struct LRow { D jl[7], z[7], ut[6], R, b, f; };
+    auto lload = [&](I base, LRow& r) {
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.jl[Dd] = lds.ldv(base + (R3_JL + Dd)); r.z[Dd] = lds.ldv(base + (R3_Z + Dd)); });
+      lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(base + (R3_UT + Bc)); });
+      r.R = lds.ldv(base + R3_R); r.b = lds.ldv(base + R3_B); r.f = lds.ldv(base + R3_F);
     };
     {
       // cost of the warm start, 1/2 f'Af + f'b: kept only if negative
       D cost = 0.0;
-      each_row([&](I base, M valid) {
-        const D f = B::sel(valid, lds.ldv(base + R3_F), D(0.0));
-        D full = lds.ldv(base + R3_R) * f;
-        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; full += lds.ldv(base + (R3_UT + Bc)) * at[Bc]; });
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; full += lds.ldv(base + (R3_JL + Dd)) * c[Dd]; });
-        cost += B::sel(valid, f * (0.5 * full + lds.ldv(base + R3_B)), D(0.0));
-      });
+      lfor<0, 3>([&](auto ss) { constexpr int S = decltype(ss)::value;
+        cost += B::sel(go, eq[S].f * (0.5 * (eq[S].R * eq[S].f + dot_c(eq[S].jl) + dot_a(eq[S].ut)) + eq[S].b), D(0.0)); });
+      for (int j = 0; j < 6; j++) {
+        const M v = go & (nlim > j);
+        if (!B::any(v)) break;
+        LRow r; lload(I(DYN0 + j * R3_N), r);
+        cost += B::sel(v, r.f * (0.5 * (r.R * r.f + dot_c(r.jl) + dot_a(r.ut)) + r.b), D(0.0));
+      }
+      for (int p = 0; p < 9; p++) {
+        const M v = go & (ncon > p);
+        if (!B::any(v)) break;
+        const I base = nlim * R3_N + (DYN0 + p * C3_N);
+        const D R = lds.ldv(base + C3_R);
+        for (int i = 0; i < 3; i++) {
+          CRow r; cload(base + i * C3_ROW, r);
+          cost += B::sel(v, r.f * (0.5 * (R * r.f + dot_c(r.jl) + dot_a(r.ut)) + r.b), D(0.0));
+        }
+      }
       cost = cost + B::swap(cost);
       const M drop = cost > 0.0;
-      if (B::any(drop)) each_row([&](I base, M valid) { lds.stv(base + R3_F, D(0.0), valid & drop); });
+      if (B::any(drop)) {
+        lfor<0, 3>([&](auto ss) { constexpr int S = decltype(ss)::value; eq[S].f = B::sel(drop, D(0.0), eq[S].f); });
+        for (int j = 0; j < 6; j++) { const M v = go & (nlim > j); if (!B::any(v)) break; lds.stv(I(DYN0 + j * R3_N + R3_F), D(0.0), v & drop); }
+        for (int p = 0; p < 9; p++) {
+          const M v = go & (ncon > p);
+          if (!B::any(v)) break;
+          const I base = nlim * R3_N + (DYN0 + p * C3_N);
+          for (int i = 0; i < 3; i++) lds.stv(base + (i * C3_ROW + C3_F), D(0.0), v & drop);
+        }
+      }
       lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::sel(drop, D(0.0), c[Dd]); });
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::sel(drop, D(0.0), at[Bc]); });
     }
-    // ---- PGS sweeps (mj_solPGS, elliptic cones), MuJoCo's row order; a~ = `at` is shared by the two lanes of an environment
+    // ---- PGS sweeps (mj_solPGS, elliptic cones), MuJoCo's row order; a~ = `at` is shared by the two lanes of an environment.
+    // A lane that does not own a step executes it all the same with its deltas masked to zero; what it reads from its own LDS slots
+    // is whatever it last wrote there (finite: the kernel clears the slots once), so 0 x it cannot poison c or a~.
     I niter = 0;
     {
       const D scale = 1.0 / (MEANINERTIA * NV);
@@ -693,46 +752,45 @@ template <class B> struct Core3 {
         lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value;
           at[Bc] = w == 0 ? B::template pair_bcast<0>(at[Bc]) : B::template pair_bcast<1>(at[Bc]); });
       };
-      struct Row { D jl[7], z[7], ut[6], R, b, f; };
-      auto load = [&](I base, Row& r) {
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.jl[Dd] = lds.ldv(base + (R3_JL + Dd)); r.z[Dd] = lds.ldv(base + (R3_Z + Dd)); });
-        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(base + (R3_UT + Bc)); });
-        r.R = lds.ldv(base + R3_R); r.b = lds.ldv(base + R3_B); r.f = lds.ldv(base + R3_F);
+      auto apply_z = [&](const D (&z)[7], const D (&ut)[6], D d) {
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::fma(z[Dd], d, c[Dd]); });
+        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::fma(ut[Bc], d, at[Bc]); });
       };
-      auto resid = [&](const Row& r) {
-        D x = B::fma(r.R, r.f, r.b);
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; x = B::fma(r.jl[Dd], c[Dd], x); });
-        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; x = B::fma(r.ut[Bc], at[Bc], x); });
-        return x;
+      auto eq_step = [&](auto ss, M mine) {   // a connect row: unclamped
+        constexpr int S = decltype(ss)::value;
+        const D res = (B::fma(eq[S].R, eq[S].f, eq[S].b) + dot_c(eq[S].jl)) + dot_a(eq[S].ut);
+        D d = -(res * eq[S].ai);
+        D chg = d * B::fma(0.5 * eq[S].ad, d, res);
+        const M keep = mine & (chg <= 1e-10);
+        d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+        apply_z(eq[S].z, eq[S].ut, d);
+        acc = acc + chg;
+        eq[S].f = eq[S].f + d;
       };
-      auto apply = [&](const Row& r, D d) {
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::fma(r.z[Dd], d, c[Dd]); });
-        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::fma(r.ut[Bc], d, at[Bc]); });
-      };
-      // A lane that does not own the step executes it all the same (its deltas are masked to zero): it reads its first connect row
-      // instead of a record it may never have written, so that 0 x (whatever LDS held) cannot poison c or a~.
-      auto single = [&](I base_, M mine, bool clamp) {   // a connect row (unclamped) or a joint limit (f >= 0)
-        const I base = B::seli(mine, base_, I(ROW_EQ0));
-        Row r; load(base, r);
+      auto lim_step = [&](I base_, M mine) {   // a joint limit: f >= 0
+        const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
+        LRow r; lload(base, r);
         const D ad = lds.ldv(base + R3_AD), ai = lds.ldv(base + R3_AI);
-        const D res = resid(r);
-        D nf = B::fma(-res, ai, r.f);
-        if (clamp) nf = B::fmax(nf, D(0.0));
+        const D res = (B::fma(r.R, r.f, r.b) + dot_c(r.jl)) + dot_a(r.ut);
+        const D nf = B::fmax(B::fma(-res, ai, r.f), D(0.0));
         D d = nf - r.f;
         D chg = d * B::fma(0.5 * ad, d, res);
         const M keep = mine & (chg <= 1e-10);
         d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-        apply(r, d);
+        apply_z(r.z, r.ut, d);
         acc = acc + chg;
         lds.stv(base + R3_F, r.f + d, keep);
       };
       auto contact = [&](I base_, M mine) {
-        const I base = B::seli(mine, base_, I(ROW_EQ0));   // (a bystander reads connect rows 0..2 and garbage-free block entries are not needed: masked)
-        Row r0, r1, r2;
-        load(base, r0); load(base + R3_N, r1); load(base + 2 * R3_N, r2);
+        const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
+        CRow r0, r1, r2;
+        cload(base, r0); cload(base + C3_ROW, r1); cload(base + 2 * C3_ROW, r2);
+        const D R = lds.ldv(base + C3_R);
         const D A00 = lds.ldv(base + (C3_BLK + 0)), A01 = lds.ldv(base + (C3_BLK + 1)), A02 = lds.ldv(base + (C3_BLK + 2));
         const D A11 = lds.ldv(base + (C3_BLK + 3)), A12 = lds.ldv(base + (C3_BLK + 4)), A22 = lds.ldv(base + (C3_BLK + 5));
-        const D q0 = resid(r0), q1 = resid(r1), q2 = resid(r2);
+        const D q0 = (B::fma(R, r0.f, r0.b) + dot_c(r0.jl)) + dot_a(r0.ut);
+        const D q1 = (B::fma(R, r1.f, r1.b) + dot_c(r1.jl)) + dot_a(r1.ut);
+        const D q2 = (B::fma(R, r2.f, r2.b) + dot_c(r2.jl)) + dot_a(r2.ut);
         const D o0 = r0.f, o1 = r1.f, o2 = r2.f;
         // normal-only update (taken when the normal force is ~0)
         const D fn_n = B::fmax(o0 - q0 * B::rcp(A00), D(0.0));
@@ -791,16 +849,27 @@ template <class B> struct Core3 {
                 d0 * q0 + d1 * q1 + d2 * q2;
         const M keep = mine & (chg <= 1e-10);
         d0 = B::sel(keep, d0, D(0.0)); d1 = B::sel(keep, d1, D(0.0)); d2 = B::sel(keep, d2, D(0.0)); chg = B::sel(keep, chg, D(0.0));
-        apply(r0, d0); apply(r1, d1); apply(r2, d2);
+        // c += L^-1 (jl_0 d0 + jl_1 d1 + jl_2 d2), a~ += u~_0 d0 + u~_1 d1 + u~_2 d2
+        D gw[7];
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; gw[Dd] = B::fma(r2.jl[Dd], d2, B::fma(r1.jl[Dd], d1, r0.jl[Dd] * d0)); });
+        lfor<0, 7>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
+          D xa = fc.Li[symidx(7, Ii, 0)] * gw[0], xb = fc.Li[symidx(7, Ii, 1)] * gw[1];
+          xa = B::fma(fc.Li[symidx(7, Ii, 2)], gw[2], xa); xb = B::fma(fc.Li[symidx(7, Ii, 3)], gw[3], xb);
+          xa = B::fma(fc.Li[symidx(7, Ii, 4)], gw[4], xa); xb = B::fma(fc.Li[symidx(7, Ii, 5)], gw[5], xb);
+          xa = B::fma(fc.Li[symidx(7, Ii, 6)], gw[6], xa);
+          c[Ii] = c[Ii] + (xa + xb);
+        });
+        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::fma(r2.ut[Bc], d2, B::fma(r1.ut[Bc], d1, B::fma(r0.ut[Bc], d0, at[Bc]))); });
         acc = acc + chg;
-        lds.stv(base + R3_F, o0 + d0, keep); lds.stv(base + (R3_N + R3_F), o1 + d1, keep); lds.stv(base + (2 * R3_N + R3_F), o2 + d2, keep);
+        lds.stv(base + C3_F, o0 + d0, keep); lds.stv(base + (C3_ROW + C3_F), o1 + d1, keep); lds.stv(base + (2 * C3_ROW + C3_F), o2 + d2, keep);
       };
-      for (int iter = 0; iter < ITERATIONS; iter++) {
+      for (int iter = 0; iter < LEG3_ITERS; iter++) {
         if (!B::any(sweeping)) break;
         acc = 0.0;
         for (int w = 0; w < 2; w++) {
           const M side = (w == 0 ? isL : !isL) & sweeping;
-          for (int s = 0; s < 3; s++) single(I(ROW_EQ0 + s * R3_N), side, false);
+          eq_step(LI<0>{}, side); eq_step(LI<1>{}, side); eq_step(LI<2>{}, side);
           sync(w);
         }
         for (int w = 0; w < 2; w++) {
@@ -809,7 +878,7 @@ template <class B> struct Core3 {
           for (int j = 0; j < 6; j++) {
             const M mine = side & (nlim > j);
             if (!B::any(mine)) break;
-            single(I(DYN0 + j * R3_N), mine, true);
+            lim_step(I(DYN0 + j * R3_N), mine);
           }
           sync(w);
         }

@@ -623,6 +623,8 @@ struct Cassie3dVec {
   hipStream_t stream = nullptr, own_stream = nullptr;  // kernels run on `stream`; `own_stream` is the one this handle created
   double *state = nullptr, *d_act = nullptr, *d_dbg = nullptr;
   int* pending = nullptr;
+  int* pending_leg = nullptr;   // substeps left per env after the lane-per-leg kernel
+  bool leg = true;    // first tier = the lane-per-leg kernel (cassie3d_leg.hip), 32 environments per wavefront; CASSIE3D_LEG=0: the r03 tiers only
   bool pair = false;  // CASSIE3D_PAIR=1: first pass with TWO environments per wavefront (cassie3d_pair.hip; parity-green, measured slower: kept as cross-check)
   unsigned long long* stats = nullptr;
   unsigned long long substeps_requested = 0;
@@ -638,7 +640,16 @@ void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
     L3::step3d(1, h->n, h->stream, p);
     return;
   }
-  p.pending_in = nullptr; p.pending_out = h->pending;
+  // tiers: one lane per leg (rows in per-lane LDS slots: 3 connect rows + 25 slots per limit + 81 per contact) -> one wavefront
+  // per environment with at most 32 rows -> the general kernel (64 rows, capped); each leaves an environment it cannot hold
+  // untouched from that substep on and says how many substeps are left
+  const int* in = nullptr;
+  if (h->leg) {
+    p.pending_in = nullptr; p.pending_out = h->pending_leg;
+    L3::step3d(3, h->n, h->stream, p);
+    in = h->pending_leg;
+  }
+  p.pending_in = in; p.pending_out = h->pending;
   L3::step3d(h->pair ? 2 : 0, h->n, h->stream, p);
   p.pending_in = h->pending; p.pending_out = nullptr;
   L3::step3d(1, h->n, h->stream, p);
@@ -672,9 +683,11 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->state, (size_t)n_envs * cassie3d::ENV3_STRIDE * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->pending_leg, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
+  { const char* e = getenv("CASSIE3D_LEG"); if (e && e[0] == '0') h->leg = false; }
   if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
-  { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '1') h->pair = true; }
+  { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '1') { h->pair = true; h->leg = false; } }   // the opt-in cross-check kernel is a FIRST tier (it takes no pending list)
   if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
   return CASSIE_OK;
@@ -684,7 +697,7 @@ void Cassie3dVecFree(Cassie3dVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending); hipFree(h->stats);
+  hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->stats);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -739,7 +752,7 @@ int Cassie3dVecGetCounters(Cassie3dVec* h, uint64_t* out4) {
   out4[0] = h->substeps_requested;
   out4[1] = host[cassie3d::S3_GENERAL_SUBSTEPS];
   out4[2] = host[cassie3d::S3_CAPPED_SUBSTEPS];
-  out4[3] = 0;
+  out4[3] = host[cassie3d::S3_LEG_HANDOVER_SUBSTEPS];
   return CASSIE_OK;
 }
 

@@ -47,7 +47,7 @@ void ctrl_g16(int ctrl, bool scripted, int n_envs, hipStream_t s, const VecParam
 namespace cassie3d {
 namespace launch {
 // tu_3d.hip
-void step3d(int variant /*0: <MAXR_FAST,2>, 1: <MAXR,1>*/, int n_envs, hipStream_t s, const Params3& p);
+void step3d(int variant /*0: <MAXR_FAST,3>, 1: <MAXR,1>, 2: two environments per wavefront, 3: one lane per leg (32 per wavefront)*/, int n_envs, hipStream_t s, const Params3& p);
 void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const double* qvel);
 }  // namespace launch
 }  // namespace cassie3d

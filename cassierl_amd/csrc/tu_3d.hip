@@ -2,6 +2,7 @@
 #include "cassie_kernels.hip"
 #include "cassie3d_kernels.hip"
 #include "cassie3d_pair.hip"
+#include "cassie3d_leg.hip"
 #include "cassie_launch.h"
 
 #ifndef C3_FAST_WPS
@@ -13,7 +14,8 @@ namespace launch {
 
 void step3d(int variant, int n_envs, hipStream_t s, const Params3& p) {
   dim3 grid(n_envs), block(64);
-  if (variant == 2) hipLaunchKernelGGL(env_step3d_pair_kernel, dim3((n_envs + 1) / 2), block, 0, s, p);   // two environments per wavefront
+  if (variant == 3) hipLaunchKernelGGL(leg::env_step3d_leg_kernel, dim3((n_envs + 31) / 32), block, 0, s, p);   // one lane per leg, 32 environments per wavefront
+  else if (variant == 2) hipLaunchKernelGGL(env_step3d_pair_kernel, dim3((n_envs + 1) / 2), block, 0, s, p);   // two environments per wavefront
   else if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, C3_FAST_WPS>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((env_step3d_kernel<MAXR, 1>), grid, block, 0, s, p);
 }

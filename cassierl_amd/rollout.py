@@ -73,6 +73,12 @@ def init_distributed(backend=None):
     # communicator and the gather exactly as an N-rank run does (tests/test_gpu_bench.py)
     force = os.environ.get("CASSIE_FORCE_PROCESS_GROUP", "") == "1" and "MASTER_ADDR" in os.environ
     if (world > 1 or force) and not dist.is_initialized():
+        # One node, rendezvous on loopback: keep the backends' socket bootstrap on `lo` too.  Left to themselves gloo and RCCL look
+        # their interfaces up through the host name, which a container may not be able to resolve -- measured on one MI355X box:
+        # 322 s for the process group of a single rank, 5 s on another (this was the driver's 643 s GPU suite of round 3).
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if backend is None:
             backend = os.environ.get("CASSIE_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":

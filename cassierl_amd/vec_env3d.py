@@ -44,11 +44,12 @@ class Cassie3dVec:
         self._chk(self.L.Cassie3dVecSynchronize(self.h))
 
     def counters(self):
-        """env-substeps requested / done by the 64-row kernel / with the 64-row cap leaving contacts out."""
+        """env-substeps requested / done by the 64-row kernel / with the 64-row cap leaving contacts out / handed down by the lane-per-leg kernel."""
         out = (ct.c_uint64 * 4)()
         self._chk(self.L.Cassie3dVecGetCounters(self.h, out))
-        req, gen, cap = int(out[0]), int(out[1]), int(out[2])
-        return dict(substeps=req, general_kernel_substeps=gen, capped_substeps=cap, general_frac=(gen / req if req else 0.0))
+        req, gen, cap, leg = int(out[0]), int(out[1]), int(out[2]), int(out[3])
+        return dict(substeps=req, general_kernel_substeps=gen, capped_substeps=cap, general_frac=(gen / req if req else 0.0),
+                    leg_handover_substeps=leg, leg_handover_frac=(leg / req if req else 0.0))
 
     def reset_counters(self):
         self._chk(self.L.Cassie3dVecResetCounters(self.h))

@@ -56,7 +56,7 @@ double* Cassie3dVecStatePtr(Cassie3dVec* h); /* device [n][CASSIE3D_STATE_STRIDE
  *   out4[2] env-substeps in which more than 64 constraint rows were active (the model's maximum is 69: 6 connect + 12 limit rows
  *           + 17 contacts x 3) and the LAST contacts in MuJoCo order were left out for that substep.  The environment keeps
  *           stepping (no frozen environment); record slot CASSIE3D_OFF_OVERFLOW counts the same per environment.
- *   out4[3] reserved (0) */
+ *   out4[3] env-substeps the lane-per-leg kernel (first tier) handed to the wavefront-per-environment kernels (row capacity of its per-lane LDS slots) */
 int Cassie3dVecGetCounters(Cassie3dVec* h, uint64_t* out4);
 int Cassie3dVecResetCounters(Cassie3dVec* h);
 /* host-pointer conveniences (tests, small batches) */

@@ -40,7 +40,7 @@ int leg3d_host_step(double* state, const double* torques, int n, int n_sub, int 
   for (int g = 0; g < groups; g++) {
     const int e0 = g * EPG;
     static thread_local HostB3::Lds lds;
-    for (auto& r : lds.a) LANES r[l] = std::nan("");   // nothing may be read that was not written in this call
+    for (auto& r : lds.a) LANES r[l] = 7.0;   // (the kernel clears its slots once; a finite non-zero value here shows a read of a slot that was never written as a wrong result)
     HCore3::Io io;
     LANES { const int e = e0 + (l >> 1); io.rec.p[l] = state + (size_t)(e < n ? e : e0) * cassie3d::ENV3_STRIDE; }
     io.has_act = torques != nullptr;

@@ -39,7 +39,8 @@ def main():
             tot_ms += env.time_steps(acts[(t0 + t) % 8], 10, 1)
         env.reset()
     s = env.get_state_host()
-    out = dict(config="configs[4]: Cassie3d torque-mode random rollout", n_envs=a.envs, steps=a.steps, ms_per_step=tot_ms / a.steps,
+    cnt = env.counters()
+    out = dict(leg_handover_frac=cnt.get("leg_handover_frac"), general_frac=cnt.get("general_frac"), config="configs[4]: Cassie3d torque-mode random rollout", n_envs=a.envs, steps=a.steps, ms_per_step=tot_ms / a.steps,
                env_steps_per_s=a.envs * a.steps / (tot_ms * 1e-3), physics_substeps_per_s=10 * a.envs * a.steps / (tot_ms * 1e-3),
                overflowed_envs=int((s[:, 74] != 0).sum()), finite=bool(np.isfinite(s).all()))
     if a.cpu_baseline:

@@ -39,6 +39,14 @@ def random_state(rng, kat, spread=0.3, height=None):
     return q, v
 
 
+@pytest.fixture(params=["leg", "wave"])
+def tier(request, monkeypatch):
+    """First Cassie3d kernel tier: "leg" = one lane per leg, 32 environments per wavefront (cassie3d_leg.hip, the default),
+    "wave" = the r03 tiers only (one wavefront per environment; CASSIE3D_LEG=0).  Read by Cassie3dVecCreate."""
+    monkeypatch.setenv("CASSIE3D_LEG", "1" if request.param == "leg" else "0")
+    return request.param
+
+
 def test_forward_dynamics_terms_match_oracle(V3, kat):
     """mj_forward piece by piece on random states (in the air and in contact): M, bias, smooth acceleration, constraint rows,
     reference accelerations, forces, qacc."""
@@ -85,7 +93,7 @@ def _set_ctrl_forward(o, u):
     o.forward()
 
 
-def test_teacher_forced_steps_match_oracle(V3, kat):
+def test_teacher_forced_steps_match_oracle(V3, kat, tier):
     """1000 substeps of random torques, the kernel restarted from the oracle's state (incl. warm start) at every substep."""
     import oracle_py
     rng = np.random.default_rng(1)
@@ -111,7 +119,7 @@ def test_teacher_forced_steps_match_oracle(V3, kat):
     env.close()
 
 
-def test_free_running_1000_substeps_within_1e5(V3, kat):
+def test_free_running_1000_substeps_within_1e5(V3, kat, tier):
     """north_star tolerance: state trajectories within 1e-5 relative over 1000 steps on identical actions (free running)."""
     import oracle_py
     rng = np.random.default_rng(2)
@@ -133,7 +141,7 @@ def test_free_running_1000_substeps_within_1e5(V3, kat):
     env.close()
 
 
-def test_reset_and_batch_independence(V3, kat):
+def test_reset_and_batch_independence(V3, kat, tier):
     """Every environment of a batch is independent and the default reset is the standing pose with a valid warm start."""
     import torch
     env = V3.Cassie3dVec(130)
@@ -151,7 +159,7 @@ def test_reset_and_batch_independence(V3, kat):
     env.close()
 
 
-def test_many_contacts_hand_over_to_the_general_kernel(V3, kat):
+def test_many_contacts_hand_over_to_the_general_kernel(V3, kat, tier):
     """A robot lying on the floor has more than 32 constraint rows: the high-occupancy kernel hands the environment over to the
     64-row kernel (pending list).  Same checks as above on such states, through both the debug (general kernel only) and the
     normal two-kernel path, including an Env.step that starts below 32 rows and crosses the limit part-way."""
@@ -243,7 +251,7 @@ def test_two_environments_per_wavefront_kernel_agrees_with_the_default(V3, kat, 
     env_a.close(); env_b.close()
 
 
-def test_row_cap_beyond_64_rows_matches_the_capped_oracle(V3, kat):
+def test_row_cap_beyond_64_rows_matches_the_capped_oracle(V3, kat, tier):
     """The model's worst case is 69 rows (6 connect + 12 limits + 17 contacts x 3); the 64-row kernel then leaves the last
     contacts out for that substep instead of freezing the environment.  A pressed-down, folded-up robot reaches
     that regime: the kernel must match the oracle run with the same cap, count the event, and keep stepping."""
