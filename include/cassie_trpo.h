@@ -1,0 +1,51 @@
+/* cassie_trpo.h -- fused policy kernels of the TRPO outer loop: the counterpart of what rllab's TRPO
+ * (rllab/envs/trpo_cassie.py:21-42: GaussianMLPPolicy 32x32 tanh, conjugate-gradient optimiser with Fisher-vector products by
+ * double backprop through the mean KL) evaluates on the sampled batch, for the batch sizes the vectorised environment produces
+ * (65 536 envs x 8 steps = 524 288 samples per rank and iteration).
+ *
+ * The policy is mean(obs) = W3 tanh(W2 tanh(W1 obs + b1) + b2) + b3 with a state-independent log-std; float32, row-major weights
+ * as torch.nn.Linear stores them (W1 [32][obs_dim], W2 [32][32], W3 [act_dim][32]).  Plain device pointers and sizes; every call
+ * enqueues on `stream` (a hipStream_t, 0 = default) and returns 0 or a negative CASSIE_E* code (cassie_vec.h).
+ *
+ * Both entry points write PARTIAL sums, one row per wavefront of the launch: partial [n_rows][CassieTrpoParamCount] float32 with the
+ * row layout [gW1 | gb1 | gW2 | gb2 | gW3 | gb3]; the caller adds the rows up (one reduction) -- and all-reduces the result over
+ * ranks, exactly where the unfused version did.  CassieTrpoPartialRows() says how many rows a launch over n samples writes.
+ */
+#ifndef CASSIE_TRPO_H_
+#define CASSIE_TRPO_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* parameters of the mean network: 32 * obs_dim + 32 + 32 * 32 + 32 + act_dim * 32 + act_dim; 0 for an unsupported shape
+ * (supported: obs_dim 26 or 17, act_dim 6 or 7) */
+int CassieTrpoParamCount(int obs_dim, int act_dim);
+int CassieTrpoPartialRows(int n_samples);
+
+/* Fisher-vector product of the mean network, (1/n) J' S J v: J = d mean / d theta at the CURRENT weights (forward mode per sample
+ * along the direction dW1..db3, activations recomputed), S = diag(prec[act_dim]) the precision of the old Gaussian, then reverse
+ * mode back to the parameters.  scale is the 1/n (n of the whole job) the caller wants folded in. */
+int CassieTrpoFvp(const float* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* W3, const float* b3, const float* dW1, const float* db1, const float* dW2, const float* db2, const float* dW3,
+                  const float* db3, const float* prec, float scale, float* partial_dev, void* stream);
+
+/* Vector-Jacobian product J' w for per-sample cotangents w [n][act_dim] on the mean (the policy gradient of the surrogate loss:
+ * w = d loss / d mean, evaluated by the caller). */
+int CassieTrpoVjp(const float* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                  const float* W3, const float* b3, const float* w_dev, float* partial_dev, void* stream);
+
+/* One policy step of the sampler for n environments in ONE launch (the counterpart of GaussianMLPPolicy.get_actions + rllab's
+ * normalize() wrapper, rllab/envs/trpo_cassie.py:13,21-27): obs float64 [n][obs_dim] as the environment wrote it ->
+ *   obs32 [n][obs_dim] (the policy's float32 view, kept for the update), mean [n][act_dim] = mean network, act [n][act_dim] = mean +
+ *   noise * exp(log_std) (noise: standard normal numbers of the caller, row stride act_dim), and
+ *   env_actions float64 [n][act_dim] = clip(low + (act + 1) / 2 * (high - low), low, high): what CassieVecStep consumes. */
+int CassieTrpoPolicyStep(const double* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2,
+                         const float* b2, const float* W3, const float* b3, const float* log_std, const float* noise_dev,
+                         const double* low_dev, const double* high_dev, float* obs32_dev, float* mean_dev, float* act_dev,
+                         double* env_actions_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

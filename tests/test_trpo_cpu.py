@@ -227,7 +227,7 @@ def _data(n=256):
 
 
 def _dp_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), GLOO_SOCKET_IFNAME="lo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     obs, act, adv = _data()
     h = obs.shape[0] // world
@@ -285,3 +285,38 @@ def test_chunked_gram_matches_plain_products():
         X, y = torch.randn(n, 7, dtype=torch.float64), torch.randn(n, dtype=torch.float64)
         A, b = gram(X, y, chunk=2048)
         assert torch.allclose(A, X.T @ X, rtol=1e-12, atol=1e-10) and torch.allclose(b, X.T @ y, rtol=1e-12, atol=1e-10)
+
+
+def test_closed_form_policy_gradient_matches_autograd():
+    """optimize() takes the gradient of the surrogate loss in closed form when a Fisher object exists (likelihood ratio 1 at theta_old:
+    d loss / d mean = -adv z / std / N through the Fisher object's reverse pass, d loss / d log_std = -sum adv (z^2 - 1) / N):
+    against autograd through the surrogate, float64."""
+    import torch
+    from cassierl_amd.trpo import AnalyticFisher, GaussianMLPPolicy, flat_grad
+    torch.manual_seed(5)
+    pol = GaussianMLPPolicy(26, 6, (32, 32), init_std=2.0, dtype=torch.float64)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    n = 700
+    obs = torch.randn(n, 26, dtype=torch.float64)
+    adv = torch.randn(n, dtype=torch.float64)
+    with torch.no_grad():
+        mean, lstd = pol.dist_info(obs)
+        act = mean + torch.randn_like(mean) * lstd.exp()
+        old_ll = pol.log_likelihood(act, mean, lstd)
+    m2, l2 = pol.dist_info(obs)
+    loss = -((pol.log_likelihood(act, m2, l2) - old_ll).exp() * adv).mean()
+    g_ref = flat_grad(loss, pol)
+    fisher = AnalyticFisher(pol, obs)
+    std = lstd.exp()
+    z = (act - mean) / std
+    g = fisher.vjp(-(adv.unsqueeze(-1) * z / std) / n)
+    g_ls = -((adv.unsqueeze(-1) * (z * z - 1.0)).sum(0)) / n
+    i0 = 0
+    for nm, p_ in pol.named_parameters():
+        if nm == "log_std":
+            g[i0:i0 + p_.numel()] += g_ls
+        i0 += p_.numel()
+    assert (g - g_ref).abs().max() < 1e-12 * (1 + g_ref.abs().max())
+    assert abs(float(loss) - float(-adv.mean())) < 1e-14
