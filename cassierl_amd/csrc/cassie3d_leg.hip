@@ -23,6 +23,12 @@
 namespace cassie3d {
 namespace leg {
 
+// LANES: active lanes per wavefront (64 = 32 environments, 32 = 16 environments with the upper half of the wavefront idle).  The kernel is
+// bound by the latency of its own chains at one wavefront per SIMD, and LDS -- NSLOT3 slots per ACTIVE lane -- is what limits the
+// wavefronts per CU: with 32 active lanes a wavefront needs 40 KB, so FOUR share a CU (one per SIMD) instead of two, each walks the
+// row counts of the worst of 16 environments instead of 32, and configs[4]'s 16 384 environments are 1024 wavefronts = one round of
+// the whole chip (r04: 7.55 -> ... ms per step).  The idle lanes cost nothing: a wave instruction takes the same time either way.
+template <int LANES>
 struct DevB3 {
   typedef double D;
   typedef int I;
@@ -31,12 +37,13 @@ struct DevB3 {
   typedef const double* K;   // the lane's row of c3_legk
   static LEG_FN K kbase(int leg) { return &c3_legk[0][0] + leg * LK3_N; }
   static LEG_FN double kld(K k, int idx) { return k[idx]; }
-  struct Lds {
-    double a[NSLOT3][64];
-    LEG_FN double ld(int s) const { return a[s][threadIdx.x]; }
-    LEG_FN void st(int s, double v, bool m) { if (m) a[s][threadIdx.x] = v; }
-    LEG_FN double ldv(int s) const { return a[s][threadIdx.x]; }
-    LEG_FN void stv(int s, double v, bool m) { if (m) a[s][threadIdx.x] = v; }
+  struct Lds {   // (an idle lane stores nothing -- not even the unconditional stores of the kinematics passes -- and reads the slots of lane - LANES)
+    double a[NSLOT3][LANES];
+    static LEG_FN bool mine() { return LANES == 64 || (int)threadIdx.x < LANES; }
+    LEG_FN double ld(int s) const { return a[s][threadIdx.x & (LANES - 1)]; }
+    LEG_FN void st(int s, double v, bool m) { if (m && mine()) a[s][threadIdx.x & (LANES - 1)] = v; }
+    LEG_FN double ldv(int s) const { return a[s][threadIdx.x & (LANES - 1)]; }
+    LEG_FN void stv(int s, double v, bool m) { if (m && mine()) a[s][threadIdx.x & (LANES - 1)] = v; }
   };
   static LEG_FN int leg() { return (int)threadIdx.x & 1; }
   static LEG_FN void fence() { __builtin_amdgcn_sched_barrier(0); }
@@ -68,22 +75,23 @@ struct DevB3 {
   static LEG_FN double pld(const double* p, int off) { return p[off]; }
   static LEG_FN void pst(double* p, int off, double v, bool m) { if (m) p[off] = v; }
 };
-typedef Core3<DevB3> DCore3;
 
 // pending_out[env] = substeps this kernel did NOT do because the environment needed more constraint rows than a lane's LDS slots hold
 // (0 normally); env_step3d_kernel finishes those (cassie_cabi.hip).
+template <int LANES>
 __global__ void __launch_bounds__(64, 1) env_step3d_leg_kernel(Params3 p) {
-  __shared__ DevB3::Lds lds;
+  typedef Core3<DevB3<LANES>> DCore3;
+  __shared__ typename DevB3<LANES>::Lds lds;
   const int lane = threadIdx.x;
-  const int env = blockIdx.x * 32 + (lane >> 1);
-  const bool valid = env < p.n_envs;
+  const int env = blockIdx.x * (LANES / 2) + (lane >> 1);
+  const bool valid = lane < LANES && env < p.n_envs;
   const size_t e = valid ? (size_t)env : 0;
-  DCore3::Io io;
+  typename DCore3::Io io;
   io.rec = p.state + e * ENV3_STRIDE;
   io.has_act = p.actions != nullptr;
   io.act = io.has_act ? const_cast<double*>(p.actions) + e * NU : io.rec;
-  for (int s = 0; s < NSLOT3; s++) lds.a[s][lane] = 0.0;   // a lane only ever reads back what it wrote -- or this
-  DCore3::Out o;
+  if (lane < LANES) for (int s = 0; s < NSLOT3; s++) lds.a[s][lane] = 0.0;   // a lane only ever reads back what it wrote -- or this
+  typename DCore3::Out o;
   DCore3::env_step(lds, io, valid, p.n_sub, p.integrate != 0, o);
   if (valid && (lane & 1) == 0) {
     double* st = p.state + e * ENV3_STRIDE;

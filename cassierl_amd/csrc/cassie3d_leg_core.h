@@ -45,6 +45,9 @@
 namespace cassie3d {
 namespace leg {
 
+#ifndef LEG3_STAT   // instrumented CPU builds only (tests/leg3d_stats.py): counts executed sweeps / limit steps / contact steps / Newton iterations per wavefront
+#define LEG3_STAT(k)
+#endif
 #ifndef LEG3_ITERS
 #define LEG3_ITERS ITERATIONS   // (timing experiments only: -DLEG3_ITERS=n)
 #endif
@@ -768,6 +771,7 @@ template <class B> struct Core3 {
         eq[S].f = eq[S].f + d;
       };
       auto lim_step = [&](I base_, M mine) {   // a joint limit: f >= 0
+        LEG3_STAT(1);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
         LRow r; lload(base, r);
         const D ad = lds.ldv(base + R3_AD), ai = lds.ldv(base + R3_AI);
@@ -782,6 +786,7 @@ template <class B> struct Core3 {
         lds.stv(base + R3_F, r.f + d, keep);
       };
       auto contact = [&](I base_, M mine) {
+        LEG3_STAT(2);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
         CRow r0, r1, r2;
         cload(base, r0); cload(base + C3_ROW, r1); cload(base + 2 * C3_ROW, r2);
@@ -817,6 +822,7 @@ template <class B> struct Core3 {
           D P11 = Q22 * di0, P22 = Q11 * di0, P12 = -(Q12 * di0);
           for (int it = 0; it < 20; it++) {
             if (!B::any(run)) break;
+            LEG3_STAT(3);
             const D deriv = -2.0 * (P11 * v1 * v1 + 2.0 * P12 * v1 * v2 + P22 * v2 * v2);
             const D delta = -val * B::rcp(deriv);
             run = run & !(delta < 1e-10);
@@ -866,6 +872,7 @@ template <class B> struct Core3 {
       };
       for (int iter = 0; iter < LEG3_ITERS; iter++) {
         if (!B::any(sweeping)) break;
+        LEG3_STAT(0);
         acc = 0.0;
         for (int w = 0; w < 2; w++) {
           const M side = (w == 0 ? isL : !isL) & sweeping;

@@ -625,6 +625,7 @@ struct Cassie3dVec {
   int* pending = nullptr;
   int* pending_leg = nullptr;   // substeps left per env after the lane-per-leg kernel
   bool leg = true;    // first tier = the lane-per-leg kernel (cassie3d_leg.hip), 32 environments per wavefront; CASSIE3D_LEG=0: the r03 tiers only
+  bool leg_full = false;   // CASSIE3D_LEG=64: 32 environments per wavefront instead of 16 (A/B)
   bool pair = false;  // CASSIE3D_PAIR=1: first pass with TWO environments per wavefront (cassie3d_pair.hip; parity-green, measured slower: kept as cross-check)
   unsigned long long* stats = nullptr;
   unsigned long long substeps_requested = 0;
@@ -646,7 +647,7 @@ void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
   const int* in = nullptr;
   if (h->leg) {
     p.pending_in = nullptr; p.pending_out = h->pending_leg;
-    L3::step3d(3, h->n, h->stream, p);
+    L3::step3d(h->leg_full ? 4 : 3, h->n, h->stream, p);
     in = h->pending_leg;
   }
   p.pending_in = in; p.pending_out = h->pending;
@@ -684,7 +685,7 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->d_act, (size_t)n_envs * cassie3d::NU * sizeof(double)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMalloc(&h->pending_leg, (size_t)n_envs * sizeof(int)) != hipSuccess) return bail(CASSIE_EHIP);
-  { const char* e = getenv("CASSIE3D_LEG"); if (e && e[0] == '0') h->leg = false; }
+  { const char* e = getenv("CASSIE3D_LEG"); if (e && e[0] == '0') h->leg = false; if (e && e[0] == '6') h->leg_full = true; }
   if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '1') { h->pair = true; h->leg = false; } }   // the opt-in cross-check kernel is a FIRST tier (it takes no pending list)

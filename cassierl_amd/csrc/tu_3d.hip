@@ -14,7 +14,8 @@ namespace launch {
 
 void step3d(int variant, int n_envs, hipStream_t s, const Params3& p) {
   dim3 grid(n_envs), block(64);
-  if (variant == 3) hipLaunchKernelGGL(leg::env_step3d_leg_kernel, dim3((n_envs + 31) / 32), block, 0, s, p);   // one lane per leg, 32 environments per wavefront
+  if (variant == 3) hipLaunchKernelGGL(leg::env_step3d_leg_kernel<32>, dim3((n_envs + 15) / 16), block, 0, s, p);   // one lane per leg, 16 environments per wavefront (half of it idle: four wavefronts per CU)
+  else if (variant == 4) hipLaunchKernelGGL(leg::env_step3d_leg_kernel<64>, dim3((n_envs + 31) / 32), block, 0, s, p);   // ... 32 environments per wavefront (two per CU): CASSIE3D_LEG=64
   else if (variant == 2) hipLaunchKernelGGL(env_step3d_pair_kernel, dim3((n_envs + 1) / 2), block, 0, s, p);   // two environments per wavefront
   else if (variant == 0) hipLaunchKernelGGL((env_step3d_kernel<MAXR_FAST, C3_FAST_WPS>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((env_step3d_kernel<MAXR, 1>), grid, block, 0, s, p);

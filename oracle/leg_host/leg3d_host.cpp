@@ -7,6 +7,10 @@
 #define __forceinline__ inline
 #define LEG_FN inline
 #define LEG3_SUBSTEP_FN inline
+#ifdef LEG3_STATS
+static long long g_leg3_stat[4];
+#define LEG3_STAT(k) (++g_leg3_stat[k])
+#endif
 #include "../../cassierl_amd/csrc/cassie3d_leg_core.h"
 
 #include "lane_types.h"
@@ -58,5 +62,8 @@ int leg3d_host_step(double* state, const double* torques, int n, int n_sub, int 
 }
 
 int leg3d_host_lanes(void) { return NL; }
+#ifdef LEG3_STATS
+void leg3d_host_stats(long long* out4) { for (int i = 0; i < 4; i++) { out4[i] = g_leg3_stat[i]; g_leg3_stat[i] = 0; } }
+#endif
 
 }  // extern "C"
