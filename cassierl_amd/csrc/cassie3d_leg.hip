@@ -62,12 +62,16 @@ struct DevB3 {
   static LEG_FN int toI(bool m) { return (int)m; }
   static LEG_FN void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
   static LEG_FN double sqrt(double x) { return ::sqrt(x); }
-  static LEG_FN double rcp(double d) {   // 1/d to ~1 ulp: hardware seed + two Newton steps
+  // 1/d: hardware seed (about 2^-26 relative) + ONE Newton step = a few ulp; the second step that K1c takes (it is compared bit for
+  // bit with its host build) costs 2 dependent FMAs on each of the ~14 reciprocals of a contact step: 6.63 -> 6.32 ms per Env.step
+  static LEG_FN double rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
+#ifndef LEG3_RCP_STEPS
+#define LEG3_RCP_STEPS 1
+#endif
+#pragma unroll
+    for (int i = 0; i < LEG3_RCP_STEPS; i++) { const double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r); }
+    return r;
   }
   static LEG_FN double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
   static LEG_FN double fabs(double x) { return ::fabs(x); }

@@ -19,8 +19,8 @@
 //     stored but the 3x3 diagonal block of a contact.  qacc = qacc_smooth + [G' a~ ; c - Y G' a~] needs no second solve.
 //   * PGS in MuJoCo's row order (connect L, R; limits L, R; contacts pelvis + L, R), elliptic cones with the QCQP of mju_QCQP2,
 //     a~ exchanged once per block; every loop over rows is ROLLED (row data is in LDS, so run-time indices are free).
-//   * Capacity: the 3 connect rows of a leg in registers + NSLOT3 = 160 per-lane LDS slots at 25 per joint limit and 52 per contact
-//     (3 contacts; 2 contacts + 2 limits; 1 contact + 4 limits): 80 KB per wavefront, two wavefronts per CU.  An environment that
+//   * Capacity: the 3 connect rows of a leg in registers + NSLOT3 = 160 per-lane LDS slots
+//     at 18 per joint limit and 52 per contact (3 contacts; 2 contacts + 3 limits; 1 contact + 6 limits): 80 KB per wavefront, two wavefronts per CU.  An environment that
 //     needs more is left untouched from that substep on and handed to env_step3d_kernel through `pending`.
 //
 // The arithmetic restates the same mj_forward / mj_Euler as cassie3d_kernels.hip (kinematics, CRB, RNE bias, plane-sphere and
@@ -54,17 +54,18 @@ namespace leg {
 constexpr int NSLOT3 = 160;   // per-lane LDS slots (doubles): 80 KB per wavefront = two wavefronts per CU
 // Rows of the matrix-free solver.  The three connect rows of a leg always exist: they stay in REGISTERS (static indices).  Joint
 // limits and contacts are compacted into the per-lane LDS slots, limits first:
-//   limit record   jl(7) z(7) u~(6) R b A_ii 1/A_ii f                                              25 slots
+//   limit record   z(7) u~(6) R b A_ii f ks                                                       18 slots  (the Jacobian of a joint limit is
+//                  s e_k: ks = s (k + 1) stands for it, jl . c = s c_k comes from a select chain, 1 / A_ii is recomputed)
 //   contact record 3 x [jl(7) u~(6) b f] + R + the packed 3x3 diagonal block of A                  52 slots  (no z: a contact step
 //                  applies c += L^-1 (sum_i jl_i d_i) instead -- 49 multiply-adds more per step, 21 slots less per contact)
-enum { R3_JL = 0, R3_Z = 7, R3_UT = 14, R3_R = 20, R3_B = 21, R3_AD = 22, R3_AI = 23, R3_F = 24, R3_N = 25,
-       R3_JB = R3_UT, R3_POS = R3_R, R3_INVW = R3_B,   // raw limit rows carry the base Jacobian, position and inverse weight there
+enum { R3_Z = 0, R3_UT = 7, R3_R = 13, R3_B = 14, R3_AD = 15, R3_F = 16, R3_KS = 17, R3_N = 18,
+       R3_POS = R3_R, R3_INVW = R3_B,   // a raw limit row carries its position and inverse weight there
        C3_JL = 0, C3_UT = 7, C3_B = 13, C3_F = 14, C3_ROW = 15, C3_R = 3 * C3_ROW, C3_BLK = C3_R + 1, C3_N = C3_BLK + 6,
        C3_JB = C3_UT, C3_POS = C3_B, C3_INVW = C3_F,   // raw contact rows likewise
        DYN0 = 0 };
 // scratch layout of the first two passes (dead before any row is written): per link h(3) J(6) F(3) T(3); per dof axis(3) anchor(3)
 enum { T3_LINK = 0, T3_DOF = 7 * 15, T3_END = 7 * 15 + 7 * 6 };
-static_assert(T3_END <= NSLOT3 && DYN0 + 2 * C3_N + 2 * R3_N <= NSLOT3 && DYN0 + 3 * C3_N <= NSLOT3, "slot budget");
+static_assert(T3_END <= NSLOT3 && DYN0 + 2 * C3_N + 3 * R3_N <= NSLOT3 && DYN0 + 3 * C3_N <= NSLOT3 && DYN0 + C3_N + 6 * R3_N <= NSLOT3, "slot budget");
 
 template <int I_> struct LI { static constexpr int value = I_; };
 template <int B_, int E_, class F> LEG_FN void lfor(F&& f) {
@@ -448,7 +449,7 @@ template <class B> struct Core3 {
         const I base = nlim * R3_N + DYN0;
         const M fits = base + R3_N <= NSLOT3;
         ovf = ovf | (act & !fits);
-        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_JL + Dd), Dd == Jj ? B::sel(dlo < 0.0, D(1.0), D(-1.0)) : D(0.0), act & fits); });
+        lds.stv(base + R3_KS, B::sel(dlo < 0.0, D(Jj + 1.0), D(-(Jj + 1.0))), act & fits);
         lds.stv(base + R3_POS, B::sel(dlo < 0.0, dlo, dhi), act & fits); lds.stv(base + R3_INVW, kc(K, LK3_DOF_INVW + Jj), act & fits);
       }
       nlim = nlim + B::toI(act);
@@ -632,12 +633,15 @@ template <class B> struct Core3 {
       RowW w;
       const I base = I(DYN0 + j * R3_N);
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; w.jb[Bc] = 0.0; });
-      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = B::sel(valid, lds.ldv(base + (R3_JL + Dd)), D(0.0)); });
+      {
+        const D ks = B::sel(valid, lds.ldv(base + R3_KS), D(0.0)), ak = B::fabs(ks);
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; w.jl[Dd] = B::sel(ak == D(Dd + 1.0), B::sel(ks > 0.0, D(1.0), D(-1.0)), D(0.0)); });
+      }
       finish(B::sel(valid, lds.ldv(base + R3_POS), D(0.0)), B::sel(valid, lds.ldv(base + R3_INVW), D(1.0)), kp_lim, false, D(0.0), w);
       const D f = B::sel(valid & (w.jar < 0.0), -(B::rcp(w.R) * w.jar), D(0.0));
       lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; lds.stv(base + (R3_Z + Dd), w.z[Dd], valid); });
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.stv(base + (R3_UT + Bc), w.ut[Bc], valid); });
-      lds.stv(base + R3_R, w.R, valid); lds.stv(base + R3_B, w.bv, valid); lds.stv(base + R3_AD, w.ad, valid); lds.stv(base + R3_AI, B::rcp(w.ad), valid);
+      lds.stv(base + R3_R, w.R, valid); lds.stv(base + R3_B, w.bv, valid); lds.stv(base + R3_AD, w.ad, valid);
       lds.stv(base + R3_F, f, valid);
       warm(w, f);
     }
@@ -700,11 +704,15 @@ template <class B> struct Core3 {
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(rb + (C3_UT + Bc)); });
       r.b = lds.ldv(rb + C3_B); r.f = lds.ldv(rb + C3_F);
     };
-    struct LRow { D jl[7], z[7], ut[6], R, b, f; };
+    struct LRow { D z[7], ut[6], R, b, f, jc; };   // jc = jl . c = s c_k
     auto lload = [&](I base, LRow& r) {
-      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.jl[Dd] = lds.ldv(base + (R3_JL + Dd)); r.z[Dd] = lds.ldv(base + (R3_Z + Dd)); });
+      lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.z[Dd] = lds.ldv(base + (R3_Z + Dd)); });
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(base + (R3_UT + Bc)); });
       r.R = lds.ldv(base + R3_R); r.b = lds.ldv(base + R3_B); r.f = lds.ldv(base + R3_F);
+      const D ks = lds.ldv(base + R3_KS), ak = B::fabs(ks);
+      D ck = c[0];
+      lfor<1, 6>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ck = B::sel(ak == D(Dd + 1.0), c[Dd], ck); });
+      r.jc = B::sel(ks > 0.0, ck, -ck);
     };
     {
       // cost of the warm start, 1/2 f'Af + f'b: kept only if negative
@@ -715,7 +723,7 @@ template <class B> struct Core3 {
         const M v = go & (nlim > j);
         if (!B::any(v)) break;
         LRow r; lload(I(DYN0 + j * R3_N), r);
-        cost += B::sel(v, r.f * (0.5 * (r.R * r.f + dot_c(r.jl) + dot_a(r.ut)) + r.b), D(0.0));
+        cost += B::sel(v, r.f * (0.5 * (r.R * r.f + r.jc + dot_a(r.ut)) + r.b), D(0.0));
       }
       for (int p = 0; p < 9; p++) {
         const M v = go & (ncon > p);
@@ -774,8 +782,8 @@ template <class B> struct Core3 {
         LEG3_STAT(1);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
         LRow r; lload(base, r);
-        const D ad = lds.ldv(base + R3_AD), ai = lds.ldv(base + R3_AI);
-        const D res = (B::fma(r.R, r.f, r.b) + dot_c(r.jl)) + dot_a(r.ut);
+        const D ad = lds.ldv(base + R3_AD), ai = B::rcp(ad);
+        const D res = (B::fma(r.R, r.f, r.b) + r.jc) + dot_a(r.ut);
         const D nf = B::fmax(B::fma(-res, ai, r.f), D(0.0));
         D d = nf - r.f;
         D chg = d * B::fma(0.5 * ad, d, res);
