@@ -820,34 +820,33 @@ template <class B> struct Core3 {
           const D bc1 = q1 - (A11 * o1 + A12 * o2) + A01 * (f0 - o0);
           const D bc2 = q2 - (A12 * o1 + A22 * o2) + A02 * (f0 - o0);
           const D b1 = bc1 * mu, b2 = bc2 * mu, Q11 = A11 * (mu * mu), Q22 = A22 * (mu * mu), Q12 = A12 * (mu * mu);
-          const D det0 = Q11 * Q22 - Q12 * Q12;
-          const D di0 = B::rcp(det0);
-          D v1 = -(Q22 * di0) * b1 + (Q12 * di0) * b2, v2 = (Q12 * di0) * b1 - (Q11 * di0) * b2;
-          D val = v1 * v1 + v2 * v2 - f0 * f0;
-          D la = 0.0;
-          M degenerate = det0 < 1e-10;
-          M run = mine & !degenerate & (val >= 1e-10) & (f0 >= MINVAL);   // sliding contact: Newton iterations on the multiplier
-          D P11 = Q22 * di0, P22 = Q11 * di0, P12 = -(Q12 * di0);
+          // Newton iterations on the multiplier la of |v| <= f0, v = -(Q + la)^-1 b, in mju_QCQP2's order (v, test the violation,
+          // step, test the step, update; 20 rounds at most, v is the one of the last round) but with everything multiplied through by
+          // det = |Q + la|: w = det v = -adj(Q + la) b, val det^2 = w.w - f0^2 det^2, step = -val / val' = (val det^2) det / (2 w'adj w):
+          // ONE reciprocal per round on a chain half as long.  Only la is carried per lane: a lane that has stopped keeps its la, so
+          // every later round recomputes ITS w and det unchanged and they are still right behind the loop.
+          D la = 0.0, w1 = 0.0, w2 = 0.0, det = 1.0;
+          M degenerate = mine & !mine;
+          M run = mine & (f0 >= MINVAL);
           for (int it = 0; it < 20; it++) {
             if (!B::any(run)) break;
             LEG3_STAT(3);
-            const D deriv = -2.0 * (P11 * v1 * v1 + 2.0 * P12 * v1 * v2 + P22 * v2 * v2);
-            const D delta = -val * B::rcp(deriv);
-            run = run & !(delta < 1e-10);
-            la = B::sel(run, la + delta, la);
-            if (it == 19) break;   // iteration budget of mju_QCQP2: the last multiplier is kept, v is not recomputed
-            const D det = (Q11 + la) * (Q22 + la) - Q12 * Q12;
+            const D qa = Q11 + la, qd = Q22 + la;
+            det = qa * qd - Q12 * Q12;
             const M sing = run & (det < 1e-10);
             degenerate = degenerate | sing;
             run = run & !sing;
-            const D di = B::rcp(det);
-            const D n11 = (Q22 + la) * di, n22 = (Q11 + la) * di, n12 = -(Q12 * di);
-            P11 = B::sel(run, n11, P11); P22 = B::sel(run, n22, P22); P12 = B::sel(run, n12, P12);
-            const D nv1 = -P11 * b1 - P12 * b2, nv2 = -P12 * b1 - P22 * b2;
-            v1 = B::sel(run, nv1, v1); v2 = B::sel(run, nv2, v2);
-            val = B::sel(run, v1 * v1 + v2 * v2 - f0 * f0, val);
-            run = run & !(val < 1e-10);
+            w1 = Q12 * b2 - qd * b1; w2 = Q12 * b1 - qa * b2;
+            const D det2 = det * det;
+            const D num = (w1 * w1 + w2 * w2) - (f0 * f0) * det2;
+            run = run & !(num < 1e-10 * det2);   // inside the cone (la = 0) or on it: done
+            const D den = 2.0 * (qd * w1 * w1 - 2.0 * Q12 * w1 * w2 + qa * w2 * w2);
+            const D delta = num * det * B::rcp(den);
+            run = run & !(delta < 1e-10);
+            la = B::sel(run, la + delta, la);
           }
+          const D di = B::rcp(det);
+          const D v1 = w1 * di, v2 = w2 * di;
           D g1 = B::sel(degenerate, D(0.0), v1 * mu), g2 = B::sel(degenerate, D(0.0), v2 * mu);
           {  // active constraint: put the friction exactly on the cone
             D s = (g1 * g1 + g2 * g2) * (1.0 / (MU * MU));
