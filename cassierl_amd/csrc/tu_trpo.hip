@@ -2,13 +2,25 @@
 //
 // One TRPO update evaluates, on the 524 288 samples one rank collects per iteration, the policy gradient and ~11 Fisher-vector
 // products of the 26-32-32-6 tanh policy.  As torch operations a product is ~8 skinny GEMMs (K = 32) and a dozen element-wise passes
-// over [N, 32] tensors: 0.7 ms each, 7.8 ms per update (r04 profile, tests/prof_trpo_update.py).  Here it is ONE launch: a lane owns
-// a sample, the weights (and the direction of the product) come through the scalar unit, the sample's activations are
-// recomputed in registers (obs is the only per-sample input read from HBM: 104 B), the directional derivative runs forward, the
-// cotangent runs back, and the outer products that make up the parameter gradient are accumulated per wavefront: the 64 samples of a
-// tile are staged in LDS and every lane adds them into the ~35 parameters it owns, in registers, over all the tiles of the launch.
-// Each wavefront writes one row of partial sums; the caller adds the rows (and all-reduces over ranks where it did before).
-// FP32 vector arithmetic on purpose: per sample 6.3 k multiply-adds with K = 26..32 -- far too small for MFMA tiles to pay.
+// over [N, 32] tensors: 0.67 ms each, 7.3 ms per update (r04 profile, tests/prof_trpo_update.py).  Here it is ONE launch on the
+// matrix cores, exact float32 (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain):
+//
+//   * a wavefront owns a tile of 32 samples; every activation-like quantity X (hidden units x samples, 32 x 32) lives in the
+//     accumulator layout -- the sample on the lane (column = lane & 31), the hidden unit in the 16 registers
+//     (row r(v, h) = (v & 3) + 8 (v >> 2) + 4 h, h = lane >> 5) -- so element-wise work (tanh, 1 - h^2, the precision) is register-wise;
+//   * a layer Y = W X takes X's registers AS ITS B OPERAND with no data movement: k-step v sums over row r(v, h), and the A operand
+//     of that step is W[i][r(v, h)] (lane i, half h), read from memory ONCE per wavefront in exactly that order and kept in registers
+//     for all tiles (W1, W2, W3, their directions, W2', W3': 110 registers);
+//   * the parameter gradients are products over the SAMPLE index (gW2 = G2 H1', ...): both operands are needed with the hidden unit on
+//     the lane, i.e. transposed -- one pass through a per-wavefront LDS tile (16 ds_write_b32 + 4 ds_read_b128 per matrix and lane);
+//     the observations are read from HBM in both forms (104 B per sample, twice);
+//   * the 6-wide output layer is padded to 32 rows (64 of the 174 MFMAs of a tile do 6 useful rows of 32): simpler and exact, and still
+//     ~80 us of matrix-core time per product against 670 us for the torch operations;
+//   * gradients are accumulated in three accumulator tiles per wavefront over all its tiles; bias gradients are row sums (b1 rides on
+//     a column of ones next to the observations).  Each wavefront writes one row of partial sums; the caller adds the rows (and
+//     all-reduces over ranks where it did before).
+// r04 history: a one-lane-per-sample FP32 vector version (weights through the scalar unit) was parity-green and SLOWER than torch
+// (0.80 ms against 0.67; weights in LDS 1.44 ms: the compiler hoists the weight reads and spills) -- replaced by this one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -18,34 +30,197 @@
 namespace cassie_trpo {
 
 constexpr int H = 32;         // hidden units (both layers)
-constexpr int STG = 36;       // floats per staged sample row: 16-byte aligned rows, bank = (36 lane + k) mod 64
-constexpr int WAVES = 2;      // wavefronts per workgroup
-constexpr int MAX_BLOCKS = 768;
+constexpr int TP = 36;        // floats per row of a transpose tile (16-byte aligned rows; ds_read_b128 of 16 lanes conflict-free)
+constexpr int WAVES = 4;      // wavefronts per workgroup: one per SIMD
+constexpr int MAX_BLOCKS = 256;
 
 template <int D, int A> struct Shape {
-  static constexpr int DP = (D + 3) / 4 * 4;   // obs row padded to float4s (zeros)
   static constexpr int NP = H * D + H + H * H + H + A * H + A;
   static constexpr int O_W1 = 0, O_B1 = H * D, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H, O_W3 = O_B2 + H, O_B3 = O_W3 + A * H;
 };
 
 struct Net { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define TRPO_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// tanh through the hardware exp2 / rcp: 1 - 2 / (e^2x + 1); absolute error ~1e-7 (the saturated ends are exact: e = inf or 0)
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ void wave_lds_sync() {   // a wavefront's LDS accesses complete in order; this keeps the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// FVP: w = S J dir (forward mode) per sample; otherwise w comes from memory.  Then J' w, accumulated per wavefront.
+template <int D, int A, bool FVP>
+__global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __restrict__ obs, int n, Net th, Net dir, const float* __restrict__ prec, float scale,
+                                                         const float* __restrict__ wext, float* __restrict__ partial) {
+  typedef Shape<D, A> S;
+  static_assert(D < 32 && A <= 8, "a column of ones next to the observations; the cotangent rows in registers 0..3 of the two lane halves");
+  constexpr int KS1 = (D + 1) / 2;   // k-steps of the first layer (k = 2 s + h)
+  __shared__ alignas(16) float tile[WAVES][2][32 * TP];
+  __shared__ alignas(16) float sbias[5][32];   // b1, b2, db1, db2, db3 (zero padded)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  if (tid < 32) {
+    sbias[0][tid] = th.b1[tid]; sbias[1][tid] = th.b2[tid];
+    sbias[2][tid] = FVP ? dir.b1[tid] : 0.0f; sbias[3][tid] = FVP ? dir.b2[tid] : 0.0f; sbias[4][tid] = (FVP && tid < A) ? dir.b3[tid] : 0.0f;
+  }
+  // ---- A operands, once per wavefront: lane (i = c, h) holds column k of row i for every k-step
+  float aW1[KS1], adW1[KS1], aW2[16], adW2[16], aW3[16], adW3[16], aW2T[16], aW3T[4], pr[4];
+#pragma unroll
+  for (int s = 0; s < KS1; s++) {
+    const int k = 2 * s + h;
+    aW1[s] = k < D ? th.W1[c * D + k] : 0.0f;
+    adW1[s] = (FVP && k < D) ? dir.W1[c * D + k] : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+    aW2[v] = th.W2[c * H + r]; aW2T[v] = th.W2[r * H + c];
+    adW2[v] = FVP ? dir.W2[c * H + r] : 0.0f;
+    aW3[v] = c < A ? th.W3[c * H + r] : 0.0f;
+    adW3[v] = (FVP && c < A) ? dir.W3[c * H + r] : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int a = v + 4 * h;
+    aW3T[v] = a < A ? th.W3[a * H + c] : 0.0f;
+    pr[v] = (FVP && a < A) ? prec[a] * scale : 0.0f;
+  }
+  __syncthreads();
+  auto bias_tile = [&](int which) {   // C operand: bias[r(v, h)] in register v (rows 8 g + 4 h .. + 3 are one float4)
+    v16f z;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 b = *reinterpret_cast<const float4*>(&sbias[which][8 * g + 4 * h]);
+      z[4 * g] = b.x; z[4 * g + 1] = b.y; z[4 * g + 2] = b.z; z[4 * g + 3] = b.w;
+    }
+    return z;
+  };
+  float* t0 = tile[wave][0];
+  float* t1 = tile[wave][1];
+  auto put = [&](float* t, const v16f& x) {   // accumulator layout -> [row][sample] image
+#pragma unroll
+    for (int v = 0; v < 16; v++) t[((v & 3) + 8 * (v >> 2) + 4 * h) * TP + c] = x[v];
+  };
+  auto get = [&](const float* t, float (&y)[16]) {   // lane (i = c, h): row i, samples 16 h .. 16 h + 15
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 b = *reinterpret_cast<const float4*>(&t[c * TP + 16 * h + 4 * q]);
+      y[4 * q] = b.x; y[4 * q + 1] = b.y; y[4 * q + 2] = b.z; y[4 * q + 3] = b.w;
+    }
+  };
+  v16f gW1, gW2, gW3;
+#pragma unroll
+  for (int v = 0; v < 16; v++) { gW1[v] = 0.0f; gW2[v] = 0.0f; gW3[v] = 0.0f; }
+  float gb2 = 0.0f, gb3 = 0.0f;
+  const int ntiles = (n + 31) / 32;
+  for (int tl = blockIdx.x * WAVES + wave; tl < ntiles; tl += gridDim.x * WAVES) {
+    const int s0 = tl * 32, smp = s0 + c;
+    const bool valid = smp < n;
+    // observations: as the B operand of the first layer (sample on the lane) and transposed (feature on the lane; column D = ones)
+    float xb[KS1], xt[16];
+#pragma unroll
+    for (int s = 0; s < KS1; s++) { const int k = 2 * s + h; xb[s] = (valid && k < D) ? obs[(size_t)smp * D + k] : 0.0f; }
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const int sm = s0 + 16 * h + s;
+      xt[s] = c < D ? (sm < n ? obs[(size_t)sm * D + c] : 0.0f) : (c == D ? 1.0f : 0.0f);
+    }
+    v16f h1 = bias_tile(0);
+#pragma unroll
+    for (int s = 0; s < KS1; s++) h1 = TRPO_MFMA(aW1[s], xb[s], h1);
+    v16f wt;   // cotangent on the mean, rows a = v + 4 h in registers v = 0 .. 3
+    v16f d1;
+    if (FVP) {
+      d1 = bias_tile(2);
+#pragma unroll
+      for (int s = 0; s < KS1; s++) d1 = TRPO_MFMA(adW1[s], xb[s], d1);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; v++) h1[v] = tanh_fast(h1[v]);
+    v16f h2 = bias_tile(1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h2 = TRPO_MFMA(aW2[v], h1[v], h2);
+    if (FVP) {
+      v16f d2 = bias_tile(3);
+#pragma unroll
+      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(adW2[v], h1[v], d2);
+#pragma unroll
+      for (int v = 0; v < 16; v++) d1[v] *= 1.0f - h1[v] * h1[v];
+#pragma unroll
+      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(aW2[v], d1[v], d2);
+#pragma unroll
+      for (int v = 0; v < 16; v++) h2[v] = tanh_fast(h2[v]);
+      v16f dm = bias_tile(4);
+#pragma unroll
+      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(adW3[v], h2[v], dm);
+#pragma unroll
+      for (int v = 0; v < 16; v++) d2[v] *= 1.0f - h2[v] * h2[v];
+#pragma unroll
+      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(aW3[v], d2[v], dm);
+#pragma unroll
+      for (int v = 0; v < 16; v++) wt[v] = (v < 4 && valid) ? dm[v] * pr[v] : 0.0f;
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; v++) h2[v] = tanh_fast(h2[v]);
+#pragma unroll
+      for (int v = 0; v < 16; v++) wt[v] = (v < 4 && valid && v + 4 * h < A) ? wext[(size_t)smp * A + v + 4 * h] : 0.0f;
+    }
+    // reverse mode: G2 = (W3' w) o (1 - H2^2), G1 = (W2' G2) o (1 - H1^2)
+    v16f g2, g1;
+#pragma unroll
+    for (int v = 0; v < 16; v++) { g2[v] = 0.0f; g1[v] = 0.0f; }
+#pragma unroll
+    for (int v = 0; v < 4; v++) g2 = TRPO_MFMA(aW3T[v], wt[v], g2);
+#pragma unroll
+    for (int v = 0; v < 16; v++) g2[v] *= 1.0f - h2[v] * h2[v];
+#pragma unroll
+    for (int v = 0; v < 16; v++) g1 = TRPO_MFMA(aW2T[v], g2[v], g1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) g1[v] *= 1.0f - h1[v] * h1[v];
+    // ---- parameter gradients: products over the sample index, operands transposed through the wavefront's LDS tiles
+    float ta[16], tb[16];
+    put(t0, g2); put(t1, h1);
+    wave_lds_sync();
+    get(t0, ta); get(t1, tb);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 16; s++) { gW2 = TRPO_MFMA(ta[s], tb[s], gW2); gb2 += ta[s]; }
+    put(t0, g1);
+    wave_lds_sync();
+    get(t0, ta);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 16; s++) gW1 = TRPO_MFMA(ta[s], xt[s], gW1);
+    put(t0, wt); put(t1, h2);
+    wave_lds_sync();
+    get(t0, ta); get(t1, tb);
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 16; s++) { gW3 = TRPO_MFMA(ta[s], tb[s], gW3); gb3 += ta[s]; }
+  }
+  // ---- one row of partial sums per wavefront: gW[r(v, h)][c] in register v
+  float* out = partial + (size_t)(blockIdx.x * WAVES + wave) * S::NP;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+    out[S::O_W2 + r * H + c] = gW2[v];
+    if (c < D) out[S::O_W1 + r * D + c] = gW1[v];
+    if (c == D) out[S::O_B1 + r] = gW1[v];
+    if (r < A) out[S::O_W3 + r * H + c] = gW3[v];
+  }
+  gb2 += __shfl_xor(gb2, 32, 64); gb3 += __shfl_xor(gb3, 32, 64);
+  if (h == 0) out[S::O_B2 + c] = gb2;
+  if (h == 0 && c < A) out[S::O_B3 + c] = gb3;
+}
+
 // The weights are the same for every lane: read through the CONSTANT address space at compile-time offsets they are scalar loads
-// (s_load through the scalar cache) and the multiply-adds take them as SGPR operands -- no LDS traffic, no vector registers for the
-// 2 x 2118 weights.  (r04 history, 524 288 samples, ms per product: weights in LDS read as broadcasts 1.44 -- the scheduler hoists the
-// ~800 reads of a product and spills ~1000 registers whatever barriers are put in --, this form 0.80, the torch operations it would
-// replace 0.67: not the default, see TRPO.fused_fisher.)
+// (s_load through the scalar cache) and the multiply-adds take them as SGPR operands -- no LDS traffic, no vector registers.
 typedef const __attribute__((address_space(4))) float* cptr;
 struct CNet { cptr W1, b1, W2, b2, W3, b3; };
-// the same pointer, wave-uniform, but opaque to the optimiser: otherwise all 4236 loads are hoisted out of the tile loop and kept in
-// VGPR lanes (a v_readlane per use)
-__device__ __forceinline__ cptr reissue(const float* p) {
-  uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);
-  asm volatile("" : "+v"(lo), "+v"(hi));
-  lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
-  return (cptr)(((uintptr_t)hi << 32) | lo);
-}
-__device__ __forceinline__ CNet reissue(const Net& n) { return CNet{reissue(n.W1), reissue(n.b1), reissue(n.W2), reissue(n.b2), reissue(n.W3), reissue(n.b3)}; }
 // y[j] = bias[j] + sum_i W[j * LD + i] x[i]
 template <int NO, int NI, int LD> __device__ __forceinline__ void matvec(cptr W, cptr bias, const float (&x)[NI], float (&y)[NO]) {
 #pragma unroll
@@ -56,147 +231,9 @@ template <int NO, int NI, int LD> __device__ __forceinline__ void matvec(cptr W,
     y[j] = a;
   }
 }
-// y[i] = sum_j W[j * LD + i] g[j]   (transposed product)
-template <int NJ, int NI, int LD> __device__ __forceinline__ void matvec_t(cptr W, const float (&g)[NJ], float (&y)[NI]) {
-#pragma unroll
-  for (int i = 0; i < NI; i++) y[i] = 0.0f;
-#pragma unroll
-  for (int j = 0; j < NJ; j++) {
-#pragma unroll
-    for (int i = 0; i < NI; i++) y[i] = __builtin_fmaf(W[j * LD + i], g[j], y[i]);
-  }
-}
 template <int N> __device__ __forceinline__ void tanh_all(float (&h)[N]) {
 #pragma unroll
   for (int j = 0; j < N; j++) h[j] = tanhf(h[j]);
-}
-
-// one sample's vector into its staging row (float4 stores, zero padded)
-template <int N> __device__ __forceinline__ void stage_row(float* row, const float (&v)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; i += 4)
-    *reinterpret_cast<float4*>(row + i) = make_float4(v[i], i + 1 < N ? v[i + 1 < N ? i + 1 : 0] : 0.0f, i + 2 < N ? v[i + 2 < N ? i + 2 : 0] : 0.0f, i + 3 < N ? v[i + 3 < N ? i + 3 : 0] : 0.0f);
-}
-
-// FVP: w = S J dir (forward mode) per sample; otherwise w comes from memory.  Then J' w, accumulated per wavefront.
-template <int D, int A, bool FVP>
-__global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __restrict__ obs, int n, Net th, Net dir, const float* __restrict__ prec, float scale,
-                                                         const float* __restrict__ wext, float* __restrict__ partial) {
-  typedef Shape<D, A> S;
-  constexpr int DP = S::DP;
-  constexpr int A3 = (A + 1) / 2;   // rows of W3 a lane accumulates
-  __shared__ alignas(16) float bufA[WAVES][64][STG];
-  __shared__ alignas(16) float bufB[WAVES][64][STG];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float pr[A];
-#pragma unroll
-  for (int a = 0; a < A; a++) pr[a] = FVP ? prec[a] * scale : 0.0f;
-  // the parameters this lane accumulates: W2[j2][c2 .. c2 + 15], W1[j2][c1 .. c1 + DP/2 - 1], W3[r3 .. r3 + A3 - 1][i3], one bias each
-  const int j2 = lane >> 1, c2 = (lane & 1) * 16, c1 = (lane & 1) * (DP / 2), i3 = lane & 31, r3 = (lane >> 5) * A3;
-  float acc2[16], acc1[DP / 2], acc3[A3], accb12 = 0.0f, accb3 = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 16; i++) acc2[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < DP / 2; i++) acc1[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < A3; i++) acc3[i] = 0.0f;
-  float (*sa)[STG] = bufA[wave];
-  float (*sb)[STG] = bufB[wave];
-  const int ntiles = (n + 63) / 64;
-  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
-    const CNet W = reissue(th), V = FVP ? reissue(dir) : W;
-    const int s = tile * 64 + lane;
-    const bool valid = s < n;
-    float x[DP];
-#pragma unroll
-    for (int i = 0; i < DP; i++) x[i] = (valid && i < D) ? obs[(size_t)s * D + i] : 0.0f;
-    float xin[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) xin[i] = x[i];
-
-    float h1[H], h2[H], w[A], g2[H], g1[H];
-    matvec<H, D, D>(W.W1, W.b1, xin, h1);
-    tanh_all(h1);
-    matvec<H, H, H>(W.W2, W.b2, h1, h2);
-    tanh_all(h2);
-    if (FVP) {
-      float dh1[H], dh2[H], t[H], dmu[A], t3[A];
-      matvec<H, D, D>(V.W1, V.b1, xin, dh1);
-#pragma unroll
-      for (int j = 0; j < H; j++) dh1[j] *= 1.0f - h1[j] * h1[j];
-      matvec<H, H, H>(W.W2, (cptr)nullptr, dh1, dh2);
-      matvec<H, H, H>(V.W2, V.b2, h1, t);
-#pragma unroll
-      for (int j = 0; j < H; j++) dh2[j] = (dh2[j] + t[j]) * (1.0f - h2[j] * h2[j]);
-      matvec<A, H, H>(W.W3, (cptr)nullptr, dh2, dmu);
-      matvec<A, H, H>(V.W3, V.b3, h2, t3);
-#pragma unroll
-      for (int a = 0; a < A; a++) w[a] = valid ? (dmu[a] + t3[a]) * pr[a] : 0.0f;
-    } else {
-#pragma unroll
-      for (int a = 0; a < A; a++) w[a] = valid ? wext[(size_t)s * A + a] : 0.0f;
-    }
-    // reverse mode: g2 = (W3' w) o (1 - h2^2), g1 = (W2' g2) o (1 - h1^2)
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-      float a = 0.0f;
-#pragma unroll
-      for (int r = 0; r < A; r++) a = __builtin_fmaf(W.W3[r * H + i], w[r], a);
-      g2[i] = a * (1.0f - h2[i] * h2[i]);
-    }
-    matvec_t<H, H, H>(W.W2, g2, g1);
-#pragma unroll
-    for (int i = 0; i < H; i++) g1[i] *= 1.0f - h1[i] * h1[i];
-    // ---- outer products, 64 samples at a time: stage (cotangent, activation) rows, every lane adds into the parameters it owns
-    // (a wavefront's LDS accesses complete in order; the fences keep the compiler from moving them across the phases)
-    stage_row<H>(sa[lane], g2); stage_row<H>(sb[lane], h1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-    for (int k = 0; k < 64; k++) {
-      const float g = sa[k][j2];
-#pragma unroll
-      for (int i = 0; i < 16; i += 4) {
-        const float4 h = *reinterpret_cast<const float4*>(&sb[k][c2 + i]);
-        acc2[i] = __builtin_fmaf(g, h.x, acc2[i]); acc2[i + 1] = __builtin_fmaf(g, h.y, acc2[i + 1]);
-        acc2[i + 2] = __builtin_fmaf(g, h.z, acc2[i + 2]); acc2[i + 3] = __builtin_fmaf(g, h.w, acc2[i + 3]);
-      }
-      if (lane < 32) accb12 += sa[k][lane];   // b2
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stage_row<H>(sa[lane], g1); stage_row<DP>(sb[lane], x);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-    for (int k = 0; k < 64; k++) {
-      const float g = sa[k][j2];
-#pragma unroll
-      for (int i = 0; i < DP / 2; i += 2) {
-        const float2 xv = *reinterpret_cast<const float2*>(&sb[k][c1 + i]);
-        acc1[i] = __builtin_fmaf(g, xv.x, acc1[i]); acc1[i + 1] = __builtin_fmaf(g, xv.y, acc1[i + 1]);
-      }
-      if (lane >= 32) accb12 += sa[k][lane - 32];   // b1
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    stage_row<A>(sa[lane], w); stage_row<H>(sb[lane], h2);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-    for (int k = 0; k < 64; k++) {
-      const float h = sb[k][i3];
-#pragma unroll
-      for (int r = 0; r < A3; r++) acc3[r] = __builtin_fmaf(r3 + r < A ? sa[k][r3 + r] : 0.0f, h, acc3[r]);
-      if (lane < A) accb3 += sa[k][lane];   // b3
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  // ---- one row of partial sums per wavefront
-  float* out = partial + (size_t)(blockIdx.x * WAVES + wave) * S::NP;
-#pragma unroll
-  for (int i = 0; i < 16; i++) out[S::O_W2 + j2 * H + c2 + i] = acc2[i];
-#pragma unroll
-  for (int i = 0; i < DP / 2; i++) if (c1 + i < D) out[S::O_W1 + j2 * D + c1 + i] = acc1[i];
-#pragma unroll
-  for (int r = 0; r < A3; r++) if (r3 + r < A) out[S::O_W3 + (r3 + r) * H + i3] = acc3[r];
-  if (lane < 32) out[S::O_B2 + lane] = accb12; else out[S::O_B1 + lane - 32] = accb12;
-  if (lane < A) out[S::O_B3 + lane] = accb3;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- policy step
@@ -230,7 +267,7 @@ __global__ void __launch_bounds__(256) policy_step_kernel(const double* __restri
 }
 
 inline int blocks_for(int n) {
-  const int tiles = (n + 63) / 64;
+  const int tiles = (n + 31) / 32;
   int b = (tiles + WAVES - 1) / WAVES;
   return b < 1 ? 1 : (b > MAX_BLOCKS ? MAX_BLOCKS : b);
 }
