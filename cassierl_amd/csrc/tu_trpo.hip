@@ -217,6 +217,89 @@ __global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __rest
   if (h == 0 && c < A) out[S::O_B3 + c] = gb3;
 }
 
+// Line search of the TRPO step (rllab's f_loss / f_constraint on the sampled batch): surrogate loss terms -exp(ll_new - ll_old) adv and
+// KL(old || new) per sample (GaussianMLPPolicy.log_likelihood / .kl of trpo.py), summed per wavefront in float64.  The forward pass is
+// the one of trpo_kernel (same tiles, same operands); the mean comes out with action a = v + 4 h in register v < 4 of lane (sample, h).
+template <int D, int A>
+__global__ void __launch_bounds__(64 * WAVES, 1) surrogate_kernel(const float* __restrict__ obs, int n, Net th, const float* __restrict__ ls_new,
+                                                              const float* __restrict__ ls_old, const float* __restrict__ act, const float* __restrict__ adv,
+                                                              const float* __restrict__ old_mean, double* __restrict__ partial) {
+  constexpr int KS1 = (D + 1) / 2;
+  __shared__ alignas(16) float sbias[3][32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  if (tid < 32) { sbias[0][tid] = th.b1[tid]; sbias[1][tid] = th.b2[tid]; sbias[2][tid] = tid < A ? th.b3[tid] : 0.0f; }
+  float aW1[KS1], aW2[16], aW3[16], isn[4], iso[4], dls[4], kden[4], kvar[4];
+#pragma unroll
+  for (int s = 0; s < KS1; s++) { const int k = 2 * s + h; aW1[s] = k < D ? th.W1[c * D + k] : 0.0f; }
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+    aW2[v] = th.W2[c * H + r];
+    aW3[v] = c < A ? th.W3[c * H + r] : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int a = v + 4 * h;
+    const float ln = a < A ? ls_new[a] : 0.0f, lo = a < A ? ls_old[a] : 0.0f;
+    const float sn = expf(ln), so = expf(lo);
+    isn[v] = 1.0f / sn; iso[v] = 1.0f / so; dls[v] = ln - lo;
+    kden[v] = 1.0f / (2.0f * sn * sn + 1e-8f); kvar[v] = so * so - sn * sn;
+  }
+  __syncthreads();
+  auto bias_tile = [&](int which) {
+    v16f z;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 b = *reinterpret_cast<const float4*>(&sbias[which][8 * g + 4 * h]);
+      z[4 * g] = b.x; z[4 * g + 1] = b.y; z[4 * g + 2] = b.z; z[4 * g + 3] = b.w;
+    }
+    return z;
+  };
+  double accL = 0.0, accK = 0.0;
+  const int ntiles = (n + 31) / 32;
+  for (int tl = blockIdx.x * WAVES + wave; tl < ntiles; tl += gridDim.x * WAVES) {
+    const int smp = tl * 32 + c;
+    const bool valid = smp < n;
+    float xb[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; s++) { const int k = 2 * s + h; xb[s] = (valid && k < D) ? obs[(size_t)smp * D + k] : 0.0f; }
+    float ac[4], om[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const bool on = valid && v + 4 * h < A;
+      ac[v] = on ? act[(size_t)smp * A + v + 4 * h] : 0.0f; om[v] = on ? old_mean[(size_t)smp * A + v + 4 * h] : 0.0f;
+    }
+    const float ad = valid ? adv[smp] : 0.0f;
+    v16f h1 = bias_tile(0);
+#pragma unroll
+    for (int s = 0; s < KS1; s++) h1 = TRPO_MFMA(aW1[s], xb[s], h1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h1[v] = tanh_fast(h1[v]);
+    v16f h2 = bias_tile(1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h2 = TRPO_MFMA(aW2[v], h1[v], h2);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h2[v] = tanh_fast(h2[v]);
+    v16f mu = bias_tile(2);
+#pragma unroll
+    for (int v = 0; v < 16; v++) mu = TRPO_MFMA(aW3[v], h2[v], mu);
+    float ll = 0.0f, kl = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      if (v + 4 * h < A) {
+        const float zn = (ac[v] - mu[v]) * isn[v], zo = (ac[v] - om[v]) * iso[v], dm = om[v] - mu[v];
+        ll += 0.5f * (zo * zo - zn * zn) - dls[v];
+        kl += (dm * dm + kvar[v]) * kden[v] + dls[v];
+      }
+    }
+    ll += __shfl_xor(ll, 32, 64); kl += __shfl_xor(kl, 32, 64);
+    if (h == 0 && valid) { accL -= (double)(expf(ll) * ad); accK += (double)kl; }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { accL += __shfl_xor(accL, m, 64); accK += __shfl_xor(accK, m, 64); }
+  if (lane == 0) { double* out = partial + (size_t)(blockIdx.x * WAVES + wave) * 2; out[0] = accL; out[1] = accK; }
+}
+
 // The weights are the same for every lane: read through the CONSTANT address space at compile-time offsets they are scalar loads
 // (s_load through the scalar cache) and the multiply-adds take them as SGPR operands -- no LDS traffic, no vector registers.
 typedef const __attribute__((address_space(4))) float* cptr;
@@ -307,6 +390,23 @@ int CassieTrpoVjp(const float* obs_dev, int n, int obs_dim, int act_dim, const f
   if (!W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !w_dev) return CASSIE_EINVAL;
   const cassie_trpo::Net th{W1, b1, W2, b2, W3, b3};
   return cassie_trpo::launch<false>(obs_dev, n, obs_dim, act_dim, th, th, nullptr, 0.0f, w_dev, partial_dev, (hipStream_t)stream);
+}
+
+int CassieTrpoSurrogate(const float* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, const float* log_std_new, const float* log_std_old, const float* act_dev,
+                        const float* adv_dev, const float* old_mean_dev, double* partial_dev, void* stream) {
+  if (!obs_dev || n <= 0 || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !log_std_new || !log_std_old || !act_dev || !adv_dev || !old_mean_dev || !partial_dev)
+    return CASSIE_EINVAL;
+  const cassie_trpo::Net th{W1, b1, W2, b2, W3, b3};
+  const dim3 grid(cassie_trpo::blocks_for(n)), block(64 * cassie_trpo::WAVES);
+  hipStream_t s = (hipStream_t)stream;
+  using namespace cassie_trpo;
+  if (obs_dim == 26 && act_dim == 6) hipLaunchKernelGGL((surrogate_kernel<26, 6>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
+  else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((surrogate_kernel<26, 7>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
+  else if (obs_dim == 17 && act_dim == 6) hipLaunchKernelGGL((surrogate_kernel<17, 6>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
+  else if (obs_dim == 17 && act_dim == 7) hipLaunchKernelGGL((surrogate_kernel<17, 7>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
+  else return CASSIE_EINVAL;
+  return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
 
 int CassieTrpoPolicyStep(const double* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2,

@@ -338,6 +338,24 @@ class FusedFisher:
             raise RuntimeError("CassieTrpoVjp failed (%d)" % rc)
         return self._assemble(self.partial.sum(0), torch.zeros_like(self.theta["log_std"]))
 
+    @torch.no_grad()
+    def surrogate(self, policy, act, adv, old_mean, old_log_std):
+        """(surrogate loss, mean KL) of `policy` AS IT IS NOW against the old Gaussian on this batch, in one launch (CassieTrpoSurrogate):
+        the line search's evaluation.  old_log_std: the [act_dim] vector of the state-independent old log-std.  Two float64 scalars on the device."""
+        live = dict(policy.named_parameters())
+        if not hasattr(self, "_sur"):
+            self._sur = torch.empty((self.rows, 2), dtype=torch.float64, device=self.obs.device)
+        P = lambda t: self.ct.c_void_p(t.data_ptr())
+        act, adv, old_mean = act.contiguous(), adv.to(torch.float32).contiguous(), old_mean.contiguous()
+        old_ls = old_log_std.to(torch.float32).contiguous()
+        stream = self.ct.c_void_p(torch.cuda.current_stream(self.obs.device).cuda_stream)
+        rc = self.L.CassieTrpoSurrogate(P(self.obs), self.n, self.D, self.A, *[P(live[k].detach()) for k in self.order], P(live["log_std"].detach()), P(old_ls),
+                                        P(act), P(adv), P(old_mean), P(self._sur), stream)
+        if rc != 0:
+            raise RuntimeError("CassieTrpoSurrogate failed (%d)" % rc)
+        s = self._sur.sum(0) / self.n
+        return s[0], s[1]
+
 
 # --------------------------------------------------------------------------------------------- TRPO
 class TRPO:
@@ -488,9 +506,12 @@ class TRPO:
     def optimize(self, d):
         pol = self.policy
         obs, act, adv, old_mean, old_lstd = d["obs"], d["act"], d["adv"], d["mean"], d["log_std"]
-        old_ll = pol.log_likelihood(act, old_mean, old_lstd)
+        old_ll = None
 
         def surrogate():
+            nonlocal old_ll
+            if old_ll is None:
+                old_ll = pol.log_likelihood(act, old_mean, old_lstd)
             mean, log_std = pol.dist_info(obs)
             lr = (pol.log_likelihood(act, mean, log_std) - old_ll).exp()
             return -(lr * adv).mean(), pol.kl(old_mean, old_lstd, mean, log_std).mean()
@@ -537,6 +558,9 @@ class TRPO:
 
         descent = conjugate_gradient(Fvp, g, self.cg_iters)
         shs = 0.5 * (descent @ Fvp(descent))
+        if isinstance(fisher, FusedFisher):   # the line search evaluates loss and KL in one launch each (CassieTrpoSurrogate)
+            ff, old_ls_vec = fisher, old_lstd[0].detach().clone()
+            surrogate = lambda: ff.surrogate(pol, act, adv, old_mean, old_ls_vec)
         del gk, kl0, fisher
         step = torch.sqrt(self.step_size / (shs + 1e-8)) * descent
         if not torch.isfinite(step).all():
@@ -547,7 +571,7 @@ class TRPO:
             set_flat_params(pol, theta - (self.backtrack_ratio ** k) * step)
             with torch.no_grad():
                 l_new, kl_new = surrogate()
-            l_new = float(all_mean_(l_new.view(1).clone())); kl_new = float(all_mean_(kl_new.view(1).clone()))
+            l_new, kl_new = all_mean_(torch.stack([l_new.detach().double().reshape(()), kl_new.detach().double().reshape(())])).tolist()   # one read-back
             if math.isfinite(l_new) and l_new < loss_before and kl_new <= self.step_size:
                 return dict(loss_before=loss_before, loss_after=l_new, kl=kl_new, backtracks=k)
         set_flat_params(pol, theta)  # line search failed: keep the old policy

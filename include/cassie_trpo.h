@@ -35,6 +35,15 @@ int CassieTrpoFvp(const float* obs_dev, int n, int obs_dim, int act_dim, const f
 int CassieTrpoVjp(const float* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2, const float* b2,
                   const float* W3, const float* b3, const float* w_dev, float* partial_dev, void* stream);
 
+/* Line search of the TRPO step on the sampled batch (what rllab's f_loss / f_constraint evaluate per backtrack): for the mean network
+ * AT THE GIVEN WEIGHTS and log-std log_std_new [act_dim], against the old Gaussian (old_mean [n][act_dim], log_std_old [act_dim]):
+ *   partial[row][0] = sum_s -exp(ll_new(act_s) - ll_old(act_s)) adv_s,   partial[row][1] = sum_s KL(old_s || new_s)
+ * (GaussianMLPPolicy.log_likelihood / .kl of cassierl_amd/trpo.py), float64, one row per wavefront (CassieTrpoPartialRows); the
+ * caller adds the rows and divides by the job's n. */
+int CassieTrpoSurrogate(const float* obs_dev, int n, int obs_dim, int act_dim, const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, const float* log_std_new, const float* log_std_old, const float* act_dev,
+                        const float* adv_dev, const float* old_mean_dev, double* partial_dev, void* stream);
+
 /* One policy step of the sampler for n environments in ONE launch (the counterpart of GaussianMLPPolicy.get_actions + rllab's
  * normalize() wrapper, rllab/envs/trpo_cassie.py:13,21-27): obs float64 [n][obs_dim] as the environment wrote it ->
  *   obs32 [n][obs_dim] (the policy's float32 view, kept for the update), mean [n][act_dim] = mean network, act [n][act_dim] = mean +

@@ -9,7 +9,7 @@ from conftest import ROOT
 
 def declared_symbols():
     names = []
-    for hdr in ("cassie2d.h", "cassie_vec.h", "cassie3d_vec.h"):
+    for hdr in ("cassie2d.h", "cassie_vec.h", "cassie3d_vec.h", "cassie_trpo.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", txt, flags=re.M):

@@ -84,3 +84,32 @@ def test_fused_policy_step_matches_the_torch_operations(control_mode, adim):
     assert (algo._env_actions - e_ref).abs().max().item() < 1e-12
     lo, hi = torch.as_tensor(box.low, device="cuda"), torch.as_tensor(box.high, device="cuda")
     assert (algo._env_actions >= lo).all() and (algo._env_actions <= hi).all()
+
+
+@pytest.mark.parametrize("n,obs_dim,act_dim", [(1000, 26, 6), (65536, 26, 6), (4099, 26, 7), (777, 17, 6)])
+def test_fused_surrogate_matches_the_torch_line_search_evaluation(n, obs_dim, act_dim):
+    """CassieTrpoSurrogate (loss and mean KL of the line search in one launch) against the torch expressions of TRPO.optimize on a
+    perturbed policy."""
+    import torch
+    from cassierl_amd import trpo as T
+    torch.manual_seed(5)
+    pol = T.GaussianMLPPolicy(obs_dim, act_dim, (32, 32), init_std=1.3).cuda()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    obs = torch.randn(n, obs_dim, device="cuda") * 0.7
+    with torch.no_grad():
+        old_mean, old_lstd = pol.dist_info(obs)
+        old_mean, old_lstd = old_mean.clone(), old_lstd.clone()
+        act = old_mean + torch.randn_like(old_mean) * old_lstd.exp()
+        adv = torch.randn(n, device="cuda")
+        fused = T.FusedFisher(pol, obs)
+        for p in pol.parameters():   # the candidate of a backtrack
+            p.add_(0.02 * torch.randn_like(p))
+        mean, log_std = pol.dist_info(obs)
+        lr = (pol.log_likelihood(act, mean, log_std) - pol.log_likelihood(act, old_mean, old_lstd)).exp()
+        l_ref, k_ref = -(lr.double() * adv.double()).mean().item(), pol.kl(old_mean, old_lstd, mean, log_std).double().mean().item()
+        l, k = fused.surrogate(pol, act, adv, old_mean, old_lstd[0])
+    scale = (lr.double() * adv.double()).abs().mean().item()
+    assert abs(l.item() - l_ref) < 2e-5 * scale, (l.item(), l_ref)
+    assert abs(k.item() - k_ref) < 2e-5 * max(k_ref, 1e-3), (k.item(), k_ref)
