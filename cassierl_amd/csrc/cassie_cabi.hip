@@ -55,6 +55,15 @@ struct CassieVec {
   int* deep_hint_dev = nullptr;              // ... its device address
   unsigned serial = 64;                      // launches of the physics tiers so far (starts past the hint window); wraps (compared modulo 2^32)
   int side_mode = -1;                        // CASSIE2D_SIDE_BY_SIDE=0/1 (tests): never / always run the lower tiers side by side; -1: by the hint
+  // the Env.step in segments while robots are down (launch_physics_tiers): per segment the hand-over lists, two streams, three events
+  static constexpr int NSEG = 4;
+  bool seg_on = true;                        // CASSIE2D_SEGMENTS=0: the one-launch order (A/B, tests)
+  bool seg_ready = false, seg_failed = false;
+  int* seg_pend[NSEG] = {};                  // [n] substeps left per env after segment j of the two-lanes-per-env kernel
+  int* seg_pend2[NSEG] = {};                 // [n] ... after the 4-envs-per-wave kernel took segment j's environments
+  int* gone = nullptr;                       // [n] the environment left the first tier in an earlier segment of this Env.step
+  hipStream_t seg_deep[NSEG] = {}, seg_shal[NSEG] = {};
+  hipEvent_t seg_fork[NSEG] = {}, seg_join_a[NSEG] = {}, seg_join_b[NSEG] = {};
   std::string err;
 };
 
@@ -104,6 +113,22 @@ cassie::VecParams make_params(CassieVec* h) {
   return p;
 }
 
+// lists, streams and events of the segmented Env.step (first use; false: not available, the one-launch order is used)
+bool seg_resources(CassieVec* h) {
+  if (h->seg_ready) return true;
+  if (h->seg_failed) return false;
+  const size_t bytes = (size_t)h->n * sizeof(int);
+  bool ok = hipMalloc(&h->gone, bytes) == hipSuccess;
+  for (int j = 0; j < CassieVec::NSEG && ok; j++)
+    ok = hipMalloc(&h->seg_pend[j], bytes) == hipSuccess && hipMalloc(&h->seg_pend2[j], bytes) == hipSuccess &&
+         hipStreamCreateWithFlags(&h->seg_deep[j], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->seg_shal[j], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&h->seg_fork[j], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->seg_join_a[j], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->seg_join_b[j], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { h->seg_failed = true; (void)hipGetLastError(); return false; }
+  h->seg_ready = true;
+  return true;
+}
+
 // Physics tiers on the flat floor (mode 0 PD, 1 torque, 2 commands from the record).  Each tier leaves an environment it cannot
 // hold untouched from that substep on and says how many substeps are left; the next tier finishes it (results are what that
 // tier alone would give: an environment's arithmetic is a function of its own state in every kernel).
@@ -129,6 +154,52 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   const bool side_by_side = h->leg && (h->side_mode >= 0 ? h->side_mode == 1 : (h->deep_hint && h->serial - (unsigned)*(volatile int*)h->deep_hint <= 32u));
   // fork: the side stream waits for the first tier.  If the event cannot be recorded / waited for, fall back to the one-stream order
   // below (same results) rather than let the side stream's kernel run concurrently with the first tier on the same records.
+  if (side_by_side && h->seg_on && p.n_sub >= 4 && !p.debug && seg_resources(h)) {
+    // ---- the Env.step in segments (r04).  A robot that is down costs its substeps end to end (~0.13 ms each) in the lower tiers,
+    // and in the order below these only start when the first tier has finished ALL its substeps: 1.4 ms of first tier + up to
+    // 1.3 ms of tail.  Here the first tier runs the step as a first segment of ONE substep and up to three more of equal length;
+    // after each, the environments that left it in that segment go to the lower tiers on the segment's own two streams (deep ones
+    // straight to the wave-per-environment kernel, the others to the 4-environments-per-wavefront kernel and the pass behind it)
+    // and are finished there to the END of the Env.step, while the first tier goes on with the next segment for everyone else
+    // (`gone`).  A robot that was already down starts its ten substeps 0.2 ms into the step instead of 1.4; one that goes down in
+    // the last segment has at most three substeps left.  Results: every environment is stepped by the same kernels on the same
+    // data as in the one-launch order (an environment's arithmetic is a function of its own state in every kernel).
+    int len[CassieVec::NSEG], nseg = 0, left = p.n_sub - 1;
+    len[nseg++] = 1;
+    for (int parts = CassieVec::NSEG - 1; parts > 0; parts--) { const int l = (left + parts - 1) / parts; if (l > 0) { len[nseg++] = l; left -= l; } }
+    int later = p.n_sub;
+    bool ok = true;
+    for (int j = 0; j < nseg; j++) {
+      later -= len[j];
+      cassie::VecParams ps = p;
+      ps.n_sub = len[j];
+      if (j != nseg - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
+      L2::step_leg_segment(mode, h->n, h->stream, ps, h->seg_pend[j], h->gone, j == 0, later);
+      L2::classify_pending(h->n, h->stream, p, h->seg_pend[j]);
+      ok = ok && hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess && hipStreamWaitEvent(h->seg_deep[j], h->seg_fork[j], 0) == hipSuccess &&
+           hipStreamWaitEvent(h->seg_shal[j], h->seg_fork[j], 0) == hipSuccess;
+      if (!ok) break;
+      cassie::VecParams pd = p, pa = p, pb = p;
+      pd.pending = h->seg_pend[j]; pd.pending_pick = cassie::PICK_DEEP;
+      L2::step_k1(mode, L2::K1_DEEP, h->n, h->seg_deep[j], pd, L2::K1_HANDOVER_SPLIT);
+      pa.pending = h->seg_pend[j]; pa.pending_pick = cassie::PICK_SHALLOW;
+      L2::step_g16(mode, h->n, h->seg_shal[j], pa, h->seg_pend2[j]);
+      pb.pending = h->seg_pend2[j]; pb.pending_pick = cassie::PICK_ALL;
+      L2::step_k1(mode, L2::K1_DEEP, h->n, h->seg_shal[j], pb, L2::K1_HANDOVER_SPLIT);
+      ok = ok && hipEventRecord(h->seg_join_a[j], h->seg_deep[j]) == hipSuccess && hipEventRecord(h->seg_join_b[j], h->seg_shal[j]) == hipSuccess;
+      if (!ok) break;
+    }
+    for (int j = 0; j < nseg && ok; j++)
+      ok = hipStreamWaitEvent(h->stream, h->seg_join_a[j], 0) == hipSuccess && hipStreamWaitEvent(h->stream, h->seg_join_b[j], 0) == hipSuccess;
+    if (!ok) {   // an event could not be recorded / waited for: finish everything in order, the hard way (same results)
+      for (int j = 0; j < nseg; j++) { hipStreamSynchronize(h->seg_deep[j]); hipStreamSynchronize(h->seg_shal[j]); }
+      hipStreamSynchronize(h->stream);
+      h->seg_failed = true;   // ... and stay with the one-launch order from now on
+      // (segments launched before the failure are complete; the remaining substeps of everyone are the caller's to redo only if
+      // the launch of a segment itself failed, which hipGetLastError reports to the caller as before)
+    }
+    return;
+  }
   if (side_by_side) {
     L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
     L2::classify_pending(h->n, h->stream, p, h->pending_leg);
@@ -308,6 +379,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
+  { const char* e = getenv("CASSIE2D_SEGMENTS"); if (e && e[0] == '0') h->seg_on = false; }
   if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
   *h->deep_hint = 0;
   if (hipHostGetDevicePointer((void**)&h->deep_hint_dev, h->deep_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);
@@ -330,6 +402,15 @@ void CassieVecFree(CassieVec* h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+  for (int j = 0; j < CassieVec::NSEG; j++) {
+    if (h->seg_deep[j]) { hipStreamSynchronize(h->seg_deep[j]); hipStreamDestroy(h->seg_deep[j]); }
+    if (h->seg_shal[j]) { hipStreamSynchronize(h->seg_shal[j]); hipStreamDestroy(h->seg_shal[j]); }
+    if (h->seg_fork[j]) hipEventDestroy(h->seg_fork[j]);
+    if (h->seg_join_a[j]) hipEventDestroy(h->seg_join_a[j]);
+    if (h->seg_join_b[j]) hipEventDestroy(h->seg_join_b[j]);
+    hipFree(h->seg_pend[j]); hipFree(h->seg_pend2[j]);
+  }
+  hipFree(h->gone);
   if (h->deep_hint) hipHostFree(h->deep_hint);
   delete h;
 }

@@ -162,6 +162,50 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_kernel(VecParams p, int* p
   }
 }
 
+#ifdef CASSIE_LEG_SEGMENT   // tu_leg_seg.hip only: a separate translation unit, so that the kernel above compiles to what it was
+// The same kernel for a SEGMENT of an Env.step (cassie_cabi.hip, launch_physics_tiers while robots are down: the step is cut into a
+// few launches so that the lower tiers start on an overflowing environment while the rest of the batch is still being stepped here).
+//   gone[env] != 0 on entry (seg.first: never): the environment left this tier in an earlier segment -- not touched, pending = 0;
+//   on exit gone[env] = 1 if it left in this one (seg.first: written for everyone, so the array needs no clearing);
+//   pending[env] counts to the END of the Env.step (seg.later = substeps of the segments behind this one).
+// A separate kernel: the one above is not to be touched (its solver loop's register allocation reacts to anything, 0.8-2.6 %).
+struct Segment { int first, later; };
+template <int MODE>
+__global__ void __launch_bounds__(64, 1) env_step_leg_seg_kernel(VecParams p, int* pending, int* gone, Segment seg) {
+  __shared__ DevB::Lds lds;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x * 32 + (lane >> 1);
+  const bool exists = env < p.n_envs;
+  const bool valid = exists && (seg.first || gone[env] == 0);
+  const size_t e = valid ? (size_t)env : 0;
+  EnvCfg cfg;
+  cfg.n_sub = p.n_sub; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
+  cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
+  cfg.pend_extra = seg.later; cfg.cont = !seg.first;
+  DCore::Io io;
+  io.rec = p.state + e * ENV_STRIDE;
+  io.has_act = p.actions != nullptr;
+  io.act = const_cast<double*>(p.actions) + (io.has_act ? e * p.adim : 0);
+  io.obs = p.obs + (cfg.want_obs ? e * 26 : 0);
+  io.has_tobs = p.terminal_obs != nullptr;
+  io.tobs = p.terminal_obs + (io.has_tobs ? e * 26 : 0);
+  io.rew = p.reward + (cfg.want_obs ? e : 0);
+  io.done = p.done + (cfg.want_obs ? e : 0);
+  DCore::Out o;
+  DCore::env_step<MODE>(cfg, lds, io, valid, o);
+  if (exists && (lane & 1) == 0) {
+    const int pend = valid ? o.pend : 0;
+    pending[env] = pend;
+    if (seg.first) gone[env] = pend > 0; else if (pend > 0) gone[env] = 1;
+    if (p.stats && valid) {
+      if (pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)pend);
+      if (o.bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+    }
+  }
+}
+
+#endif
+
 #ifdef CASSIE_LEG_HF
 // ---------------------------------------------------------------- height-field instantiation (tu_hf.hip)
 // The same core with the terrain collision stage (`terrain_sphere`, cassie_kernels.hip, which the including translation unit

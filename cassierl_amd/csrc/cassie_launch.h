@@ -33,6 +33,9 @@ void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 // tu_leg.hip: two lanes per environment (one per leg), 32 environments per wavefront; environments that need more than 8 rows on
 // a leg are handed on through `pending` (step_g16 with p.pending = that array, then step_k1)
 void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
+// ... for a SEGMENT of the Env.step's substeps (p.n_sub = its length; `later` = substeps of the segments behind it; gone[env]: the
+// environment left this tier in an earlier segment; see env_step_leg_seg_kernel)
+void step_leg_segment(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, int* gone, bool first, int later);
 // tags the pending environments the 4-envs-per-wave kernel could not hold either (PENDING_DEEP): they go straight to step_k1
 void classify_pending(int n_envs, hipStream_t s, const VecParams& p, int* pending);
 void step_leg_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);   // ... on the height field (p.hf)

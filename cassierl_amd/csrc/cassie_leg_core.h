@@ -70,6 +70,11 @@ constexpr int symidx(int n, int i, int j) { return i <= j ? i * n - i * (i - 1) 
 struct EnvCfg {
   int n_sub, flags, env_kind, auto_reset, adim;
   bool want_obs;
+  // a launch that does only a SEGMENT of the Env.step's substeps (cassie_cabi.hip: launch_physics_tiers while robots are down):
+  // cont = not the first segment (the iteration counter of the record carries on), pend_extra = substeps of the later segments
+  // (a handed-over environment is finished to the end of the Env.step by the lower tiers)
+  int pend_extra = 0;
+  bool cont = false;
   const double* traj_qpos;
   double traj_tmax;
   int traj_n;
@@ -997,6 +1002,7 @@ template <class B> struct Core {
     M live = valid;
     o.set_state = (valid & !valid);
     o.pend = 0; o.niter = 0;
+    if (cfg.cont) o.niter = B::toint(B::pld(io.rec, I(ES_NITER)));
     o.do_reset = o.set_state; o.bad = o.set_state;
     const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
     bool reset_pass = false;
@@ -1006,7 +1012,7 @@ template <class B> struct Core {
       substep<MODE, HF>(lds, st, reset_pass || MODE == 2, reset_pass ? o.do_reset : live, !reset_pass, so, hf);
       if (!reset_pass) {
         const M ovf = live & so.overflow;
-        o.pend = B::seli(ovf, I(cfg.n_sub - sub), o.pend);   // hand the rest of this environment to the next kernel tier
+        o.pend = B::seli(ovf, I(cfg.n_sub - sub + cfg.pend_extra), o.pend);   // hand the rest of this environment to the next kernel tier
         live = live & !ovf;
         o.niter = o.niter + B::seli(live, so.niter, I(0));
         o.set_state = o.set_state | live;
