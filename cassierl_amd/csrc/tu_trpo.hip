@@ -349,6 +349,37 @@ __global__ void __launch_bounds__(256) policy_step_kernel(const double* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- sampler step
+// Per-path clocks and returns of the sampler for one Env.step, one lane per environment (trpo.collect did this with ~20 element-wise
+// torch launches per step; rllab's sampler keeps the same quantities on the host).  Episode statistics: one (count, summed return) pair
+// per workgroup by a fixed-order tree, so the caller's sum over the rows is the same number on every run (a resumed run logs what the
+// uninterrupted one does).
+__global__ void __launch_bounds__(256) sampler_step_kernel(const double* __restrict__ rew, const uint8_t* __restrict__ done, int n, long long max_len,
+                                                          long long* __restrict__ path_t, double* __restrict__ path_ret, double* __restrict__ rew_row,
+                                                          long long* __restrict__ t_row, uint8_t* __restrict__ cut_row, double* __restrict__ partial) {
+  __shared__ double red[2][256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double cnt = 0.0, sum = 0.0;
+  if (i < n) {
+    const double r = rew[i];
+    const long long t = path_t[i];
+    rew_row[i] = r; t_row[i] = t;
+    const double ret = path_ret[i] + r;
+    const bool cut = done[i] != 0 || t + 1 >= max_len;   // rllab truncates paths at max_path_length
+    cut_row[i] = cut ? 1 : 0;
+    cnt = cut ? 1.0 : 0.0; sum = cut ? ret : 0.0;
+    path_ret[i] = cut ? 0.0 : ret;
+    path_t[i] = cut ? 0 : t + 1;
+  }
+  red[0][threadIdx.x] = cnt; red[1][threadIdx.x] = sum;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) { red[0][threadIdx.x] += red[0][threadIdx.x + m]; red[1][threadIdx.x] += red[1][threadIdx.x + m]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
 inline int blocks_for(int n) {
   const int tiles = (n + 31) / 32;
   int b = (tiles + WAVES - 1) / WAVES;
@@ -406,6 +437,16 @@ int CassieTrpoSurrogate(const float* obs_dev, int n, int obs_dim, int act_dim, c
   else if (obs_dim == 17 && act_dim == 6) hipLaunchKernelGGL((surrogate_kernel<17, 6>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
   else if (obs_dim == 17 && act_dim == 7) hipLaunchKernelGGL((surrogate_kernel<17, 7>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
   else return CASSIE_EINVAL;
+  return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
+}
+
+int CassieTrpoSamplerRows(int n_envs) { return n_envs > 0 ? (n_envs + 255) / 256 : 0; }
+
+int CassieTrpoSamplerStep(const double* rew_dev, const unsigned char* done_dev, int n, long long max_path_length, long long* path_t_dev, double* path_ret_dev,
+                          double* rew_row_dev, long long* t_row_dev, unsigned char* cut_row_dev, double* partial_dev, void* stream) {
+  if (!rew_dev || !done_dev || n <= 0 || !path_t_dev || !path_ret_dev || !rew_row_dev || !t_row_dev || !cut_row_dev || !partial_dev) return CASSIE_EINVAL;
+  hipLaunchKernelGGL(cassie_trpo::sampler_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew_dev, done_dev, n, max_path_length, path_t_dev,
+                     path_ret_dev, rew_row_dev, t_row_dev, cut_row_dev, partial_dev);
   return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
 

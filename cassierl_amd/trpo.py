@@ -430,6 +430,30 @@ class TRPO:
                 raise RuntimeError("CassieTrpoPolicyStep failed (%d)" % rc)
         return step
 
+    def _fused_sampler_step(self, dev):
+        """The sampler's per-step bookkeeping as one launch (include/cassie_trpo.h: CassieTrpoSamplerStep), or None."""
+        if not getattr(self, "fused_sampler_step", True) or dev.type != "cuda":
+            return None
+        try:
+            import ctypes as ct
+            from . import _lib
+            L = _lib.load()
+        except OSError:
+            return None
+        n = self.n_envs
+        if not hasattr(self, "_book_partial") or self._book_partial.shape[0] != L.CassieTrpoSamplerRows(n):
+            self._book_partial = torch.empty((L.CassieTrpoSamplerRows(n), 2), dtype=torch.float64, device=dev)
+        P = lambda t: ct.c_void_p(t.data_ptr())
+
+        def book(rew, done, rew_row, t_row, cut_row):
+            assert rew.is_contiguous() and done.is_contiguous() and rew_row.is_contiguous() and t_row.is_contiguous() and cut_row.is_contiguous()
+            assert self.path_t.dtype == torch.int64 and self.path_ret.dtype == torch.float64
+            rc = L.CassieTrpoSamplerStep(P(rew), P(done), n, ct.c_longlong(int(self.max_path_length)), P(self.path_t), P(self.path_ret), P(rew_row), P(t_row),
+                                         P(cut_row), P(self._book_partial), ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("CassieTrpoSamplerStep failed (%d)" % rc)
+        return book
+
     # ---- sampling: T vectorised Env.steps, everything stays on the device
     @torch.no_grad()
     def collect(self):
@@ -445,9 +469,9 @@ class TRPO:
         rew_b = torch.empty((T, N), dtype=torch.float64, device=dev)
         done_b = torch.empty((T, N), dtype=torch.bool, device=dev)
         t_b = torch.empty((T, N), dtype=torch.int64, device=dev)
-        ep_n = torch.zeros((), dtype=torch.float64, device=dev)   # finished episodes / their summed returns, kept on the
-        ep_sum = torch.zeros((), dtype=torch.float64, device=dev) # device: boolean-mask indexing would synchronise every step
-        fused = self._fused_policy_step(dev, pol_dtype)
+        ep = torch.zeros(2, dtype=torch.float64, device=dev)   # finished episodes / their summed returns, kept on the device:
+        fused = self._fused_policy_step(dev, pol_dtype)          # boolean-mask indexing would synchronise every step
+        book = self._fused_sampler_step(dev) if fused is not None else None
         if fused is not None:
             lstd_b[:] = self.policy.log_std.detach()
         for t in range(T):
@@ -464,26 +488,32 @@ class TRPO:
                 a, mean, log_std = self.policy.get_actions(o, noise=noise)
                 nobs, rew, done = self.env_step(self.act_map(a))
                 obs_b[t], act_b[t], mean_b[t], lstd_b[t] = o, a, mean, log_std
-            done = done.bool().clone()
-            rew_b[t], t_b[t] = rew, self.path_t
-            self.path_ret += rew
-            self.path_t += 1
-            cut = done | (self.path_t >= self.max_path_length)  # rllab truncates paths at max_path_length
-            done_b[t] = cut
-            ep_n += cut.sum()
-            ep_sum += torch.where(cut, self.path_ret, torch.zeros_like(self.path_ret)).sum()
-            self.path_ret = torch.where(cut, torch.zeros_like(self.path_ret), self.path_ret)
-            self.path_t = torch.where(cut, torch.zeros_like(self.path_t), self.path_t)
+            if book is not None and rew.dtype == torch.float64 and done.dtype == torch.uint8:
+                # clocks, returns, truncation and episode statistics of this step in ONE launch (CassieTrpoSamplerStep)
+                book(rew, done, rew_b[t], t_b[t], done_b[t])
+                ep += self._book_partial.sum(0)
+                cut = done_b[t]
+            else:
+                done = done.bool().clone()
+                rew_b[t], t_b[t] = rew, self.path_t
+                self.path_ret += rew
+                self.path_t += 1
+                cut = done | (self.path_t >= self.max_path_length)  # rllab truncates paths at max_path_length
+                done_b[t] = cut
+                ep[0] += cut.sum()
+                ep[1] += torch.where(cut, self.path_ret, torch.zeros_like(self.path_ret)).sum()
+                self.path_ret = torch.where(cut, torch.zeros_like(self.path_ret), self.path_ret)
+                self.path_t = torch.where(cut, torch.zeros_like(self.path_t), self.path_t)
             self._steps_to_trunc -= 1
             if self.env_reset_masked is not None and self._steps_to_trunc <= 0:
                 # a path may have been truncated at max_path_length while its env is still alive: rllab resets the env there
-                trunc = cut & ~done
+                trunc = cut & ~done.bool()
                 if bool(trunc.any()):
                     nobs = self.env_reset_masked(trunc.to(torch.uint8))
                 self._steps_to_trunc = self.max_path_length - int(self.path_t.max())  # re-arm from the oldest live path
             self.obs = nobs.clone()
         return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
-                    episode_count=ep_n, episode_return_sum=ep_sum)
+                    episode_count=ep[0], episode_return_sum=ep[1])
 
     def process(self, batch):
         T, N = batch["rew"].shape

@@ -54,6 +54,16 @@ int CassieTrpoPolicyStep(const double* obs_dev, int n, int obs_dim, int act_dim,
                          const double* low_dev, const double* high_dev, float* obs32_dev, float* mean_dev, float* act_dev,
                          double* env_actions_dev, void* stream);
 
+/* Sampler bookkeeping of one Env.step for n environments in one launch (the per-path clocks and returns rllab's sampler keeps on the
+ * host; cassierl_amd/trpo.py: collect): with rew / done as CassieVecStep wrote them,
+ *   rew_row[i] = rew[i], t_row[i] = path_t[i]  (this step's rows of the batch),  path_ret[i] += rew[i], path_t[i] += 1,
+ *   cut = done[i] || path_t[i] >= max_path_length  (rllab truncates paths there),  cut_row[i] = cut (one byte, 0 / 1),
+ *   a cut path adds (1, path_ret[i]) to its workgroup's row of partial [CassieTrpoSamplerRows(n)][2] and restarts: path_ret[i] = path_t[i] = 0.
+ * The rows are summed in a fixed order inside the kernel; the caller adds them up. */
+int CassieTrpoSamplerRows(int n_envs);
+int CassieTrpoSamplerStep(const double* rew_dev, const unsigned char* done_dev, int n, long long max_path_length, long long* path_t_dev, double* path_ret_dev,
+                          double* rew_row_dev, long long* t_row_dev, unsigned char* cut_row_dev, double* partial_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

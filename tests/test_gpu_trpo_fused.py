@@ -113,3 +113,23 @@ def test_fused_surrogate_matches_the_torch_line_search_evaluation(n, obs_dim, ac
     scale = (lr.double() * adv.double()).abs().mean().item()
     assert abs(l.item() - l_ref) < 2e-5 * scale, (l.item(), l_ref)
     assert abs(k.item() - k_ref) < 2e-5 * max(k_ref, 1e-3), (k.item(), k_ref)
+
+
+def test_fused_sampler_step_matches_the_torch_bookkeeping():
+    """CassieTrpoSamplerStep (path clocks / returns / truncation / episode statistics in one launch) against the element-wise torch
+    operations of TRPO.collect: two samplers from the same seed, paths truncated after 5 steps so that every branch is taken."""
+    import torch
+    from cassierl_amd import trpo as T
+    algos = []
+    for fused in (True, False):
+        a = T.make_cassie_trpo(4096, kind="stand", control_mode="Torque", batch_size=4096 * 12, max_path_length=5, seed=3)
+        a.fused_sampler_step = fused
+        algos.append(a)
+    for it in range(2):
+        b0, b1 = algos[0].collect(), algos[1].collect()
+        for k in ("obs", "act", "mean", "rew", "done", "t"):
+            assert torch.equal(b0[k], b1[k]), (it, k)
+        assert b0["done"].any() and not b0["done"].all()
+        assert float(b0["episode_count"]) == float(b1["episode_count"]) > 0
+        assert abs(float(b0["episode_return_sum"]) - float(b1["episode_return_sum"])) < 1e-9 * (1 + abs(float(b1["episode_return_sum"])))
+        assert torch.equal(algos[0].path_t, algos[1].path_t) and torch.equal(algos[0].path_ret, algos[1].path_ret)
