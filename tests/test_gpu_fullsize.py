@@ -550,17 +550,23 @@ def test_lower_tiers_side_by_side_or_one_after_the_other_give_the_same_bits(vec,
     synchronising: one after the other (the middle tier looks at every handed-down environment first) or side by side on two streams
     (a small kernel routes the environments the middle tier could not hold straight to the wave-per-environment kernel).  The order
     must not change a single bit: 16 384 robots driven to the ground with random torques (hand-overs to both lower tiers in every
-    step), once with each order forced, and once with the automatic choice."""
+    step), once with each order forced, and once with the automatic choice.  r04: side by side means the Env.step in SEGMENTS (the
+    lower tiers start on an overflowing environment while the first tier goes on with the rest; CASSIE2D_SEGMENTS=0 keeps the r03
+    side-by-side order of one launch of the first tier) -- a fourth run."""
     from cassierl_amd.vec_env import LEG_TIER_ON
     n, T = 16384, 120
     rng = np.random.default_rng(77)
     acts = rng.uniform(-TQ * 1.5, TQ * 1.5, (T, n, 6))
     finals, counters = [], []
-    for mode in ("0", "1", None):
+    for mode, seg in (("0", None), ("1", None), (None, None), ("1", "0")):
         if mode is None:
             monkeypatch.delenv("CASSIE2D_SIDE_BY_SIDE", raising=False)
         else:
             monkeypatch.setenv("CASSIE2D_SIDE_BY_SIDE", mode)
+        if seg is None:
+            monkeypatch.delenv("CASSIE2D_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("CASSIE2D_SEGMENTS", seg)
         e = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False, flags=LEG_TIER_ON)
         e.reset_host()
         for t in range(T):
@@ -569,7 +575,8 @@ def test_lower_tiers_side_by_side_or_one_after_the_other_give_the_same_bits(vec,
         counters.append(e.counters())
         e.close()
     monkeypatch.delenv("CASSIE2D_SIDE_BY_SIDE", raising=False)
+    monkeypatch.delenv("CASSIE2D_SEGMENTS", raising=False)
     assert np.isfinite(finals[0]).all()
     assert counters[0]["cleanup_substeps"] > 0 and counters[0]["k1_substeps"] > 0, counters[0]   # both lower tiers had work
-    assert np.array_equal(finals[0], finals[1]) and np.array_equal(finals[0], finals[2])
-    assert counters[0]["cleanup_substeps"] == counters[1]["cleanup_substeps"] == counters[2]["cleanup_substeps"]
+    assert np.array_equal(finals[0], finals[1]) and np.array_equal(finals[0], finals[2]) and np.array_equal(finals[0], finals[3])
+    assert counters[0]["cleanup_substeps"] == counters[1]["cleanup_substeps"] == counters[2]["cleanup_substeps"] == counters[3]["cleanup_substeps"]
