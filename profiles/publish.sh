@@ -9,9 +9,11 @@ src=gpurun_out/$tag
 [ -f $src/pytest_gpu.log ] && tail -3 $src/pytest_gpu.log > profiles/${tag}_pytest_gpu.txt
 [ -f $src/pytest_gpu_leg_forced.log ] && tail -3 $src/pytest_gpu_leg_forced.log > profiles/${tag}_pytest_gpu_leg_forced.txt
 [ -f $src/trpo_65536.jsonl ] && cp $src/trpo_65536.jsonl profiles/${tag}_trpo_65536.jsonl
+[ -f $src/trpo_walk_65536.jsonl ] && cp $src/trpo_walk_65536.jsonl profiles/${tag}_trpo_walk_65536.jsonl
+[ -f $src/cassie3d_bench.json ] && cp $src/cassie3d_bench.json profiles/${tag}_cassie3d_bench.json
 ks=$(find $src/stats -name "*kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$ks" ] && grep -v "at::native\|__amd_rocclr" "$ks" > profiles/${tag}_kernel_stats.csv
-for w in osc fallen; do
+for w in osc fallen trpo 3d; do
   ks=$(find $src/stats_$w -name "*kernel_stats.csv" 2>/dev/null | head -1)
   [ -n "$ks" ] && grep -v "at::native\|__amd_rocclr" "$ks" > profiles/${tag}_kernel_stats_$w.csv
 done

@@ -34,7 +34,19 @@ for w in $what; do
       find "$out/stats_fallen" -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-170 ;;
     trpo)
       timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
-      tail -2 "$out/trpo_65536.jsonl" | cut -c1-400 ;;
+      tail -2 "$out/trpo_65536.jsonl" | cut -c1-400
+      # the loop's headline configuration: walk env / PD (what bench.py steps), 65 536 envs x 8 steps per iteration
+      timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 10 --kind walk --control-mode PD --timing > "$out/trpo_walk_65536.jsonl" 2>> "$out/trpo.err"
+      tail -2 "$out/trpo_walk_65536.jsonl" | cut -c1-400 ;;
+    proftrpo)   # kernel statistics of the TRPO loop (walk env / PD): Env.step, policy step, sampler step, Fisher-vector products, line search
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_trpo" -o trpo -- \
+          python3 "$root/train_trpo.py" --envs-per-gpu 65536 --horizon 8 --n-itr 8 --kind walk --control-mode PD > "$out/stats_trpo.log" 2>&1 )
+      find "$out/stats_trpo" -name "*kernel_stats.csv" | head -1 | xargs -r head -14 | cut -c1-170 ;;
+    prof3d)   # kernel statistics of configs[4] (Cassie3d, 16 384 envs, reset every 40 steps)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_3d" -o c3d -- \
+          python3 "$root/tests/bench_cassie3d.py" > "$out/stats_3d.log" 2>&1 )
+      grep -a "^{" "$out/stats_3d.log" | tail -1 > "$out/cassie3d_bench.json"
+      find "$out/stats_3d" -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-170 ;;
     pmc)
       bash profiles/collect_pmc.sh $tag | tail -12
       # refresh profiles/pmc_traffic.json on the box so that a `bench` listed AFTER `pmc` reports this build's own counters
