@@ -23,6 +23,11 @@ struct Params3 {
   int* pending_out;        // [n] substeps NOT done because the env needed more rows than this kernel has, or null: flag E3_OVF
   unsigned long long* stats;  // [S3_N] event counters of the handle (rare-path atomics only)
   int n_envs, n_sub, integrate;
+  // the lane-per-leg kernel on a SEGMENT of the step's substeps (cassie_cabi.hip: launch3d): gone[env] != 0 = the environment left that
+  // kernel in an earlier segment (not touched; seg_first: written for everyone); pending_out counts to the END of the step (seg_later
+  // = substeps of the segments behind this one).  gone == null: the whole step in one launch.
+  int* gone;
+  int seg_first, seg_later;
 };
 // S3_GENERAL_SUBSTEPS: env-substeps the 32-row kernel handed to the 64-row kernel; S3_CAPPED_SUBSTEPS: env-substeps in which
 // the 64-row kernel had to leave contacts out (more than 64 constraint rows)

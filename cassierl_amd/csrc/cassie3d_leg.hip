@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(64, 1) env_step3d_leg_kernel(Params3 p) {
   __shared__ typename DevB3<LANES>::Lds lds;
   const int lane = threadIdx.x;
   const int env = blockIdx.x * (LANES / 2) + (lane >> 1);
-  const bool valid = lane < LANES && env < p.n_envs;
+  const bool exists = lane < LANES && env < p.n_envs;
+  const bool first = p.gone == nullptr || p.seg_first != 0;
+  const bool valid = exists && (first || p.gone[env] == 0);
   const size_t e = valid ? (size_t)env : 0;
   typename DCore3::Io io;
   io.rec = p.state + e * ENV3_STRIDE;
@@ -97,12 +99,16 @@ __global__ void __launch_bounds__(64, 1) env_step3d_leg_kernel(Params3 p) {
   if (lane < LANES) for (int s = 0; s < NSLOT3; s++) lds.a[s][lane] = 0.0;   // a lane only ever reads back what it wrote -- or this
   typename DCore3::Out o;
   DCore3::env_step(lds, io, valid, p.n_sub, p.integrate != 0, o);
-  if (valid && (lane & 1) == 0) {
-    double* st = p.state + e * ENV3_STRIDE;
-    st[E3_NITER] = (double)o.niter;
-    if (o.pend == 0) st[E3_NEFC] = (double)o.nrows;
-    if (p.pending_out) p.pending_out[e] = o.pend;
-    if (o.pend > 0 && p.stats) atomicAdd(p.stats + S3_LEG_HANDOVER_SUBSTEPS, (unsigned long long)o.pend);
+  if (exists && (lane & 1) == 0) {
+    const int pend = (valid && o.pend > 0) ? o.pend + (p.gone ? p.seg_later : 0) : 0;
+    if (valid) {
+      double* st = p.state + e * ENV3_STRIDE;
+      st[E3_NITER] = (double)o.niter + (first ? 0.0 : st[E3_NITER]);
+      if (pend == 0) st[E3_NEFC] = (double)o.nrows;
+      if (pend > 0 && p.stats) atomicAdd(p.stats + S3_LEG_HANDOVER_SUBSTEPS, (unsigned long long)pend);
+    }
+    if (p.pending_out) p.pending_out[env] = pend;
+    if (p.gone) { if (first) p.gone[env] = pend > 0; else if (pend > 0) p.gone[env] = 1; }
   }
 }
 

@@ -711,6 +711,14 @@ struct Cassie3dVec {
   unsigned long long* stats = nullptr;
   unsigned long long substeps_requested = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the step in segments (launch3d): per segment the hand-over lists, a side stream and two events
+  static constexpr int NSEG = 3;
+  bool seg_on = true;                        // CASSIE3D_SEGMENTS=0: the whole step in one launch of the lane-per-leg kernel (A/B, tests)
+  int* seg_pend[NSEG] = {};
+  int* seg_pend2[NSEG] = {};
+  int* gone = nullptr;
+  hipStream_t seg_side[NSEG] = {};
+  hipEvent_t seg_fork[NSEG] = {}, seg_join[NSEG] = {};
   std::string err;
 };
 
@@ -725,6 +733,39 @@ void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
   // tiers: one lane per leg (rows in per-lane LDS slots: 3 connect rows + 25 slots per limit + 81 per contact) -> one wavefront
   // per environment with at most 32 rows -> the general kernel (64 rows, capped); each leaves an environment it cannot hold
   // untouched from that substep on and says how many substeps are left
+  p.gone = nullptr; p.seg_first = 1; p.seg_later = 0;
+  if (h->leg && h->seg_on && h->gone && p.n_sub >= 2 * Cassie3dVec::NSEG) {
+    // ---- the step in segments (r04): the lane-per-leg kernel runs the substeps in three launches; after each, the environments that
+    // left its row capacity in that segment are finished -- to the END of the step -- by the wavefront-per-environment kernels on the
+    // segment's own stream, while the lane-per-leg kernel goes on with the next segment for everyone else.  A hand-over costs ~0.25 ms
+    // per substep in the lower tiers against ~0.5 ms per substep of the first tier's own chain, so all but the last segment's
+    // hand-overs are off the step's critical path (16 384 envs: 0.26 ms of tail per step -> 0.0x).
+    int later = p.n_sub;
+    bool ok = true;
+    for (int j = 0; j < Cassie3dVec::NSEG && ok; j++) {
+      const int len = (later + (Cassie3dVec::NSEG - j) - 1) / (Cassie3dVec::NSEG - j);
+      later -= len;
+      cassie3d::Params3 ps = p;
+      ps.n_sub = len; ps.pending_in = nullptr; ps.pending_out = h->seg_pend[j];
+      ps.gone = h->gone; ps.seg_first = j == 0; ps.seg_later = later;
+      L3::step3d(h->leg_full ? 4 : 3, h->n, h->stream, ps);
+      ok = hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess && hipStreamWaitEvent(h->seg_side[j], h->seg_fork[j], 0) == hipSuccess;
+      if (!ok) break;
+      cassie3d::Params3 pa = p, pb = p;
+      pa.pending_in = h->seg_pend[j]; pa.pending_out = h->seg_pend2[j];
+      L3::step3d(0, h->n, h->seg_side[j], pa);
+      pb.pending_in = h->seg_pend2[j]; pb.pending_out = nullptr;
+      L3::step3d(1, h->n, h->seg_side[j], pb);
+      ok = hipEventRecord(h->seg_join[j], h->seg_side[j]) == hipSuccess;
+    }
+    for (int j = 0; j < Cassie3dVec::NSEG && ok; j++) ok = hipStreamWaitEvent(h->stream, h->seg_join[j], 0) == hipSuccess;
+    if (!ok) {   // an event could not be recorded / waited for: finish in order the hard way and stay with one launch from now on
+      for (int j = 0; j < Cassie3dVec::NSEG; j++) hipStreamSynchronize(h->seg_side[j]);
+      hipStreamSynchronize(h->stream);
+      h->seg_on = false;
+    }
+    return;
+  }
   const int* in = nullptr;
   if (h->leg) {
     p.pending_in = nullptr; p.pending_out = h->pending_leg;
@@ -770,6 +811,15 @@ int Cassie3dVecCreate(Cassie3dVec** out, int n_envs, int device) {
   if (hipMalloc(&h->stats, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipMemset(h->stats, 0, cassie3d::S3_N * sizeof(unsigned long long)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE3D_PAIR"); if (e && e[0] == '1') { h->pair = true; h->leg = false; } }   // the opt-in cross-check kernel is a FIRST tier (it takes no pending list)
+  { const char* e = getenv("CASSIE3D_SEGMENTS"); if (e && e[0] == '0') h->seg_on = false; }
+  if (h->leg && h->seg_on) {   // lists, streams and events of the segmented step (not available: one launch, same results)
+    bool ok = hipMalloc(&h->gone, (size_t)n_envs * sizeof(int)) == hipSuccess;
+    for (int j = 0; j < Cassie3dVec::NSEG && ok; j++)
+      ok = hipMalloc(&h->seg_pend[j], (size_t)n_envs * sizeof(int)) == hipSuccess && hipMalloc(&h->seg_pend2[j], (size_t)n_envs * sizeof(int)) == hipSuccess &&
+           hipStreamCreateWithFlags(&h->seg_side[j], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->seg_fork[j], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&h->seg_join[j], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { h->seg_on = false; (void)hipGetLastError(); }
+  }
   if (Cassie3dVecReset(h, nullptr, nullptr) != CASSIE_OK || hipStreamSynchronize(h->stream) != hipSuccess) return bail(CASSIE_EHIP);
   *out = h;
   return CASSIE_OK;
@@ -779,6 +829,13 @@ void Cassie3dVecFree(Cassie3dVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  for (int j = 0; j < Cassie3dVec::NSEG; j++) {
+    if (h->seg_side[j]) { hipStreamSynchronize(h->seg_side[j]); hipStreamDestroy(h->seg_side[j]); }
+    if (h->seg_fork[j]) hipEventDestroy(h->seg_fork[j]);
+    if (h->seg_join[j]) hipEventDestroy(h->seg_join[j]);
+    hipFree(h->seg_pend[j]); hipFree(h->seg_pend2[j]);
+  }
+  hipFree(h->gone);
   hipFree(h->state); hipFree(h->d_act); hipFree(h->d_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->stats);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
