@@ -29,6 +29,7 @@ EXPORTS = [
     "Cassie3dVecSetStateHost", "Cassie3dVecDebugForwardHost", "Cassie3dVecTimeSteps",
     # fused policy kernels of the TRPO outer loop (include/cassie_trpo.h)
     "CassieTrpoParamCount", "CassieTrpoPartialRows", "CassieTrpoFvp", "CassieTrpoVjp", "CassieTrpoSurrogate", "CassieTrpoPolicyStep", "CassieTrpoSamplerRows", "CassieTrpoSamplerStep",
+    "CassieTrpoBaselineFeatures", "CassieTrpoBaselinePredict", "CassieTrpoReturnsAdvantages", "CassieTrpoGramRows", "CassieTrpoGramRowSize", "CassieTrpoBaselineGram",
 ]
 
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcassie2d.so")
-UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo"]
+UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo", "tu_trpo_baseline"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("CASSIE_HIPCC_FLAGS", "").split()

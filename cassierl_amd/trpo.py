@@ -122,6 +122,10 @@ class LinearFeatureBaseline:
         X = self.features(obs, t).double()
         y = returns.double()
         A, b = gram(X, y)
+        self.fit_normal_equations(A, b)
+
+    def fit_normal_equations(self, A, b):
+        """coeffs from this rank's X'X [F, F] and X'y [F] (summed over ranks here)."""
         A, b = all_sum_(A.contiguous()), all_sum_(b.contiguous())
         reg = self.reg_coeff
         eye = torch.eye(A.shape[0], dtype=A.dtype, device=A.device)
@@ -136,6 +140,77 @@ class LinearFeatureBaseline:
         if self.coeffs is None:
             return torch.zeros(obs.shape[0], dtype=torch.float64, device=obs.device)
         return self.features(obs, t).double() @ self.coeffs
+
+
+class BaselineKernels:
+    """LinearFeatureBaseline on the device batch as three HIP kernels (csrc/tu_trpo_baseline.hip, include/cassie_trpo.h): prediction,
+    returns / advantages of the [T, n] batch in one pass, and the regression's normal equations on the FP64 matrix cores -- the feature
+    matrix is never materialised.  CUDA float32 observations of a supported width only (ValueError otherwise: TRPO.process falls back to
+    the torch expressions of LinearFeatureBaseline)."""
+
+    def __init__(self, dev, obs_dim):
+        import ctypes as ct
+        from . import _lib
+        if dev.type != "cuda":
+            raise ValueError("BaselineKernels need a CUDA device")
+        self.L, self.ct, self.dev, self.D = _lib.load(), ct, dev, obs_dim
+        self.F = self.L.CassieTrpoBaselineFeatures(obs_dim)
+        if self.F == 0:
+            raise ValueError("BaselineKernels: unsupported observation width %d" % obs_dim)
+        rows, size = self.L.CassieTrpoGramRows(), self.L.CassieTrpoGramRowSize(obs_dim)
+        self.gram_partial = torch.empty((rows, size), dtype=torch.float64, device=dev)
+        # full symmetric matrix from the upper 16 x 16 blocks (r <= c, r-major, each row-major): one gather
+        nb = ((self.F + 1) + 15) // 16
+        order, k = {}, 0
+        for r in range(nb):
+            for c in range(r, nb):
+                order[(r, c)] = k
+                k += 1
+        idx = torch.empty((16 * nb, 16 * nb), dtype=torch.int64)
+        for I in range(16 * nb):
+            for J in range(16 * nb):
+                r, c, i, j = I // 16, J // 16, I % 16, J % 16
+                idx[I, J] = order[(r, c)] * 256 + i * 16 + j if r <= c else order[(c, r)] * 256 + j * 16 + i
+        self.idx = idx.reshape(-1).to(dev)
+        self.nz = 16 * nb
+
+    def _stream(self):
+        return self.ct.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _p(self, t):
+        return self.ct.c_void_p(t.data_ptr()) if t is not None else None
+
+    def predict(self, obs32, t, coeffs):
+        m = obs32.shape[0]
+        out = torch.empty(m, dtype=torch.float64, device=self.dev)
+        rc = self.L.CassieTrpoBaselinePredict(self._p(obs32.contiguous()), self._p(t.contiguous()), m, self.D, self._p(coeffs.contiguous()), self._p(out), self._stream())
+        if rc != 0:
+            raise RuntimeError("CassieTrpoBaselinePredict failed (%d)" % rc)
+        return out
+
+    def returns_advantages(self, obs_b, t_b, rew_b, cut_b, coeffs, last_value, gamma):
+        """[T, n] batch -> returns [T, n], advantages [T, n] (float64) and (sum adv, sum adv^2) as a float64 pair on the device."""
+        T, n = rew_b.shape
+        assert obs_b.is_contiguous() and t_b.is_contiguous() and rew_b.is_contiguous() and cut_b.is_contiguous()
+        assert obs_b.dtype == torch.float32 and t_b.dtype == torch.int64 and rew_b.dtype == torch.float64 and cut_b.dtype in (torch.bool, torch.uint8)
+        returns, adv = torch.empty_like(rew_b), torch.empty_like(rew_b)
+        partial = torch.empty(((n + 255) // 256, 2), dtype=torch.float64, device=self.dev)
+        rc = self.L.CassieTrpoReturnsAdvantages(self._p(obs_b), self._p(t_b), self._p(rew_b), self._p(cut_b), T, n, self.D,
+                                                self._p(None if coeffs is None else coeffs.contiguous()), self._p(None if last_value is None else last_value.contiguous()),
+                                                self.ct.c_double(gamma), self._p(returns), self._p(adv), self._p(partial), self._stream())
+        if rc != 0:
+            raise RuntimeError("CassieTrpoReturnsAdvantages failed (%d)" % rc)
+        return returns, adv, partial.sum(0)
+
+    def gram(self, obs32, t, y):
+        """(X'X [F, F], X'y [F]) of the baseline's features on m samples."""
+        m = obs32.shape[0]
+        assert obs32.is_contiguous() and t.is_contiguous() and y.is_contiguous() and y.dtype == torch.float64
+        rc = self.L.CassieTrpoBaselineGram(self._p(obs32), self._p(t), self._p(y), m, self.D, self._p(self.gram_partial), self._stream())
+        if rc != 0:
+            raise RuntimeError("CassieTrpoBaselineGram failed (%d)" % rc)
+        G = self.gram_partial.sum(0)[self.idx].view(self.nz, self.nz)
+        return G[:self.F, :self.F], G[:self.F, self.F]
 
 
 class NormalizedActions:
@@ -515,10 +590,39 @@ class TRPO:
         return dict(obs=obs_b, act=act_b, mean=mean_b, log_std=lstd_b, rew=rew_b, done=done_b, t=t_b,
                     episode_count=ep[0], episode_return_sum=ep[1])
 
+    def _baseline_kernels(self, obs):
+        """BaselineKernels for this batch (float32 CUDA observations of a supported width, LinearFeatureBaseline) or None."""
+        if not getattr(self, "fused_baseline", True) or not obs.is_cuda or obs.dtype != torch.float32 or type(self.baseline) is not LinearFeatureBaseline:
+            return None
+        bk = getattr(self, "_bk", None)
+        if bk is None or bk.D != obs.shape[-1] or bk.dev != obs.device:
+            try:
+                bk = BaselineKernels(obs.device, obs.shape[-1])
+            except (ValueError, OSError):
+                bk = None
+            self._bk = bk
+        return bk
+
     def process(self, batch):
         T, N = batch["rew"].shape
         flat = lambda x: x.reshape(T * N, *x.shape[2:])
         obs, tt = flat(batch["obs"]), flat(batch["t"])
+        bk = self._baseline_kernels(obs)
+        if bk is not None:
+            # value of every sample, return-to-go and advantage in one pass over the batch, the regression's normal equations on the
+            # FP64 matrix cores (csrc/tu_trpo_baseline.hip): no feature matrix in memory
+            coeffs = self.baseline.coeffs
+            last_v = None if coeffs is None else bk.predict(self.obs.to(obs.dtype), self.path_t, coeffs)
+            returns, adv, sums = bk.returns_advantages(batch["obs"], batch["t"], batch["rew"], batch["done"], coeffs, last_v, self.discount)
+            adv = flat(adv)
+            n = torch.tensor([adv.numel()], dtype=torch.float64, device=adv.device)
+            s12 = all_sum_(sums.clone()); n = all_sum_(n)
+            mean = s12[0] / n
+            std = (s12[1] / n - mean * mean).clamp_min(0).sqrt()
+            adv = ((adv - mean) / (std + 1e-8)).to(obs.dtype)  # center_adv
+            A, b = bk.gram(obs, tt, flat(returns))
+            self.baseline.fit_normal_equations(A, b)
+            return dict(obs=obs, act=flat(batch["act"]), mean=flat(batch["mean"]), log_std=flat(batch["log_std"]), adv=adv)
         # bootstrap unfinished paths with the baseline of the next observation (0 at iteration 0)
         last_v = self.baseline.predict(self.obs.to(obs.dtype), self.path_t)
         returns = discounted_returns(batch["rew"], batch["done"], self.discount, last_v)

@@ -64,6 +64,30 @@ int CassieTrpoSamplerRows(int n_envs);
 int CassieTrpoSamplerStep(const double* rew_dev, const unsigned char* done_dev, int n, long long max_path_length, long long* path_t_dev, double* path_ret_dev,
                           double* rew_row_dev, long long* t_row_dev, unsigned char* cut_row_dev, double* partial_dev, void* stream);
 
+/* ---- the baseline side: rllab's LinearFeatureBaseline (trpo_cassie.py:30) on the [T][n] batch of the vectorised environment.
+ * Features of a sample: [o, o^2, a, a^2, a^3, 1] with o = clip(obs, -10, 10) [obs_dim] and a = path clock / 100, evaluated in float32 as the
+ * torch expressions of cassierl_amd/trpo.py evaluate them, used in float64; CassieTrpoBaselineFeatures(obs_dim) = 2 obs_dim + 4 (0: unsupported). */
+int CassieTrpoBaselineFeatures(int obs_dim);
+
+/* values[s] = features(obs[s], t[s]) . coeffs  (obs float32 [m][obs_dim], t int64 [m], coeffs float64 [features]) */
+int CassieTrpoBaselinePredict(const float* obs_dev, const long long* t_dev, int m, int obs_dim, const double* coeffs_dev, double* out_dev, void* stream);
+
+/* One lane per environment, backwards over the T steps of its column of the batch (sample s = step * n + env):
+ *   value = features . coeffs (0 with coeffs = NULL: the first iteration),
+ *   returns[s] = rew[s] + gamma * returns[next step] * !cut[s]  (bootstrapped behind the last step with last_value [n], NULL = 0),
+ *   adv[s] = returns[s] - value  (gae_lambda = 1),
+ * and partial[(n + 255) / 256][2] = per workgroup (sum adv, sum adv^2), fixed order: what the advantage normalisation needs. */
+int CassieTrpoReturnsAdvantages(const float* obs_dev, const long long* t_dev, const double* rew_dev, const unsigned char* cut_dev, int T, int n, int obs_dim,
+                                const double* coeffs_dev, const double* last_value_dev, double gamma, double* returns_dev, double* adv_dev, double* partial_dev,
+                                void* stream);
+
+/* Normal equations of the baseline's ridge regression: Z'Z for Z = [features | y] (m samples, 2 obs_dim + 5 columns padded to a multiple
+ * of 16) on the FP64 matrix cores.  partial [CassieTrpoGramRows()][CassieTrpoGramRowSize(obs_dim)]: per wavefront the UPPER 16 x 16 blocks
+ * (r <= c, r-major) of the Gram matrix, each row-major; the caller adds the rows up: X'X = Z'Z[:features, :features], X'y = Z'Z[:features, features]. */
+int CassieTrpoGramRows(void);
+int CassieTrpoGramRowSize(int obs_dim);
+int CassieTrpoBaselineGram(const float* obs_dev, const long long* t_dev, const double* y_dev, int m, int obs_dim, double* partial_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
