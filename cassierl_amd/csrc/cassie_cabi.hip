@@ -58,6 +58,8 @@ struct CassieVec {
   // the Env.step in segments while robots are down (launch_physics_tiers): per segment the hand-over lists, two streams, three events
   static constexpr int NSEG = 4;
   bool seg_on = true;                        // CASSIE2D_SEGMENTS=0: the one-launch order (A/B, tests)
+  bool reset_packed = true;                  // CASSIE2D_RESET_PACKED=0: CassieVecReset with one wavefront per environment only (A/B, tests)
+  uint8_t* need_slow = nullptr;              // [n] written by the packed reset kernel: environments the wave-per-environment reset takes
   bool seg_ready = false, seg_failed = false;
   int* seg_pend[NSEG] = {};                  // [n] substeps left per env after segment j of the two-lanes-per-env kernel
   int* seg_pend2[NSEG] = {};                 // [n] ... after the 4-envs-per-wave kernel took segment j's environments
@@ -323,7 +325,12 @@ int launch_reset(CassieVec* h, const uint8_t* mask, const double* q, const doubl
     q = h->d_q; v = h->d_v;
   }
   if (h->hf.h) L2::reset_hf(h->n, h->stream, p, mask, q, v);
-  else L2::reset(h->n, h->stream, p, mask, q, v);
+  else if (h->g16 && h->reset_packed && h->need_slow) {
+    // two lanes per environment, 32 environments per wavefront; a state with more than 8 rows on a leg is left to the
+    // wave-per-environment kernel through the mask the packed kernel writes
+    L2::reset_leg(h->n, h->stream, p, mask, q, v, h->need_slow);
+    L2::reset(h->n, h->stream, p, h->need_slow, q, v);
+  } else L2::reset(h->n, h->stream, p, mask, q, v);
   HIPCHK(h, hipGetLastError());
   return CASSIE_OK;
 }
@@ -380,6 +387,8 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
   { const char* e = getenv("CASSIE2D_SEGMENTS"); if (e && e[0] == '0') h->seg_on = false; }
+  { const char* e = getenv("CASSIE2D_RESET_PACKED"); if (e && e[0] == '0') h->reset_packed = false; }
+  if (hipMalloc(&h->need_slow, n) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
   *h->deep_hint = 0;
   if (hipHostGetDevicePointer((void**)&h->deep_hint_dev, h->deep_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);
@@ -410,7 +419,7 @@ void CassieVecFree(CassieVec* h) {
     if (h->seg_join_b[j]) hipEventDestroy(h->seg_join_b[j]);
     hipFree(h->seg_pend[j]); hipFree(h->seg_pend2[j]);
   }
-  hipFree(h->gone);
+  hipFree(h->gone); hipFree(h->need_slow);
   if (h->deep_hint) hipHostFree(h->deep_hint);
   delete h;
 }

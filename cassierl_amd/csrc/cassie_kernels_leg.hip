@@ -204,6 +204,29 @@ __global__ void __launch_bounds__(64, 1) env_step_leg_seg_kernel(VecParams p, in
   }
 }
 
+// CassieVecReset with the two-lanes-per-environment core (r04): mask [n] or null = everyone, qpos / qvel [n][13] or null = the reset
+// pose.  need_slow[env] = 1: the given state needs more than 8 rows on a leg -- untouched here, env_reset_kernel takes it (need_slow as
+// its mask).  65 536 environments: one wavefront per 32 of them instead of one each (5.1 ms -> see DESIGN.md K2).
+__global__ void __launch_bounds__(64, 1) env_reset_leg_kernel(VecParams p, const uint8_t* mask, const double* qpos_in, const double* qvel_in, uint8_t* need_slow) {
+  __shared__ DevB::Lds lds;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x * 32 + (lane >> 1);
+  const bool exists = env < p.n_envs;
+  const bool want = exists && (!mask || mask[env]);
+  const size_t e = exists ? (size_t)env : 0;
+  EnvCfg cfg;
+  cfg.n_sub = 0; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
+  cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
+  DCore::Io io;
+  io.rec = p.state + e * ENV_STRIDE;
+  io.has_act = false; io.act = io.rec;
+  io.obs = p.obs + (cfg.want_obs ? e * 26 : 0);
+  io.has_tobs = false; io.tobs = io.obs; io.rew = io.rec; io.done = nullptr;
+  const bool has_qv = qpos_in != nullptr;
+  DCore::Out o;
+  DCore::env_reset<false>(cfg, lds, io, want, const_cast<double*>(qpos_in) + (has_qv ? e * 13 : 0), const_cast<double*>(qvel_in) + (has_qv ? e * 13 : 0), has_qv, o);
+  if (exists && (lane & 1) == 0) need_slow[env] = (want && o.pend != 0) ? 1 : 0;
+}
 #endif
 
 #ifdef CASSIE_LEG_HF

@@ -36,6 +36,8 @@ void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 // ... for a SEGMENT of the Env.step's substeps (p.n_sub = its length; `later` = substeps of the segments behind it; gone[env]: the
 // environment left this tier in an earlier segment; see env_step_leg_seg_kernel)
 void step_leg_segment(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, int* gone, bool first, int later);
+// CassieVecReset through the same core: need_slow[env] = 1 where the state needs the wave-per-environment reset kernel (its mask)
+void reset_leg(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel, uint8_t* need_slow);
 // tags the pending environments the 4-envs-per-wave kernel could not hold either (PENDING_DEEP): they go straight to step_k1
 void classify_pending(int n_envs, hipStream_t s, const VecParams& p, int* pending);
 void step_leg_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);   // ... on the height field (p.hf)

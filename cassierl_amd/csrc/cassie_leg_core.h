@@ -962,6 +962,77 @@ template <class B> struct Core {
     bool has_act, has_tobs;
   };
 
+  // ------------------------------------------------------------------------------------------------ masked reset
+  // Cassie2dEnv.reset / Cassie2d::Reset for the environments of `want` (identical on the two lanes of a pair; CassieVecReset): state <-
+  // (qin, vin) or the reset pose, mj_forward with the stale ctrl, no setState; observation = the 17 op-space values, trajectory slots zero
+  // -- what env_step's reset pass does for a terminated environment, for any state.  o.pend = 1: the state needs more rows than this
+  // tier holds and the environment is left untouched (the wave-per-environment reset kernel takes it).
+  template <bool HF = false>
+  static LEG_FN void env_reset(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, M want, typename B::P qin, typename B::P vin, bool has_qv, Out& o,
+                               const Terrain* hf = nullptr) {
+    const I leg = B::leg();
+    const I lo = leg * 5 + 3, ao = leg * 3;
+    const M left = leg == 0;
+    const M all = want | !want;
+    Lane st;
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      st.wb[Bc] = B::pld(io.rec, I(ES_WS + Bc));
+      st.qb[Bc] = has_qv ? B::pld(qin, I(Bc)) : D(cp_env_qinit[Bc]);
+      st.vb[Bc] = has_qv ? B::pld(vin, I(Bc)) : D(0.0);
+      lds.cst(C_CTRL + Bc, B::pld(io.rec, ao + (ES_CTRL + Bc)), all);
+      lds.cst(C_ACT + Bc, D(0.0), all);
+      lds.cst(C_KQ + Bc, B::pld(io.rec, I(ES_KQ + Bc)), all); lds.cst(C_KV + Bc, B::pld(io.rec, I(ES_KV + Bc)), all);
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      st.wl[Dd] = B::pld(io.rec, lo + (ES_WS + Dd));
+      st.ql[Dd] = has_qv ? B::pld(qin, lo + Dd) : ldc(cp_env_qinit, lo + Dd);
+      st.vl[Dd] = has_qv ? B::pld(vin, lo + Dd) : D(0.0);
+      lds.cst(C_QST + Dd, st.ql[Dd], all);
+      lds.cst(C_KQ + 3 + Dd, B::pld(io.rec, lo + (ES_KQ + Dd)), all); lds.cst(C_KV + 3 + Dd, B::pld(io.rec, lo + (ES_KV + Dd)), all);
+    });
+    lds.cst(C_TIME, D(0.0), all);
+    lds.cst(C_A2, D(0.0), all);
+    SubOut so;
+    substep<1, HF>(lds, st, true, want, false, so, hf);
+    const M ovf = want & so.overflow;
+    const M live = want & !ovf;
+    o.pend = B::seli(ovf, I(1), I(0));
+    o.niter = so.niter;
+    o.do_reset = live; o.bad = (want & !want); o.set_state = o.bad;
+    if (cfg.want_obs) {
+      const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
+      D body[4], foot[4];
+      D kqb[3], kql[5], kvb[3], kvl[5];
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; kqb[Bc] = fix_kin ? st.qb[Bc] : lds.cld(C_KQ + Bc); kvb[Bc] = fix_kin ? st.vb[Bc] : lds.cld(C_KV + Bc); });
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; kql[Dd] = fix_kin ? st.ql[Dd] : lds.cld(C_KQ + 3 + Dd); kvl[Dd] = fix_kin ? st.vl[Dd] : lds.cld(C_KV + 3 + Dd); });
+      opstate(kqb, kql, kvb, kvl, body, foot);
+      D ob[5], of[6];
+      ob[0] = body[1]; ob[1] = st.qb[2]; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
+      of[0] = foot[0] - body[0]; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
+      lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(Ii), ob[Ii], live & left); });
+      lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, leg * 6 + (5 + Ii), of[Ii], live); });
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), live & !left); });
+    }
+    // ---- state write-back (what store_state of the wave-per-environment reset kernel writes: q, v, warm start, qstate, clock, iteration
+    // count, cold start of the OSC QP; ctrl and the setState copies stay)
+    lfor<0, 3>([&](auto bb) {
+      constexpr int Bc = decltype(bb)::value;
+      const M lv = live & left;
+      B::pst(io.rec, I(ES_Q + Bc), st.qb[Bc], lv); B::pst(io.rec, I(ES_V + Bc), st.vb[Bc], lv); B::pst(io.rec, I(ES_WS + Bc), st.wb[Bc], lv);
+      B::pst(io.rec, I(ES_QSTATE + Bc), st.qb[Bc], lv);
+    });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      B::pst(io.rec, lo + (ES_Q + Dd), st.ql[Dd], live); B::pst(io.rec, lo + (ES_V + Dd), st.vl[Dd], live); B::pst(io.rec, lo + (ES_WS + Dd), st.wl[Dd], live);
+      B::pst(io.rec, lo + (ES_QSTATE + Dd), st.ql[Dd], live);
+    });
+    B::pst(io.rec, I(ES_TIME), D(0.0), live & left);
+    B::pst(io.rec, I(ES_NITER), B::toD(o.niter), live & left);
+    B::pst(io.rec, I(ES_QPWSET), D(0.0), live & left);
+  }
+
   // ------------------------------------------------------------------------------------------------ fused Env.step
   // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (StepOsc / StepJacobian:
   // the controller kernel wrote them).  valid: the lane's environment exists.  One loop, ONE copy of the substep code: passes

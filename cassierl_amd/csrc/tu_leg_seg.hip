@@ -15,5 +15,9 @@ void step_leg_segment(int mode, int n_envs, hipStream_t s, const VecParams& p, i
   else hipLaunchKernelGGL((leg::env_step_leg_seg_kernel<2>), grid, block, 0, s, p, pending, gone, seg);
 }
 
+void reset_leg(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask, const double* qpos, const double* qvel, uint8_t* need_slow) {
+  hipLaunchKernelGGL(leg::env_reset_leg_kernel, dim3((n_envs + 31) / 32), dim3(64), 0, s, p, mask, qpos, qvel, need_slow);
+}
+
 }  // namespace launch
 }  // namespace cassie

@@ -519,3 +519,47 @@ def test_error_behaviour_of_the_batched_abi(vec):
     assert L.CassieVecStandingStep(env.h, 0, a.data_ptr(), a.data_ptr(), 1) != 0  # scripted controllers exist for OSC / Jacobian only
     assert L.CassieVecNumEnvs(env.h) == 4 and L.CassieVecActionDim(env.h) == 6
     env.close()
+
+
+def test_packed_reset_kernel_agrees_with_the_wave_per_environment_reset(vec, monkeypatch):
+    """CassieVecReset / CassieVecResetTo run the two-lanes-per-environment core (32 environments per wavefront; r04) and leave a state with
+    more than 8 rows on a leg to the wave-per-environment reset kernel (CASSIE2D_RESET_PACKED=0: that kernel for everyone).  Same records
+    and observations from both on: the reset pose, random poses around it, robots pushed into the floor and into their joint limits
+    (which take the slow path), a mask; environments outside the mask untouched to the bit."""
+    import torch
+    rng = np.random.default_rng(31)
+    n = 333
+    qinit = np.array([0.0, 0.939, 0.0, 0.0, 0.0, 0.0, 0.0, 0.68111815, -1.40730357, 1.62972042, -1.77611107, -0.61968407, 0.0])
+    recs, obss = [], []
+    for packed in ("1", "0"):
+        monkeypatch.setenv("CASSIE2D_RESET_PACKED", packed)
+        e = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False)
+        e.reset_host()
+        q0, _ = e.get_state_host()
+        r = np.random.default_rng(32)
+        for t in range(3):   # stale ctrl / warm start / setState copies that differ per environment
+            e.step_host(r.uniform(-1, 1, (n, 6)) * TQ)
+        q, v = e.get_state_host()
+        qn = q0 + rng.normal(0, 0.08, (n, 13)) if packed == "1" else qn
+        vn = rng.normal(0, 0.5, (n, 13)) if packed == "1" else vn
+        if packed == "1":
+            qn[::7, 1] = 0.35                                  # pelvis near the floor: many contacts
+            qn[3::11, 3:] += rng.normal(0, 0.8, (len(qn[3::11]), 10))   # joints far outside their ranges: limits
+            mask = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+        dev = "cuda:0"
+        out = e.alloc()
+        pre = e.get_full_state_host()
+        obs = e.reset_to(torch.as_tensor(qn, device=dev), torch.as_tensor(vn, device=dev), out, mask=torch.as_tensor(mask, device=dev)).cpu().numpy().copy()
+        before = e.get_full_state_host()
+        assert np.array_equal(before[mask == 0], pre[mask == 0])   # outside the mask: untouched to the bit
+        obs2 = e.reset(out, mask=torch.as_tensor(1 - mask, device=dev)).cpu().numpy().copy()   # the others: to the reset pose
+        recs.append((before, e.get_full_state_host())); obss.append((obs, obs2))
+        e.close()
+    monkeypatch.delenv("CASSIE2D_RESET_PACKED")
+    (b1, a1), (b0, a0) = recs
+    assert np.isfinite(a1).all()
+    np.testing.assert_allclose(b1, b0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(a1, a0, rtol=0, atol=1e-8)
+    m = mask.astype(bool)
+    np.testing.assert_allclose(obss[0][0][m], obss[1][0][m], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(obss[0][1][~m], obss[1][1][~m], rtol=0, atol=1e-9)
