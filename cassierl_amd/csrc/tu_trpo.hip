@@ -32,7 +32,7 @@ namespace cassie_trpo {
 constexpr int H = 32;         // hidden units (both layers)
 constexpr int TP = 36;        // floats per row of a transpose tile (16-byte aligned rows; ds_read_b128 of 16 lanes conflict-free)
 constexpr int WAVES = 4;      // wavefronts per workgroup: one per SIMD
-constexpr int MAX_BLOCKS = 256;
+constexpr int MAX_BLOCKS = 512;   // two workgroups of four wavefronts per CU
 
 template <int D, int A> struct Shape {
   static constexpr int NP = H * D + H + H * H + H + A * H + A;
@@ -54,42 +54,55 @@ __device__ __forceinline__ void wave_lds_sync() {   // a wavefront's LDS accesse
 }
 
 // FVP: w = S J dir (forward mode) per sample; otherwise w comes from memory.  Then J' w, accumulated per wavefront.
+// The A operands (weights in k-step order, see the header) are the same for every tile and every wavefront: the workgroup lays them
+// out ONCE in LDS as [quad of k-steps][lane] float4 images (29 quads, 29.7 KB) and a wavefront reads the four quads of a product right
+// before its 16 MFMAs -- conflict-free ds_read_b128, 29 per tile.  Holding them in registers instead (110 per lane, the first build of
+// this kernel) costs the second wavefront per SIMD: with two, one wavefront's tanh / transposes run under the other's MFMAs
+// (0.134 -> see DESIGN.md section 8 ms per product at 524 288 samples).
+enum { Q_W1 = 0, Q_DW1 = 4, Q_W2 = 8, Q_DW2 = 12, Q_W3 = 16, Q_DW3 = 20, Q_W2T = 24, Q_W3T = 28, Q_N = 29 };
 template <int D, int A, bool FVP>
-__global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __restrict__ obs, int n, Net th, Net dir, const float* __restrict__ prec, float scale,
+__global__ void __launch_bounds__(64 * WAVES, 2) trpo_kernel(const float* __restrict__ obs, int n, Net th, Net dir, const float* __restrict__ prec, float scale,
                                                          const float* __restrict__ wext, float* __restrict__ partial) {
   typedef Shape<D, A> S;
   static_assert(D < 32 && A <= 8, "a column of ones next to the observations; the cotangent rows in registers 0..3 of the two lane halves");
   constexpr int KS1 = (D + 1) / 2;   // k-steps of the first layer (k = 2 s + h)
   __shared__ alignas(16) float tile[WAVES][2][32 * TP];
   __shared__ alignas(16) float sbias[5][32];   // b1, b2, db1, db2, db3 (zero padded)
+  __shared__ float4 wimg[Q_N][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   if (tid < 32) {
     sbias[0][tid] = th.b1[tid]; sbias[1][tid] = th.b2[tid];
     sbias[2][tid] = FVP ? dir.b1[tid] : 0.0f; sbias[3][tid] = FVP ? dir.b2[tid] : 0.0f; sbias[4][tid] = (FVP && tid < A) ? dir.b3[tid] : 0.0f;
   }
-  // ---- A operands, once per wavefront: lane (i = c, h) holds column k of row i for every k-step
-  float aW1[KS1], adW1[KS1], aW2[16], adW2[16], aW3[16], adW3[16], aW2T[16], aW3T[4], pr[4];
+  // ---- A operands, once per workgroup: element e of quad q = k-step 4 (q mod 4) + e of its matrix, for lane (i = c, h)
+  for (int q = wave; q < Q_N; q += WAVES) {
+    float v4[4];
 #pragma unroll
-  for (int s = 0; s < KS1; s++) {
-    const int k = 2 * s + h;
-    aW1[s] = k < D ? th.W1[c * D + k] : 0.0f;
-    adW1[s] = (FVP && k < D) ? dir.W1[c * D + k] : 0.0f;
+    for (int e = 0; e < 4; e++) {
+      const int st = 4 * (q & 3) + e;                       // k-step within the matrix
+      const int r = (st & 3) + 8 * (st >> 2) + 4 * h;       // accumulator-order row of that step (layers 2, 3 and the transposes)
+      const int k1 = 2 * st + h;                            // first layer: k = 2 s + h
+      float x = 0.0f;
+      if (q < Q_DW1) x = (st < KS1 && k1 < D) ? th.W1[c * D + k1] : 0.0f;
+      else if (q < Q_W2) x = (FVP && st < KS1 && k1 < D) ? dir.W1[c * D + k1] : 0.0f;
+      else if (q < Q_DW2) x = th.W2[c * H + r];
+      else if (q < Q_W3) x = FVP ? dir.W2[c * H + r] : 0.0f;
+      else if (q < Q_DW3) x = c < A ? th.W3[c * H + r] : 0.0f;
+      else if (q < Q_W2T) x = (FVP && c < A) ? dir.W3[c * H + r] : 0.0f;
+      else if (q < Q_W3T) x = th.W2[r * H + c];
+      else x = (e + 4 * h < A) ? th.W3[(e + 4 * h) * H + c] : 0.0f;   // W3': cotangent row a = v + 4 h
+      v4[e] = x;
+    }
+    wimg[q][lane] = make_float4(v4[0], v4[1], v4[2], v4[3]);
   }
+  float pr[4];
 #pragma unroll
-  for (int v = 0; v < 16; v++) {
-    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
-    aW2[v] = th.W2[c * H + r]; aW2T[v] = th.W2[r * H + c];
-    adW2[v] = FVP ? dir.W2[c * H + r] : 0.0f;
-    aW3[v] = c < A ? th.W3[c * H + r] : 0.0f;
-    adW3[v] = (FVP && c < A) ? dir.W3[c * H + r] : 0.0f;
-  }
-#pragma unroll
-  for (int v = 0; v < 4; v++) {
-    const int a = v + 4 * h;
-    aW3T[v] = a < A ? th.W3[a * H + c] : 0.0f;
-    pr[v] = (FVP && a < A) ? prec[a] * scale : 0.0f;
-  }
+  for (int v = 0; v < 4; v++) { const int a = v + 4 * h; pr[v] = (FVP && a < A) ? prec[a] * scale : 0.0f; }
   __syncthreads();
+  auto aop = [&](int q0, float (&a)[16]) {   // the 16 k-steps of a product
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const float4 w = wimg[q0 + q][lane]; a[4 * q] = w.x; a[4 * q + 1] = w.y; a[4 * q + 2] = w.z; a[4 * q + 3] = w.w; }
+  };
   auto bias_tile = [&](int which) {   // C operand: bias[r(v, h)] in register v (rows 8 g + 4 h .. + 3 are one float4)
     v16f z;
 #pragma unroll
@@ -121,7 +134,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __rest
     const int s0 = tl * 32, smp = s0 + c;
     const bool valid = smp < n;
     // observations: as the B operand of the first layer (sample on the lane) and transposed (feature on the lane; column D = ones)
-    float xb[KS1], xt[16];
+    float xb[KS1], xt[16], aw[16];
 #pragma unroll
     for (int s = 0; s < KS1; s++) { const int k = 2 * s + h; xb[s] = (valid && k < D) ? obs[(size_t)smp * D + k] : 0.0f; }
 #pragma unroll
@@ -130,37 +143,43 @@ __global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __rest
       xt[s] = c < D ? (sm < n ? obs[(size_t)sm * D + c] : 0.0f) : (c == D ? 1.0f : 0.0f);
     }
     v16f h1 = bias_tile(0);
+    aop(Q_W1, aw);
 #pragma unroll
-    for (int s = 0; s < KS1; s++) h1 = TRPO_MFMA(aW1[s], xb[s], h1);
+    for (int s = 0; s < KS1; s++) h1 = TRPO_MFMA(aw[s], xb[s], h1);
     v16f wt;   // cotangent on the mean, rows a = v + 4 h in registers v = 0 .. 3
     v16f d1;
     if (FVP) {
       d1 = bias_tile(2);
+      aop(Q_DW1, aw);
 #pragma unroll
-      for (int s = 0; s < KS1; s++) d1 = TRPO_MFMA(adW1[s], xb[s], d1);
+      for (int s = 0; s < KS1; s++) d1 = TRPO_MFMA(aw[s], xb[s], d1);
     }
 #pragma unroll
     for (int v = 0; v < 16; v++) h1[v] = tanh_fast(h1[v]);
     v16f h2 = bias_tile(1);
+    aop(Q_W2, aw);
 #pragma unroll
-    for (int v = 0; v < 16; v++) h2 = TRPO_MFMA(aW2[v], h1[v], h2);
+    for (int v = 0; v < 16; v++) h2 = TRPO_MFMA(aw[v], h1[v], h2);
     if (FVP) {
       v16f d2 = bias_tile(3);
 #pragma unroll
-      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(adW2[v], h1[v], d2);
-#pragma unroll
       for (int v = 0; v < 16; v++) d1[v] *= 1.0f - h1[v] * h1[v];
 #pragma unroll
-      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(aW2[v], d1[v], d2);
+      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(aw[v], d1[v], d2);   // W2 dH1
+      aop(Q_DW2, aw);
+#pragma unroll
+      for (int v = 0; v < 16; v++) d2 = TRPO_MFMA(aw[v], h1[v], d2);   // + dW2 H1
 #pragma unroll
       for (int v = 0; v < 16; v++) h2[v] = tanh_fast(h2[v]);
       v16f dm = bias_tile(4);
+      aop(Q_DW3, aw);
 #pragma unroll
-      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(adW3[v], h2[v], dm);
+      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(aw[v], h2[v], dm);
 #pragma unroll
       for (int v = 0; v < 16; v++) d2[v] *= 1.0f - h2[v] * h2[v];
+      aop(Q_W3, aw);
 #pragma unroll
-      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(aW3[v], d2[v], dm);
+      for (int v = 0; v < 16; v++) dm = TRPO_MFMA(aw[v], d2[v], dm);
 #pragma unroll
       for (int v = 0; v < 16; v++) wt[v] = (v < 4 && valid) ? dm[v] * pr[v] : 0.0f;
     } else {
@@ -173,12 +192,15 @@ __global__ void __launch_bounds__(64 * WAVES, 1) trpo_kernel(const float* __rest
     v16f g2, g1;
 #pragma unroll
     for (int v = 0; v < 16; v++) { g2[v] = 0.0f; g1[v] = 0.0f; }
-#pragma unroll
-    for (int v = 0; v < 4; v++) g2 = TRPO_MFMA(aW3T[v], wt[v], g2);
+    {
+      const float4 w = wimg[Q_W3T][lane];
+      g2 = TRPO_MFMA(w.x, wt[0], g2); g2 = TRPO_MFMA(w.y, wt[1], g2); g2 = TRPO_MFMA(w.z, wt[2], g2); g2 = TRPO_MFMA(w.w, wt[3], g2);
+    }
 #pragma unroll
     for (int v = 0; v < 16; v++) g2[v] *= 1.0f - h2[v] * h2[v];
+    aop(Q_W2T, aw);
 #pragma unroll
-    for (int v = 0; v < 16; v++) g1 = TRPO_MFMA(aW2T[v], g2[v], g1);
+    for (int v = 0; v < 16; v++) g1 = TRPO_MFMA(aw[v], g2[v], g1);
 #pragma unroll
     for (int v = 0; v < 16; v++) g1[v] *= 1.0f - h1[v] * h1[v];
     // ---- parameter gradients: products over the sample index, operands transposed through the wavefront's LDS tiles
