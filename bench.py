@@ -426,6 +426,25 @@ def extra_workloads(traj, n):
         row.update(e3.counters())
     e3.close()
     rows.append(row)
+    # (e) configs[3]'s caller: the TRPO outer loop of trpo_cassie.py on the batched environment (walk env / PD, `n` envs x 8 steps per
+    #     iteration; policy step, sampler, returns / baseline, Fisher-vector products and line search as HIP kernels)
+    try:
+        from cassierl_amd import trpo as T
+        from cassierl_amd.trajectory import default_gait
+        algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", trajectory=default_gait(), batch_size=n * 8)
+        for _ in range(4):
+            algo.train_iteration()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            st = algo.train_iteration()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        algo.env.close()
+        rows.append(dict(workload="trpo_outer_loop_walk_pd", note="TRPO iterations (rollout of 8 Env.steps + update) on %d envs; env-steps of the rollouts per second of the whole loop" % n,
+                         envs=n, iterations=6, env_steps_per_s=6 * n * 8 / dt, ms_per_iteration=dt / 6 * 1e3, kl=st.get("kl"), backtracks=st.get("backtracks")))
+    except Exception as ex:
+        rows.append(dict(workload="trpo_outer_loop_walk_pd", error=repr(ex)))
     return rows
 
 
