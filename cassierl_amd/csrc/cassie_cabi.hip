@@ -57,7 +57,10 @@ struct CassieVec {
   int side_mode = -1;                        // CASSIE2D_SIDE_BY_SIDE=0/1 (tests): never / always run the lower tiers side by side; -1: by the hint
   // the Env.step in segments while robots are down (launch_physics_tiers): per segment the hand-over lists, two streams, three events
   static constexpr int NSEG = 4;
-  bool seg_on = true;                        // CASSIE2D_SEGMENTS=0: the one-launch order (A/B, tests)
+  int seg_mode = -1;                         // CASSIE2D_SEGMENTS=0/1 (A/B, tests): never / always in segments while robots are down; -1: by the count below
+  unsigned* pend_hint = nullptr;             // pinned host words [64]: estimated environments that left the first tier in launch serial & 63 (classify_pending_kernel)
+  unsigned* pend_hint_dev = nullptr;
+  unsigned pend_rate = 0;                    // hand-overs per launch, estimated from the last 48 launches' words
   bool reset_packed = true;                  // CASSIE2D_RESET_PACKED=0: CassieVecReset with one wavefront per environment only (A/B, tests)
   uint8_t* need_slow = nullptr;              // [n] written by the packed reset kernel: environments the wave-per-environment reset takes
   bool seg_ready = false, seg_failed = false;
@@ -89,6 +92,7 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
+constexpr unsigned SEG_MIN_HANDOVERS = 96;   // hand-overs per launch from which the Env.step runs in segments (launch_physics_tiers)
 constexpr int LEG_MIN_ENVS = 6144;   // measured crossover (r03, bench workload): 4096 envs 0.63 ms (g16 tier) vs 0.75 ms (leg tier), 8192 envs 0.83 vs 0.74 ms
 constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
@@ -140,6 +144,17 @@ bool seg_resources(CassieVec* h) {
 void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) {
   cassie::VecParams p = pin;
   p.deep_hint = h->deep_hint_dev; p.serial = (int)++h->serial;   // the kernels only store the word; the comparison below is unsigned
+  p.pend_hint = h->pend_hint_dev;
+  if (h->pend_hint) {
+    // estimated hand-overs of the recent launches, one pinned word per launch (ring of 64, read without synchronisation: a stale value
+    // changes the schedule, never a result).  The host runs many launches ahead of the device, so the words of the newest launches
+    // are still empty: the statistic is the SUM over the last 48 launches (the ones executed by now carry it), compared with what
+    // 48 launches of SEG_MIN_HANDOVERS / 3 would give -- i.e. it tolerates two thirds of the window not having run yet.
+    unsigned sum = 0;
+    for (unsigned k = 1; k <= 48; k++) sum += ((volatile unsigned*)h->pend_hint)[(h->serial - k) & 63];
+    h->pend_rate = sum / 16;
+    ((volatile unsigned*)h->pend_hint)[h->serial & 63] = 0;   // this launch's word (last used 64 launches ago)
+  }
   cassie::VecParams p2 = p, p3 = p;
   p3.pending = h->pending; p3.pending_pick = cassie::PICK_ALL;
   // A handed-down environment costs its remaining substeps end to end whatever the batch size (~0.09 ms per substep in the middle
@@ -156,7 +171,11 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   const bool side_by_side = h->leg && (h->side_mode >= 0 ? h->side_mode == 1 : (h->deep_hint && h->serial - (unsigned)*(volatile int*)h->deep_hint <= 32u));
   // fork: the side stream waits for the first tier.  If the event cannot be recorded / waited for, fall back to the one-stream order
   // below (same results) rather than let the side stream's kernel run concurrently with the first tier on the same records.
-  if (side_by_side && h->seg_on && p.n_sub >= 4 && !p.debug && seg_resources(h)) {
+  // in segments only while MANY robots are down: the three extra launches of the first tier cost ~3 % of a step, and a handful of
+  // hand-overs is a short tail (r04, alternating A/B at 65 536 envs: all-fallen floor 15.5 -> 17.0 M with ~270 hand-overs per step;
+  // stand_torque_random 22.4 -> 21.6 M when forced; by this rule 22.7 M / 16.9 M)
+  const bool segments = h->seg_mode >= 0 ? h->seg_mode == 1 : h->pend_rate >= SEG_MIN_HANDOVERS;
+  if (side_by_side && segments && !h->seg_failed && p.n_sub >= 4 && !p.debug && seg_resources(h)) {
     // ---- the Env.step in segments (r04).  A robot that is down costs its substeps end to end (~0.13 ms each) in the lower tiers,
     // and in the order below these only start when the first tier has finished ALL its substeps: 1.4 ms of first tier + up to
     // 1.3 ms of tail.  Here the first tier runs the step as a first segment of ONE substep and up to three more of equal length;
@@ -170,7 +189,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     len[nseg++] = 1;
     for (int parts = CassieVec::NSEG - 1; parts > 0; parts--) { const int l = (left + parts - 1) / parts; if (l > 0) { len[nseg++] = l; left -= l; } }
     int later = p.n_sub;
-    bool ok = true;
+    bool forked[CassieVec::NSEG] = {};
     for (int j = 0; j < nseg; j++) {
       later -= len[j];
       cassie::VecParams ps = p;
@@ -178,27 +197,28 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
       if (j != nseg - 1) { ps.obs = nullptr; ps.terminal_obs = nullptr; }
       L2::step_leg_segment(mode, h->n, h->stream, ps, h->seg_pend[j], h->gone, j == 0, later);
       L2::classify_pending(h->n, h->stream, p, h->seg_pend[j]);
-      ok = ok && hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess && hipStreamWaitEvent(h->seg_deep[j], h->seg_fork[j], 0) == hipSuccess &&
-           hipStreamWaitEvent(h->seg_shal[j], h->seg_fork[j], 0) == hipSuccess;
-      if (!ok) break;
+      // the segment's hand-overs on its own two streams; if the fork cannot be set up (or one failed before), on the caller's stream,
+      // one after the other: the same kernels on the same data, only without the overlap
+      const bool fork = !h->seg_failed && hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess &&
+                        hipStreamWaitEvent(h->seg_deep[j], h->seg_fork[j], 0) == hipSuccess && hipStreamWaitEvent(h->seg_shal[j], h->seg_fork[j], 0) == hipSuccess;
+      if (!fork) h->seg_failed = true;
+      hipStream_t sd = fork ? h->seg_deep[j] : h->stream, ss = fork ? h->seg_shal[j] : h->stream;
       cassie::VecParams pd = p, pa = p, pb = p;
       pd.pending = h->seg_pend[j]; pd.pending_pick = cassie::PICK_DEEP;
-      L2::step_k1(mode, L2::K1_DEEP, h->n, h->seg_deep[j], pd, L2::K1_HANDOVER_SPLIT);
+      L2::step_k1(mode, L2::K1_DEEP, h->n, sd, pd, L2::K1_HANDOVER_SPLIT);
       pa.pending = h->seg_pend[j]; pa.pending_pick = cassie::PICK_SHALLOW;
-      L2::step_g16(mode, h->n, h->seg_shal[j], pa, h->seg_pend2[j]);
+      L2::step_g16(mode, h->n, ss, pa, h->seg_pend2[j]);
       pb.pending = h->seg_pend2[j]; pb.pending_pick = cassie::PICK_ALL;
-      L2::step_k1(mode, L2::K1_DEEP, h->n, h->seg_shal[j], pb, L2::K1_HANDOVER_SPLIT);
-      ok = ok && hipEventRecord(h->seg_join_a[j], h->seg_deep[j]) == hipSuccess && hipEventRecord(h->seg_join_b[j], h->seg_shal[j]) == hipSuccess;
-      if (!ok) break;
+      L2::step_k1(mode, L2::K1_DEEP, h->n, ss, pb, L2::K1_HANDOVER_SPLIT);
+      forked[j] = fork;
     }
-    for (int j = 0; j < nseg && ok; j++)
-      ok = hipStreamWaitEvent(h->stream, h->seg_join_a[j], 0) == hipSuccess && hipStreamWaitEvent(h->stream, h->seg_join_b[j], 0) == hipSuccess;
-    if (!ok) {   // an event could not be recorded / waited for: finish everything in order, the hard way (same results)
-      for (int j = 0; j < nseg; j++) { hipStreamSynchronize(h->seg_deep[j]); hipStreamSynchronize(h->seg_shal[j]); }
-      hipStreamSynchronize(h->stream);
-      h->seg_failed = true;   // ... and stay with the one-launch order from now on
-      // (segments launched before the failure are complete; the remaining substeps of everyone are the caller's to redo only if
-      // the launch of a segment itself failed, which hipGetLastError reports to the caller as before)
+    for (int j = 0; j < nseg; j++) {   // join: the caller's stream continues behind every segment's lower tiers
+      if (!forked[j]) continue;
+      if (hipEventRecord(h->seg_join_a[j], h->seg_deep[j]) != hipSuccess || hipEventRecord(h->seg_join_b[j], h->seg_shal[j]) != hipSuccess ||
+          hipStreamWaitEvent(h->stream, h->seg_join_a[j], 0) != hipSuccess || hipStreamWaitEvent(h->stream, h->seg_join_b[j], 0) != hipSuccess) {
+        hipStreamSynchronize(h->seg_deep[j]); hipStreamSynchronize(h->seg_shal[j]);   // the hard way
+        h->seg_failed = true;
+      }
     }
     return;
   }
@@ -386,7 +406,10 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
-  { const char* e = getenv("CASSIE2D_SEGMENTS"); if (e && e[0] == '0') h->seg_on = false; }
+  { const char* e = getenv("CASSIE2D_SEGMENTS"); if (e && (e[0] == '0' || e[0] == '1')) h->seg_mode = e[0] - '0'; }
+  if (hipHostMalloc((void**)&h->pend_hint, 64 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
+  for (int k = 0; k < 64; k++) h->pend_hint[k] = 0;
+  if (hipHostGetDevicePointer((void**)&h->pend_hint_dev, h->pend_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_RESET_PACKED"); if (e && e[0] == '0') h->reset_packed = false; }
   if (hipMalloc(&h->need_slow, n) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
@@ -421,6 +444,7 @@ void CassieVecFree(CassieVec* h) {
   }
   hipFree(h->gone); hipFree(h->need_slow);
   if (h->deep_hint) hipHostFree(h->deep_hint);
+  if (h->pend_hint) hipHostFree(h->pend_hint);
   delete h;
 }
 
@@ -750,28 +774,32 @@ void launch3d(Cassie3dVec* h, cassie3d::Params3 p) {
     // per substep in the lower tiers against ~0.5 ms per substep of the first tier's own chain, so all but the last segment's
     // hand-overs are off the step's critical path (16 384 envs: 0.26 ms of tail per step -> 0.0x).
     int later = p.n_sub;
-    bool ok = true;
-    for (int j = 0; j < Cassie3dVec::NSEG && ok; j++) {
+    bool forked[Cassie3dVec::NSEG] = {};
+    for (int j = 0; j < Cassie3dVec::NSEG; j++) {
       const int len = (later + (Cassie3dVec::NSEG - j) - 1) / (Cassie3dVec::NSEG - j);
       later -= len;
       cassie3d::Params3 ps = p;
       ps.n_sub = len; ps.pending_in = nullptr; ps.pending_out = h->seg_pend[j];
       ps.gone = h->gone; ps.seg_first = j == 0; ps.seg_later = later;
       L3::step3d(h->leg_full ? 4 : 3, h->n, h->stream, ps);
-      ok = hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess && hipStreamWaitEvent(h->seg_side[j], h->seg_fork[j], 0) == hipSuccess;
-      if (!ok) break;
+      // the segment's hand-overs on its own stream; if the fork cannot be set up (or one failed before), on the caller's stream
+      // behind the segment: the same kernels on the same data, only without the overlap
+      const bool fork = h->seg_on && hipEventRecord(h->seg_fork[j], h->stream) == hipSuccess && hipStreamWaitEvent(h->seg_side[j], h->seg_fork[j], 0) == hipSuccess;
+      if (!fork) h->seg_on = false;   // (this step is finished in segments, in order; the next ones in one launch)
+      hipStream_t ss = fork ? h->seg_side[j] : h->stream;
       cassie3d::Params3 pa = p, pb = p;
       pa.pending_in = h->seg_pend[j]; pa.pending_out = h->seg_pend2[j];
-      L3::step3d(0, h->n, h->seg_side[j], pa);
+      L3::step3d(0, h->n, ss, pa);
       pb.pending_in = h->seg_pend2[j]; pb.pending_out = nullptr;
-      L3::step3d(1, h->n, h->seg_side[j], pb);
-      ok = hipEventRecord(h->seg_join[j], h->seg_side[j]) == hipSuccess;
+      L3::step3d(1, h->n, ss, pb);
+      forked[j] = fork;
     }
-    for (int j = 0; j < Cassie3dVec::NSEG && ok; j++) ok = hipStreamWaitEvent(h->stream, h->seg_join[j], 0) == hipSuccess;
-    if (!ok) {   // an event could not be recorded / waited for: finish in order the hard way and stay with one launch from now on
-      for (int j = 0; j < Cassie3dVec::NSEG; j++) hipStreamSynchronize(h->seg_side[j]);
-      hipStreamSynchronize(h->stream);
-      h->seg_on = false;
+    for (int j = 0; j < Cassie3dVec::NSEG; j++) {
+      if (!forked[j]) continue;
+      if (hipEventRecord(h->seg_join[j], h->seg_side[j]) != hipSuccess || hipStreamWaitEvent(h->stream, h->seg_join[j], 0) != hipSuccess) {
+        hipStreamSynchronize(h->seg_side[j]);   // join the hard way
+        h->seg_on = false;
+      }
     }
     return;
   }

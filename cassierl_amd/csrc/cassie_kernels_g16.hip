@@ -728,7 +728,11 @@ __global__ void __launch_bounds__(64, 2) classify_pending_kernel(VecParams p, in
   const int env = blockIdx.x * 4 + g;
   const bool valid = env < p.n_envs;
   const int left = valid ? (pending[env] & PENDING_COUNT) : 0;
-  if (__ballot(left > 0) == 0) return;
+  const unsigned long long some = __ballot(left > 0 && l == 0);
+  if (some == 0) return;
+  // how many left the first tier, for the host's choice of schedule: an ESTIMATE from every 64th workgroup (an atomic on host memory
+  // costs microseconds: counted by every workgroup, 270 hand-overs per step cost the all-fallen floor 7 %)
+  if (lane == 0 && p.pend_hint && (blockIdx.x & 63) == 0) __hip_atomic_fetch_add(p.pend_hint + (p.serial & 63), 64u * (unsigned)__popcll(some), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   EnvLds& sm = sm4[g];
   const double* st = p.state + (valid ? (size_t)env : 0) * ENV_STRIDE;
   LaneConst c;
