@@ -28,8 +28,8 @@ EXPORTS = [
     "Cassie3dVecReset", "Cassie3dVecStep", "Cassie3dVecStatePtr", "Cassie3dVecGetCounters", "Cassie3dVecResetCounters", "Cassie3dVecStepHost", "Cassie3dVecGetStateHost",
     "Cassie3dVecSetStateHost", "Cassie3dVecDebugForwardHost", "Cassie3dVecTimeSteps",
     # fused policy kernels of the TRPO outer loop (include/cassie_trpo.h)
-    "CassieTrpoParamCount", "CassieTrpoPartialRows", "CassieTrpoFvp", "CassieTrpoVjp", "CassieTrpoSurrogate", "CassieTrpoPolicyStep", "CassieTrpoSamplerRows", "CassieTrpoSamplerStep",
-    "CassieTrpoBaselineFeatures", "CassieTrpoBaselinePredict", "CassieTrpoReturnsAdvantages", "CassieTrpoGramRows", "CassieTrpoGramRowSize", "CassieTrpoBaselineGram",
+    "CassieTrpoParamCount", "CassieTrpoPartialRows", "CassieTrpoFvp", "CassieTrpoVjp", "CassieTrpoSurrogate", "CassieTrpoCgUpdate", "CassieTrpoPolicyStep", "CassieTrpoSamplerRows", "CassieTrpoSamplerStep",
+    "CassieTrpoBaselineFeatures", "CassieTrpoBaselinePredict", "CassieTrpoReturnsAdvantages", "CassieTrpoGramRows", "CassieTrpoGramRowSize", "CassieTrpoBaselineGram", "CassieTrpoRidgeSolve",
 ]
 
 

@@ -402,6 +402,63 @@ __global__ void __launch_bounds__(256) sampler_step_kernel(const double* __restr
   if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- CG vector step
+// What rllab's conjugate gradient (rllab/misc/krylov.py: cg) does between two Fisher-vector products, on the ~2 k-entry parameter
+// vector, in one workgroup: F p from the mean network's part (summed over wavefronts and ranks by the caller) + the log-std block +
+// the damping, step length, x and r updates, new residual, early exit as a frozen step length (no host read-back), new direction.
+// As torch operations: ~15 launches per iteration, a third of what an iteration costs next to the 0.12 ms product.
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) t += red[i];   // every thread adds the 16 wavefront sums in the same order
+  return t;
+}
+__global__ void __launch_bounds__(1024) cg_update_kernel(int n, int ls_off, int n_ls, const float* __restrict__ Apm, const float* __restrict__ hls, float reg,
+                                                        float tol, float* __restrict__ x, float* __restrict__ r, float* __restrict__ p, float* __restrict__ scal) {
+  __shared__ float red[16];
+  constexpr int PER = 3;   // n <= 3072
+  float pv[PER], ap[PER], rv[PER];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = threadIdx.x + 1024 * k;
+    pv[k] = 0.0f; ap[k] = 0.0f; rv[k] = 0.0f;
+    if (i < n) {
+      pv[k] = p[i]; rv[k] = r[i];
+      const bool ls = i >= ls_off && i < ls_off + n_ls;
+      const float f = ls ? hls[i - ls_off] * pv[k] : Apm[i < ls_off ? i : i - n_ls];
+      ap[k] = f + reg * pv[k];
+      s += pv[k] * ap[k];
+    }
+  }
+  const float pAp = block_sum_1024(s, red);
+  const float rr = scal[0];
+  const bool running = scal[1] != 0.0f;
+  const float alpha = running ? rr / pAp : 0.0f;
+  s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = threadIdx.x + 1024 * k;
+    if (i < n) { x[i] += alpha * pv[k]; rv[k] -= alpha * ap[k]; r[i] = rv[k]; s += rv[k] * rv[k]; }
+  }
+  const float rr_new = block_sum_1024(s, red);
+  const bool go_on = running && rr_new >= tol;
+  const float beta = go_on ? rr_new / rr : 0.0f;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = threadIdx.x + 1024 * k;
+    if (i < n) p[i] = rv[k] + beta * pv[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { scal[0] = rr_new; scal[1] = go_on ? 1.0f : 0.0f; }
+}
+
 inline int blocks_for(int n) {
   const int tiles = (n + 31) / 32;
   int b = (tiles + WAVES - 1) / WAVES;
@@ -459,6 +516,13 @@ int CassieTrpoSurrogate(const float* obs_dev, int n, int obs_dim, int act_dim, c
   else if (obs_dim == 17 && act_dim == 6) hipLaunchKernelGGL((surrogate_kernel<17, 6>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
   else if (obs_dim == 17 && act_dim == 7) hipLaunchKernelGGL((surrogate_kernel<17, 7>), grid, block, 0, s, obs_dev, n, th, log_std_new, log_std_old, act_dev, adv_dev, old_mean_dev, partial_dev);
   else return CASSIE_EINVAL;
+  return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
+}
+
+int CassieTrpoCgUpdate(int n, int ls_off, int n_ls, const float* Ap_mean_dev, const float* hls_dev, float reg, float tol, float* x_dev, float* r_dev, float* p_dev,
+                       float* scal_dev, void* stream) {
+  if (n <= 0 || n > 3072 || ls_off < 0 || n_ls < 0 || ls_off + n_ls > n || !Ap_mean_dev || !hls_dev || !x_dev || !r_dev || !p_dev || !scal_dev) return CASSIE_EINVAL;
+  hipLaunchKernelGGL(cassie_trpo::cg_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, ls_off, n_ls, Ap_mean_dev, hls_dev, reg, tol, x_dev, r_dev, p_dev, scal_dev);
   return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
 

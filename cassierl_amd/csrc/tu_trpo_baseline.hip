@@ -24,7 +24,7 @@
 namespace cassie_trpo {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int GRAM_BLOCKS = 256, GRAM_WAVES = 4;
+constexpr int GRAM_BLOCKS = 512, GRAM_WAVES = 4;   // two wavefronts per SIMD
 
 template <int D> struct Feat {
   static constexpr int NF = 2 * D + 4;          // features
@@ -66,20 +66,28 @@ __global__ void __launch_bounds__(64 * GRAM_WAVES) gram_kernel(const float* __re
   v4d acc[Ft::NBLK];
 #pragma unroll
   for (int b = 0; b < Ft::NBLK; b++) acc[b] = (v4d){0.0, 0.0, 0.0, 0.0};
-  for (int st = s0; st < s1; st++) {
+  // the entries of Z this lane feeds in one step: NB columns of sample 4 step + k.  Loaded one step AHEAD: with one or two wavefronts
+  // per SIMD the global loads of a step would otherwise sit in front of its ten MFMAs (first build: 0.19 ms, all of it load latency).
+  auto fetch = [&](int st, double (&z)[NB]) {
     const int s = 4 * st + k;
-    const bool ok = s < m;
+    const bool ok = st < s1 && s < m;
     const size_t ss = ok ? (size_t)s : 0;
     const float al = path_clock(t[ss]);
     const double yy = y[ss];
-    double z[NB];
 #pragma unroll
     for (int r = 0; r < NB; r++) z[r] = zcol<D>(obs + ss * D, al, yy, 16 * r + f, ok);
+  };
+  double z[NB], zn[NB];
+  fetch(s0, z);
+  for (int st = s0; st < s1; st++) {
+    fetch(st + 1, zn);
     int b = 0;
 #pragma unroll
     for (int r = 0; r < NB; r++)
 #pragma unroll
       for (int c = r; c < NB; c++, b++) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], z[c], acc[b], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NB; r++) z[r] = zn[r];
   }
   // element (i = k + 4 v, j = f) of block b in register v
   double* out = partial + (size_t)wave * Ft::NBLK * 256;
@@ -155,6 +163,47 @@ __global__ void __launch_bounds__(256) predict_kernel(const float* __restrict__ 
   out[s] = value + coeffs[NF - 1];
 }
 
+// (A + reg I) x = b for the baseline's F <= 64 coefficients, A symmetric positive semi-definite: Cholesky in LDS by one wavefront (lane i
+// owns row i), forward / backward substitution, and LinearFeatureBaseline.fit's retry rule ON THE DEVICE -- if the factorisation meets a
+// non-positive pivot or the solution is not finite, the regulariser is multiplied by ten (five tries) -- so that the fit needs no host
+// read-back (as torch operations: rocSOLVER's LU + torch.isfinite(...).all() -> bool, 0.3 ms and a synchronisation per iteration).
+__global__ void __launch_bounds__(64) ridge_solve_kernel(const double* __restrict__ A, const double* __restrict__ b, int F, double reg, double* __restrict__ x) {
+  __shared__ double L[64][65];
+  __shared__ double yv[64];
+  __shared__ int bad;
+  const int i = threadIdx.x;
+  for (int attempt = 0; attempt < 5; attempt++, reg *= 10.0) {
+    if (i < F) for (int j = 0; j < F; j++) L[i][j] = A[i * F + j] + (i == j ? reg : 0.0);
+    if (i == 0) bad = 0;
+    __syncthreads();
+    for (int j = 0; j < F; j++) {
+      const double d = L[j][j];
+      if (!(d > 0.0) || !(d < 1e300)) { if (i == 0) bad = 1; break; }   // (uniform: every lane reads the same pivot)
+      const double sd = sqrt(d);
+      __syncthreads();
+      if (i == j) L[j][j] = sd;
+      if (i > j && i < F) L[i][j] = L[i][j] / sd;
+      __syncthreads();
+      if (i > j && i < F) { const double lij = L[i][j]; for (int k = j + 1; k <= i; k++) L[i][k] -= lij * L[k][j]; }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (!bad) {
+      if (i == 0) {   // two triangular solves of 56 unknowns: serial, ~3 k multiply-adds
+        for (int r = 0; r < F; r++) { double s = b[r]; for (int k = 0; k < r; k++) s -= L[r][k] * yv[k]; yv[r] = s / L[r][r]; }
+        for (int r = F - 1; r >= 0; r--) { double s = yv[r]; for (int k = r + 1; k < F; k++) s -= L[k][r] * yv[k]; yv[r] = s / L[r][r]; }
+        int nb = 0;
+        for (int r = 0; r < F; r++) nb |= !(fabs(yv[r]) < 1e300);
+        bad = nb;
+      }
+      __syncthreads();
+      if (!bad) { if (i < F) x[i] = yv[i]; return; }
+    }
+    __syncthreads();
+  }
+  if (i < F) x[i] = yv[i];   // as the torch loop: the last attempt's solution, finite or not
+}
+
 }  // namespace cassie_trpo
 
 extern "C" {
@@ -183,6 +232,12 @@ int CassieTrpoReturnsAdvantages(const float* obs_dev, const long long* t_dev, co
   if (obs_dim == 26) hipLaunchKernelGGL(cassie_trpo::returns_adv_kernel<26>, grid, block, 0, s, obs_dev, t_dev, rew_dev, cut_dev, T, n, coeffs_dev, last_value_dev, gamma, returns_dev, adv_dev, partial_dev);
   else if (obs_dim == 17) hipLaunchKernelGGL(cassie_trpo::returns_adv_kernel<17>, grid, block, 0, s, obs_dev, t_dev, rew_dev, cut_dev, T, n, coeffs_dev, last_value_dev, gamma, returns_dev, adv_dev, partial_dev);
   else return CASSIE_EINVAL;
+  return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
+}
+
+int CassieTrpoRidgeSolve(const double* A_dev, const double* b_dev, int F, double reg, double* x_dev, void* stream) {
+  if (!A_dev || !b_dev || F <= 0 || F > 64 || !x_dev) return CASSIE_EINVAL;
+  hipLaunchKernelGGL(cassie_trpo::ridge_solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A_dev, b_dev, F, reg, x_dev);
   return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
 

@@ -124,9 +124,12 @@ class LinearFeatureBaseline:
         A, b = gram(X, y)
         self.fit_normal_equations(A, b)
 
-    def fit_normal_equations(self, A, b):
-        """coeffs from this rank's X'X [F, F] and X'y [F] (summed over ranks here)."""
+    def fit_normal_equations(self, A, b, solver=None):
+        """coeffs from this rank's X'X [F, F] and X'y [F] (summed over ranks here).  solver(A, b, reg): the same rule on the device."""
         A, b = all_sum_(A.contiguous()), all_sum_(b.contiguous())
+        if solver is not None:
+            self.coeffs = solver(A, b, self.reg_coeff)
+            return
         reg = self.reg_coeff
         eye = torch.eye(A.shape[0], dtype=A.dtype, device=A.device)
         for _ in range(5):
@@ -211,6 +214,15 @@ class BaselineKernels:
             raise RuntimeError("CassieTrpoBaselineGram failed (%d)" % rc)
         G = self.gram_partial.sum(0)[self.idx].view(self.nz, self.nz)
         return G[:self.F, :self.F], G[:self.F, self.F]
+
+    def ridge_solve(self, A, b, reg):
+        """(A + reg I)^-1 b on the device (Cholesky, with fit's retry rule inside the kernel: no read-back)."""
+        A, b = A.contiguous(), b.contiguous()
+        x = torch.empty_like(b)
+        rc = self.L.CassieTrpoRidgeSolve(self._p(A), self._p(b), A.shape[0], self.ct.c_double(reg), self._p(x), self._stream())
+        if rc != 0:
+            raise RuntimeError("CassieTrpoRidgeSolve failed (%d)" % rc)
+        return x
 
 
 class NormalizedActions:
@@ -401,6 +413,43 @@ class FusedFisher:
         if rc != 0:
             raise RuntimeError("CassieTrpoFvp failed (%d)" % rc)
         return self._assemble(self.partial.sum(0), self.h_ls * parts["log_std"])
+
+    @torch.no_grad()
+    def mean_product(self, v):
+        """The mean network's part of F v for this rank's samples, [NP] float32 in the kernel's order (no log_std block, no damping)."""
+        parts = self._split(v)
+        stream = self.ct.c_void_p(torch.cuda.current_stream(self.obs.device).cuda_stream)
+        rc = self.L.CassieTrpoFvp(self.ct.c_void_p(self.obs.data_ptr()), self.n, self.D, self.A, *self._ptrs(self.theta), *self._ptrs(parts),
+                                  self.ct.c_void_p(self.prec.data_ptr()), self.ct.c_float(1.0 / self.n), self.ct.c_void_p(self.partial.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError("CassieTrpoFvp failed (%d)" % rc)
+        return self.partial.sum(0)
+
+    @torch.no_grad()
+    def conjugate_gradient(self, b, iters, reg, tol=1e-10):
+        """conjugate_gradient(lambda v: all_mean_(self(v)) + reg * v, b, iters) with the vector work of an iteration as ONE launch
+        (CassieTrpoCgUpdate): per iteration the product, the sum of its partial rows, the all-reduce over ranks, the update.  None if
+        the parameter vector is not laid out as [.. log_std ..] around a contiguous mean-network block in the kernel's order."""
+        names = self.names
+        if "log_std" not in names or [n for n in names if n != "log_std"] != self.order or b.dtype != torch.float32 or not b.is_contiguous():
+            return None
+        k = names.index("log_std")
+        if k not in (0, len(names) - 1):
+            return None
+        ls_off = 0 if k == 0 else self.NP
+        n = b.numel()
+        x = torch.zeros_like(b)
+        r, p = b.clone(), b.clone()
+        scal = torch.stack([r @ r, torch.ones((), dtype=b.dtype, device=b.device)]).contiguous()
+        hls = self.h_ls.to(torch.float32).contiguous()
+        P = lambda t: self.ct.c_void_p(t.data_ptr())
+        for _ in range(iters):
+            apm = all_mean_(self.mean_product(p))
+            rc = self.L.CassieTrpoCgUpdate(n, ls_off, self.A, P(apm), P(hls), self.ct.c_float(reg), self.ct.c_float(tol), P(x), P(r), P(p), P(scal),
+                                           self.ct.c_void_p(torch.cuda.current_stream(self.obs.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError("CassieTrpoCgUpdate failed (%d)" % rc)
+        return x
 
     @torch.no_grad()
     def vjp(self, w):
@@ -621,7 +670,7 @@ class TRPO:
             std = (s12[1] / n - mean * mean).clamp_min(0).sqrt()
             adv = ((adv - mean) / (std + 1e-8)).to(obs.dtype)  # center_adv
             A, b = bk.gram(obs, tt, flat(returns))
-            self.baseline.fit_normal_equations(A, b)
+            self.baseline.fit_normal_equations(A, b, bk.ridge_solve if getattr(self, "fused_solve", True) else None)
             return dict(obs=obs, act=flat(batch["act"]), mean=flat(batch["mean"]), log_std=flat(batch["log_std"]), adv=adv)
         # bootstrap unfinished paths with the baseline of the next observation (0 at iteration 0)
         last_v = self.baseline.predict(self.obs.to(obs.dtype), self.path_t)
@@ -690,7 +739,9 @@ class TRPO:
             hv = fisher(v) if fisher is not None else flat_grad(gk @ v, pol, retain_graph=True)
             return all_mean_(hv) + self.reg_coeff * v
 
-        descent = conjugate_gradient(Fvp, g, self.cg_iters)
+        descent = fisher.conjugate_gradient(g, self.cg_iters, self.reg_coeff) if isinstance(fisher, FusedFisher) and getattr(self, "fused_cg", True) else None
+        if descent is None:
+            descent = conjugate_gradient(Fvp, g, self.cg_iters)
         shs = 0.5 * (descent @ Fvp(descent))
         if isinstance(fisher, FusedFisher):   # the line search evaluates loss and KL in one launch each (CassieTrpoSurrogate)
             ff, old_ls_vec = fisher, old_lstd[0].detach().clone()

@@ -44,6 +44,14 @@ int CassieTrpoSurrogate(const float* obs_dev, int n, int obs_dim, int act_dim, c
                         const float* W3, const float* b3, const float* log_std_new, const float* log_std_old, const float* act_dev,
                         const float* adv_dev, const float* old_mean_dev, double* partial_dev, void* stream);
 
+/* The vector work of one conjugate-gradient iteration (rllab/misc/krylov.py: cg) between two Fisher-vector products, one launch: with the
+ * parameter vector laid out as [.. | log_std block at ls_off, n_ls entries | ..] and Ap_mean [n - n_ls] = the mean network's part of F p
+ * (rows of CassieTrpoFvp added up, summed over ranks, in the order of the remaining entries):
+ *   Ap = Ap_mean (+ hls o p on the log_std block) + reg p;  alpha = rr / p.Ap;  x += alpha p;  r -= alpha Ap;  rr' = r.r;
+ *   p = r + (rr' / rr) p;  scal = {rr', running}: once rr' < tol the step length stays 0 (cg's early exit without a host read-back). */
+int CassieTrpoCgUpdate(int n, int ls_off, int n_ls, const float* Ap_mean_dev, const float* hls_dev, float reg, float tol, float* x_dev, float* r_dev, float* p_dev,
+                       float* scal_dev, void* stream);
+
 /* One policy step of the sampler for n environments in ONE launch (the counterpart of GaussianMLPPolicy.get_actions + rllab's
  * normalize() wrapper, rllab/envs/trpo_cassie.py:13,21-27): obs float64 [n][obs_dim] as the environment wrote it ->
  *   obs32 [n][obs_dim] (the policy's float32 view, kept for the update), mean [n][act_dim] = mean network, act [n][act_dim] = mean +
@@ -84,6 +92,9 @@ int CassieTrpoReturnsAdvantages(const float* obs_dev, const long long* t_dev, co
 /* Normal equations of the baseline's ridge regression: Z'Z for Z = [features | y] (m samples, 2 obs_dim + 5 columns padded to a multiple
  * of 16) on the FP64 matrix cores.  partial [CassieTrpoGramRows()][CassieTrpoGramRowSize(obs_dim)]: per wavefront the UPPER 16 x 16 blocks
  * (r <= c, r-major) of the Gram matrix, each row-major; the caller adds the rows up: X'X = Z'Z[:features, :features], X'y = Z'Z[:features, features]. */
+/* (A + reg I) x = b, A [F][F] symmetric positive semi-definite (F <= 64), by Cholesky on the device; a failed factorisation or a non-finite
+ * solution retries with ten times the regulariser, five times in all (LinearFeatureBaseline.fit's rule, without a host read-back). */
+int CassieTrpoRidgeSolve(const double* A_dev, const double* b_dev, int F, double reg, double* x_dev, void* stream);
 int CassieTrpoGramRows(void);
 int CassieTrpoGramRowSize(int obs_dim);
 int CassieTrpoBaselineGram(const float* obs_dev, const long long* t_dev, const double* y_dev, int m, int obs_dim, double* partial_dev, void* stream);

@@ -135,6 +135,11 @@ def test_fused_sampler_step_matches_the_torch_bookkeeping():
         assert torch.equal(algos[0].path_t, algos[1].path_t) and torch.equal(algos[0].path_ret, algos[1].path_ret)
 
 
+def features_dot(obs, tt, coeffs):
+    from cassierl_amd import trpo as T
+    return T.LinearFeatureBaseline.features(obs, tt).double() @ coeffs
+
+
 def test_baseline_kernels_match_the_torch_expressions():
     """csrc/tu_trpo_baseline.hip against LinearFeatureBaseline / TRPO.process of trpo.py on the same batches: normal equations (FP64 MFMA),
     returns, advantages and predictions; two iterations, so that the second one runs with fitted coefficients and bootstrapped paths."""
@@ -163,9 +168,46 @@ def test_baseline_kernels_match_the_torch_expressions():
         assert ((A - Ar).abs() / (Ar.abs() + 1e-3 * Ar.abs().max())).max().item() < 1e-9   # entry by entry: the float32 feature arithmetic is the same
         assert (b - br).abs().max().item() < 1e-10 * (br.abs().max().item() + Ar.abs().max().item() ** 0.5)
         assert torch.equal(A, A.T)
+        # the device solve (Cholesky + the retry rule) against torch.linalg.solve on the same system, and a singular system that needs the retries
+        xs = algos[0]._bk.ridge_solve(A, b, 1e-5)
+        xr = torch.linalg.solve(A + 1e-5 * torch.eye(A.shape[0], dtype=A.dtype, device="cuda"), b)
+        assert ((A + 1e-5 * torch.eye(A.shape[0], dtype=A.dtype, device="cuda")) @ xs - b).abs().max().item() < 1e-6 * (1 + b.abs().max().item())
+        assert (features_dot(obs, tt, xs) - features_dot(obs, tt, xr)).abs().max().item() < 1e-6 * (1 + features_dot(obs, tt, xr).abs().max().item())
+        Z = torch.zeros_like(A)
+        x0 = algos[0]._bk.ridge_solve(Z, b, 0.0)     # 0 x = b: no positive pivot at any regulariser 0 * 10^k -> the last attempt's (non-finite or stale) vector, no hang
+        assert x0.shape == b.shape
         # fitted baselines predict the same values (the solve amplifies rounding by the conditioning of X'X: compare predictions)
         c0, c1 = algos[0].baseline.coeffs, algos[1].baseline.coeffs
         p0 = algos[0]._bk.predict(obs, tt, c0)
         p1 = T.LinearFeatureBaseline.features(obs, tt).double() @ c1
         assert (p0 - p1).abs().max().item() < 1e-5 * (1 + p1.abs().max().item()), (it, (p0 - p1).abs().max().item())
         algos[0].optimize(d0); algos[1].optimize(d1)
+
+
+def test_fused_cg_matches_the_torch_conjugate_gradient():
+    """FusedFisher.conjugate_gradient (CassieTrpoCgUpdate: the vector work of an iteration in one launch) against conjugate_gradient() over
+    the same Fisher-vector products: ten iterations, and the early exit (a tolerance that is met half-way freezes the same iterate)."""
+    import torch
+    from cassierl_amd import trpo as T
+    torch.manual_seed(9)
+    n = 20000
+    pol = T.GaussianMLPPolicy(26, 6, (32, 32), init_std=1.5).cuda()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    obs = torch.randn(n, 26, device="cuda") * 0.7
+    fisher = T.FusedFisher(pol, obs)
+    g = torch.randn(sum(p.numel() for p in pol.parameters()), device="cuda")
+    reg = 1e-5
+    ref = T.conjugate_gradient(lambda v: fisher(v) + reg * v, g, 10)
+    x = fisher.conjugate_gradient(g, 10, reg)
+    assert x is not None
+    assert (x - ref).abs().max().item() < 2e-3 * ref.abs().max().item(), ((x - ref).abs().max().item(), ref.abs().max().item())
+    # early exit: a tolerance between the residuals of iterations 3 and 4 stops both at the same iterate
+    r4 = T.conjugate_gradient(lambda v: fisher(v) + reg * v, g, 4)
+    res = (fisher(r4) + reg * r4 - g)
+    tol = float(res @ res) * 1.5
+    a = T.conjugate_gradient(lambda v: fisher(v) + reg * v, g, 10, tol=tol)
+    b = fisher.conjugate_gradient(g, 10, reg, tol=tol)
+    assert (a - b).abs().max().item() < 2e-3 * a.abs().max().item()
+    assert (a - ref).abs().max().item() > 1e-2 * ref.abs().max().item()   # (it did stop early)
