@@ -23,6 +23,7 @@
 // (0.80 ms against 0.67; weights in LDS 1.44 ms: the compiler hoists the weight reads and spills) -- replaced by this one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/cassie_trpo.h"
 #include "../../include/cassie_vec.h"
@@ -371,6 +372,84 @@ __global__ void __launch_bounds__(256) policy_step_kernel(const double* __restri
   }
 }
 
+// The same policy step on the matrix cores (r04): a wavefront per tile of 32 environments, the forward pass of trpo_kernel (A operands
+// from memory once per wavefront, activations in the accumulator layout), the mean with action a = v + 4 h in register v < 4 of lane
+// (environment, h).  tanh through the hardware exp2 / rcp as in the update's kernels, so that the mean the sampler records IS the mean
+// the line search evaluates at the same weights.  33 -> see DESIGN.md section 8 us per step of 65 536 environments.
+template <int D, int A>
+__global__ void __launch_bounds__(64 * WAVES, 2) policy_step_mfma_kernel(const double* __restrict__ obs, int n, Net th, const float* __restrict__ log_std,
+                                                                     const float* __restrict__ noise, const double* __restrict__ low, const double* __restrict__ high,
+                                                                     float* __restrict__ obs32, float* __restrict__ mean, float* __restrict__ act, double* __restrict__ env_act) {
+  constexpr int KS1 = (D + 1) / 2;
+  __shared__ alignas(16) float sbias[3][32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  if (tid < 32) { sbias[0][tid] = th.b1[tid]; sbias[1][tid] = th.b2[tid]; sbias[2][tid] = tid < A ? th.b3[tid] : 0.0f; }
+  float aW1[KS1], aW2[16], aW3[16], sd[4];
+  double lo[4], hi[4];
+#pragma unroll
+  for (int s = 0; s < KS1; s++) { const int k = 2 * s + h; aW1[s] = k < D ? th.W1[c * D + k] : 0.0f; }
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int r = (v & 3) + 8 * (v >> 2) + 4 * h;
+    aW2[v] = th.W2[c * H + r];
+    aW3[v] = c < A ? th.W3[c * H + r] : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int a = v + 4 * h;
+    sd[v] = a < A ? expf(log_std[a]) : 0.0f;
+    lo[v] = a < A ? low[a] : 0.0; hi[v] = a < A ? high[a] : 0.0;
+  }
+  __syncthreads();
+  auto bias_tile = [&](int which) {
+    v16f z;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const float4 b = *reinterpret_cast<const float4*>(&sbias[which][8 * g + 4 * h]);
+      z[4 * g] = b.x; z[4 * g + 1] = b.y; z[4 * g + 2] = b.z; z[4 * g + 3] = b.w;
+    }
+    return z;
+  };
+  const int ntiles = (n + 31) / 32;
+  for (int tl = blockIdx.x * WAVES + wave; tl < ntiles; tl += gridDim.x * WAVES) {
+    const int smp = tl * 32 + c;
+    const bool valid = smp < n;
+    float xb[KS1];
+#pragma unroll
+    for (int s = 0; s < KS1; s++) {
+      const int k = 2 * s + h;
+      const bool on = valid && k < D;
+      xb[s] = on ? (float)obs[(size_t)smp * D + k] : 0.0f;
+      if (on) obs32[(size_t)smp * D + k] = xb[s];
+    }
+    v16f h1 = bias_tile(0);
+#pragma unroll
+    for (int s = 0; s < KS1; s++) h1 = TRPO_MFMA(aW1[s], xb[s], h1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h1[v] = tanh_fast(h1[v]);
+    v16f h2 = bias_tile(1);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h2 = TRPO_MFMA(aW2[v], h1[v], h2);
+#pragma unroll
+    for (int v = 0; v < 16; v++) h2[v] = tanh_fast(h2[v]);
+    v16f mu = bias_tile(2);
+#pragma unroll
+    for (int v = 0; v < 16; v++) mu = TRPO_MFMA(aW3[v], h2[v], mu);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int a = v + 4 * h;
+      if (valid && a < A) {
+        const size_t o = (size_t)smp * A + a;
+        const float val = mu[v] + noise[o] * sd[v];
+        mean[o] = mu[v]; act[o] = val;
+        double e = lo[v] + ((double)val + 1.0) * 0.5 * (hi[v] - lo[v]);
+        e = e < lo[v] ? lo[v] : (e > hi[v] ? hi[v] : e);
+        env_act[o] = e;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- sampler step
 // Per-path clocks and returns of the sampler for one Env.step, one lane per environment (trpo.collect did this with ~20 element-wise
 // torch launches per step; rllab's sampler keeps the same quantities on the host).  Episode statistics: one (count, summed return) pair
@@ -544,11 +623,19 @@ int CassieTrpoPolicyStep(const double* obs_dev, int n, int obs_dim, int act_dim,
       !act_dev || !env_actions_dev)
     return CASSIE_EINVAL;
   const cassie_trpo::Net th{W1, b1, W2, b2, W3, b3};
-  const dim3 grid((n + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
   using namespace cassie_trpo;
-  if (obs_dim == 26 && act_dim == 6) hipLaunchKernelGGL((policy_step_kernel<26, 6>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
-  else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((policy_step_kernel<26, 7>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
+  static const bool vector_path = [] { const char* e = getenv("CASSIE_TRPO_POLICY_VALU"); return e && e[0] == '1'; }();   // the one-lane-per-environment kernel (A/B, tests)
+  if (vector_path) {
+    const dim3 grid((n + 255) / 256), block(256);
+    if (obs_dim == 26 && act_dim == 6) hipLaunchKernelGGL((policy_step_kernel<26, 6>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
+    else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((policy_step_kernel<26, 7>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
+    else return CASSIE_EINVAL;
+    return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
+  }
+  const dim3 grid(blocks_for(n)), block(64 * WAVES);
+  if (obs_dim == 26 && act_dim == 6) hipLaunchKernelGGL((policy_step_mfma_kernel<26, 6>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
+  else if (obs_dim == 26 && act_dim == 7) hipLaunchKernelGGL((policy_step_mfma_kernel<26, 7>), grid, block, 0, s, obs_dev, n, th, log_std, noise_dev, low_dev, high_dev, obs32_dev, mean_dev, act_dev, env_actions_dev);
   else return CASSIE_EINVAL;
   return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
