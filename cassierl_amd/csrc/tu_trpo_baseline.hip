@@ -163,45 +163,59 @@ __global__ void __launch_bounds__(256) predict_kernel(const float* __restrict__ 
   out[s] = value + coeffs[NF - 1];
 }
 
-// (A + reg I) x = b for the baseline's F <= 64 coefficients, A symmetric positive semi-definite: Cholesky in LDS by one wavefront (lane i
-// owns row i), forward / backward substitution, and LinearFeatureBaseline.fit's retry rule ON THE DEVICE -- if the factorisation meets a
-// non-positive pivot or the solution is not finite, the regulariser is multiplied by ten (five tries) -- so that the fit needs no host
-// read-back (as torch operations: rocSOLVER's LU + torch.isfinite(...).all() -> bool, 0.3 ms and a synchronisation per iteration).
-__global__ void __launch_bounds__(64) ridge_solve_kernel(const double* __restrict__ A, const double* __restrict__ b, int F, double reg, double* __restrict__ x) {
-  __shared__ double L[64][65];
-  __shared__ double yv[64];
-  __shared__ int bad;
+// (A + reg I) x = b for the baseline's F coefficients, A symmetric positive semi-definite: Cholesky by ONE wavefront with row i of the matrix
+// in the registers of lane i (the pivot column travels through v_readlane: no LDS, no barrier), forward substitution by columns, backward
+// substitution by wave sums, and LinearFeatureBaseline.fit's retry rule ON THE DEVICE -- if the factorisation meets a non-positive pivot or
+// the solution is not finite, the regulariser is multiplied by ten (five tries) -- so that the fit needs no host read-back (as torch
+// operations: rocSOLVER's LU + torch.isfinite(...).all() -> bool, 0.3 ms and a synchronisation per iteration; a first version of this
+// kernel with the matrix in LDS and serial substitutions took 0.23 ms).
+__device__ __forceinline__ double lane_bcast(double x, int src) {   // src: compile-time constant after unrolling -> v_readlane
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src), __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+template <int F>
+__global__ void __launch_bounds__(64) ridge_solve_kernel(const double* __restrict__ A, const double* __restrict__ b, double reg, double* __restrict__ x_out) {
   const int i = threadIdx.x;
+  const bool row = i < F;
+  double xs = 0.0;
   for (int attempt = 0; attempt < 5; attempt++, reg *= 10.0) {
-    if (i < F) for (int j = 0; j < F; j++) L[i][j] = A[i * F + j] + (i == j ? reg : 0.0);
-    if (i == 0) bad = 0;
-    __syncthreads();
+    double a[F], diag = 1.0;
+#pragma unroll
+    for (int k = 0; k < F; k++) a[k] = (row && k <= i) ? A[(size_t)i * F + k] + (k == i ? reg : 0.0) : 0.0;
+    bool bad = false;
+#pragma unroll
     for (int j = 0; j < F; j++) {
-      const double d = L[j][j];
-      if (!(d > 0.0) || !(d < 1e300)) { if (i == 0) bad = 1; break; }   // (uniform: every lane reads the same pivot)
-      const double sd = sqrt(d);
-      __syncthreads();
-      if (i == j) L[j][j] = sd;
-      if (i > j && i < F) L[i][j] = L[i][j] / sd;
-      __syncthreads();
-      if (i > j && i < F) { const double lij = L[i][j]; for (int k = j + 1; k <= i; k++) L[i][k] -= lij * L[k][j]; }
-      __syncthreads();
+      const double d = lane_bcast(a[j], j);
+      bad = bad || !(d > 0.0) || !(d < 1e300);
+      const double sd = sqrt(bad ? 1.0 : d), lij = a[j] / sd;   // lanes i > j: L[i][j]; lane j: sqrt(d)
+      if (i == j) diag = sd;
+      a[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < F; k++) { const double lkj = lane_bcast(lij, k); if (i >= k) a[k] -= lij * lkj; }
     }
-    __syncthreads();
-    if (!bad) {
-      if (i == 0) {   // two triangular solves of 56 unknowns: serial, ~3 k multiply-adds
-        for (int r = 0; r < F; r++) { double s = b[r]; for (int k = 0; k < r; k++) s -= L[r][k] * yv[k]; yv[r] = s / L[r][r]; }
-        for (int r = F - 1; r >= 0; r--) { double s = yv[r]; for (int k = r + 1; k < F; k++) s -= L[k][r] * yv[k]; yv[r] = s / L[r][r]; }
-        int nb = 0;
-        for (int r = 0; r < F; r++) nb |= !(fabs(yv[r]) < 1e300);
-        bad = nb;
-      }
-      __syncthreads();
-      if (!bad) { if (i < F) x[i] = yv[i]; return; }
+    // forward: L y = b, by columns (lane r finishes y_r, the lanes below subtract its column)
+    double sacc = row ? b[i] : 0.0, y = 0.0;
+#pragma unroll
+    for (int r = 0; r < F; r++) {
+      const double yr = lane_bcast(sacc / diag, r);
+      if (i == r) y = yr;
+      if (i > r) sacc -= a[r] * yr;
     }
-    __syncthreads();
+    // backward: L' x = y, x_r = (y_r - sum_{k > r} L[k][r] x_k) / L[r][r]: the sum runs over LANES
+    xs = 0.0;
+#pragma unroll
+    for (int r = F - 1; r >= 0; r--) {
+      const double t = wave_sum((row && i > r) ? a[r] * xs : 0.0);
+      if (i == r) xs = (y - t) / diag;
+    }
+    const bool nonfinite = __ballot(row && !(fabs(xs) < 1e300)) != 0ull;
+    if (!bad && !nonfinite) break;
   }
-  if (i < F) x[i] = yv[i];   // as the torch loop: the last attempt's solution, finite or not
+  if (row) x_out[i] = xs;   // (as the torch loop: after five tries the last attempt's vector, finite or not)
 }
 
 }  // namespace cassie_trpo
@@ -236,8 +250,10 @@ int CassieTrpoReturnsAdvantages(const float* obs_dev, const long long* t_dev, co
 }
 
 int CassieTrpoRidgeSolve(const double* A_dev, const double* b_dev, int F, double reg, double* x_dev, void* stream) {
-  if (!A_dev || !b_dev || F <= 0 || F > 64 || !x_dev) return CASSIE_EINVAL;
-  hipLaunchKernelGGL(cassie_trpo::ridge_solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A_dev, b_dev, F, reg, x_dev);
+  if (!A_dev || !b_dev || !x_dev) return CASSIE_EINVAL;
+  if (F == 56) hipLaunchKernelGGL(cassie_trpo::ridge_solve_kernel<56>, dim3(1), dim3(64), 0, (hipStream_t)stream, A_dev, b_dev, reg, x_dev);
+  else if (F == 38) hipLaunchKernelGGL(cassie_trpo::ridge_solve_kernel<38>, dim3(1), dim3(64), 0, (hipStream_t)stream, A_dev, b_dev, reg, x_dev);
+  else return CASSIE_EINVAL;
   return hipGetLastError() == hipSuccess ? CASSIE_OK : CASSIE_EHIP;
 }
 

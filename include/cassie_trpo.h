@@ -92,7 +92,7 @@ int CassieTrpoReturnsAdvantages(const float* obs_dev, const long long* t_dev, co
 /* Normal equations of the baseline's ridge regression: Z'Z for Z = [features | y] (m samples, 2 obs_dim + 5 columns padded to a multiple
  * of 16) on the FP64 matrix cores.  partial [CassieTrpoGramRows()][CassieTrpoGramRowSize(obs_dim)]: per wavefront the UPPER 16 x 16 blocks
  * (r <= c, r-major) of the Gram matrix, each row-major; the caller adds the rows up: X'X = Z'Z[:features, :features], X'y = Z'Z[:features, features]. */
-/* (A + reg I) x = b, A [F][F] symmetric positive semi-definite (F <= 64), by Cholesky on the device; a failed factorisation or a non-finite
+/* (A + reg I) x = b, A [F][F] symmetric positive semi-definite (F = CassieTrpoBaselineFeatures(obs_dim): 56 or 38), by Cholesky on the device; a failed factorisation or a non-finite
  * solution retries with ten times the regulariser, five times in all (LinearFeatureBaseline.fit's rule, without a host read-back). */
 int CassieTrpoRidgeSolve(const double* A_dev, const double* b_dev, int F, double reg, double* x_dev, void* stream);
 int CassieTrpoGramRows(void);
