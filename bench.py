@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-trpo", action="store_true", help="N > 1: skip the TRPO outer loop (configs[3]'s caller) after the random-policy rollout")
+    ap.add_argument("--trpo-iters", type=int, default=6)
     ap.add_argument("--cpu-legs-only", action="store_true", help="internal: print the CPU legs of configs[0]/[2]/[4] as JSON (no GPU) and exit")
     return ap.parse_args()
 
@@ -133,6 +135,35 @@ def spawn_ranks(args, poll_s=0.5, deadline_s=3600.0):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_limits():
+    """What this process may really use of the box's host cores: the affinity mask, the cgroup CPU quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us` / `cpu.cfs_period_us`; None = unlimited / not readable) and the cores the box shows."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+        src = "cgroup v2 cpu.max = %s %s" % (q, per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+            src = "cgroup v1 cfs_quota_us / cfs_period_us = %g / %g" % (q, per)
+        except Exception:
+            src = "no readable cgroup CPU quota"
+    return dict(cpu_count=os.cpu_count(), affinity=aff, cpu_quota=quota, cpu_quota_source=src)
+
+
+def thread_ladder(cores):
+    """Thread counts to try: the visible cores, then halves down to one (every figure is reported, the best is the value)."""
+    tries, th = [], max(1, cores)
+    while th >= 1:
+        tries.append(th)
+        th //= 2
+    return tries
+
+
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -165,24 +196,24 @@ def cpu_baseline(traj, cores, budget_s=12.0):
         return n * steps / t_used, steps, t_used
 
     one, s1, t1 = sample(16, 1, 2.0)
-    tries, th = [], cores
-    while th >= 1 and len(tries) < 6:
-        tries.append(th)
-        th //= 2
+    tries = [t for t in thread_ladder(cores) if t > 1][:6] or [1]
     per = max(1.0, (budget_s - 2.0) / len(tries))
-    best = None
+    best, per_threads = None, {"1": one}
     for th in tries:
         v, st, tu = sample(16 * th, th, per)
+        per_threads[str(th)] = v
         if best is None or v > best[0]:
             best = (v, th, st, tu)
-    return dict(value=best[0], unit="env-steps/s", cores=best[1], kind="port",
+    if one > best[0]:
+        best = (one, 1, s1, t1)
+    return dict(value=best[0], unit="env-steps/s", cores=best[1], kind="port", per_threads=per_threads,
                 single_thread=dict(value=one, unit="env-steps/s", cores=1, sample="16 envs x %d Env.steps in %.1f s" % (s1, t1)),
                 cores_visible=cores, threads_tried=tries,
                 sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s, OpenMP over envs on %d threads (best of %s), "
                        "oracle built %s" % (16 * best[1], best[2], best[3], best[1], tries, "-O3 -march=native" if fast else "-O2"))
 
 
-def cpu_same_source(traj, cores, budget_s=10.0):
+def cpu_same_source(traj, cores, budget_s=20.0):
     """The SAME SOURCE as the HIP kernel (cassierl_amd/csrc/cassie_leg_core.h) on the host cores: oracle/leg_host/leg_host.cpp
     instantiates it with an eight-lane backend (four environments per AVX-512 register), -O3 -march=native, built on this box;
     OpenMP over groups of environments.  Same workload as the headline (walk env, PD, random policy, auto-reset).  BASELINE.md
@@ -222,23 +253,34 @@ def cpu_same_source(traj, cores, budget_s=10.0):
         assert np.isfinite(rew).all() and bad.value == 0 and pend.sum() == 0
         return n * (steps - 1) / t_used, steps - 1, t_used
 
+    # Every thread count of the ladder is measured and REPORTED (`per_threads`): the sample is 256 environments per thread (64 register
+    # groups each, so that a wide team has work for every member) stepped for at least `per` seconds after an untimed first call
+    # (thread-team start-up, first touch of the state); the value is the best of them, and `limits` says what the box really grants --
+    # a container can show 256 hardware threads and schedule a fraction of them (cgroup quota), in which case the wide teams
+    # time-share cores and lose to the narrow ones.
+    limits = cpu_limits()
     one, s1, t1 = sample(256, 1, 1.5)
-    tries, th = [], cores
-    while th >= 1 and len(tries) < 6:
-        tries.append(th)
-        th //= 2
-    per = max(1.0, (budget_s - 1.5) / len(tries))
-    best = None
+    tries = [t for t in thread_ladder(cores) if t > 1] or [1]
+    per = max(2.0, (budget_s - 1.5) / len(tries))
+    best, per_threads = None, {"1": one}
     for th in tries:
         val, st, tu = sample(256 * th, th, per)
+        per_threads[str(th)] = val
         if best is None or val > best[0]:
             best = (val, th, st, tu)
+    if one > best[0]:
+        best = (one, 1, s1, t1)
+    q = limits.get("cpu_quota")
+    why = ("the cgroup quota grants %.1f cores of the %d visible: wider teams time-share them" % (q, cores) if q and q < cores else
+           "no CPU quota is set: the best thread count is where the same-source leg stops scaling on this box (shared L3 / memory, SMT pairs)")
     return dict(value=best[0], unit="env-steps/s", cores=best[1], kind="same-source", lanes_per_thread=int(L.leg_host_lanes()),
                 single_thread=dict(value=one, unit="env-steps/s", cores=1, sample="256 envs x %d Env.steps in %.1f s" % (s1, t1)),
+                per_threads=per_threads, cpu_quota=q, limits=limits, chosen_because=why,
+                scaling_efficiency_at_best=best[0] / (one * best[1]) if one > 0 else None,
                 cores_visible=cores, threads_tried=tries,
                 sample="%d envs x %d Env.steps (walk env, PD, random policy) in %.1f s: cassie_leg_core.h through the host backend "
                        "(oracle/leg_host, 8 lanes = 4 envs per AVX-512 register), g++ -O3 -march=native, OpenMP over envs on %d threads "
-                       "(best of %s)" % (256 * best[1], best[2], best[3], best[1], tries))
+                       "(best of %s; every figure in per_threads)" % (256 * best[1], best[2], best[3], best[1], [1] + tries))
 
 
 def cpu_legs_other_configs(budget_s=4.0):
@@ -429,23 +471,41 @@ def extra_workloads(traj, n):
     # (e) configs[3]'s caller: the TRPO outer loop of trpo_cassie.py on the batched environment (walk env / PD, `n` envs x 8 steps per
     #     iteration; policy step, sampler, returns / baseline, Fisher-vector products and line search as HIP kernels)
     try:
-        from cassierl_amd import trpo as T
-        from cassierl_amd.trajectory import default_gait
-        algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", trajectory=default_gait(), batch_size=n * 8)
-        for _ in range(4):
-            algo.train_iteration()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(6):
-            st = algo.train_iteration()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        algo.env.close()
-        rows.append(dict(workload="trpo_outer_loop_walk_pd", note="TRPO iterations (rollout of 8 Env.steps + update) on %d envs; env-steps of the rollouts per second of the whole loop" % n,
-                         envs=n, iterations=6, env_steps_per_s=6 * n * 8 / dt, ms_per_iteration=dt / 6 * 1e3, kl=st.get("kl"), backtracks=st.get("backtracks")))
+        rows.append(trpo_outer_loop(n, 1, 0))
     except Exception as ex:
         rows.append(dict(workload="trpo_outer_loop_walk_pd", error=repr(ex)))
     return rows
+
+
+def trpo_outer_loop(n, world, device, warm=4, iters=6):
+    """configs[3]'s caller (rllab/envs/trpo_cassie.py:21-48): TRPO iterations on `n` envs per rank x 8 Env.steps -- rollout, baseline,
+    gradient, ten Fisher-vector products, line search -- with the data-parallel collectives of the update (all_reduce of the
+    ~1.3 k-parameter gradient / Fisher-vector products / line-search scalars / baseline normal equations, all_gather of the per-env
+    returns) timed one by one with HIP events.  Every rank calls this; the timed region is barrier + synchronize on both sides and
+    the MAX over ranks.  Returns the row (meaningful on rank 0)."""
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd import trpo as T
+    from cassierl_amd.trajectory import default_gait
+    algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", device=device, trajectory=default_gait(), batch_size=n * world * 8)
+    for _ in range(warm):
+        algo.train_iteration()
+    T.COMM = T.CommTimer() if world > 1 else None
+    torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        st = algo.train_iteration()
+    torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
+    dt = R.max_over_ranks(time.perf_counter() - t0, device="cuda:%d" % device)
+    comm = T.COMM.summary() if T.COMM is not None else {}
+    T.COMM = None
+    algo.env.close()
+    per_iter = {k: dict(calls_per_iteration=v["calls"] / iters, ms_per_iteration=v["total_ms"] / iters, mean_ms=v["mean_ms"], max_ms=v["max_ms"]) for k, v in comm.items()}
+    return dict(workload="trpo_outer_loop_walk_pd",
+                note="TRPO iterations (rollout of 8 Env.steps + update) on %d envs per rank x %d rank(s); env-steps of the rollouts per second of the whole loop" % (n, world),
+                envs=n, envs_total=n * world, ranks=world, iterations=iters, env_steps_per_s=iters * n * world * 8 / dt, ms_per_iteration=dt / iters * 1e3,
+                samples_per_iteration=n * world * 8, kl=st.get("kl"), backtracks=st.get("backtracks"),
+                collectives_ms=per_iter, collective_ms_per_iteration=sum(v["ms_per_iteration"] for v in per_iter.values()))
 
 
 def roofline_object(n_local, kernel_ms, dominant, pmc):
@@ -568,6 +628,16 @@ def worker(args):
     q, v = env.get_state_host()
     finite = bool(np.isfinite(q).all() and np.isfinite(v).all())
     env.close()
+    backend = R.dist.get_backend() if R.dist.is_initialized() else None
+    # configs[3] as written ("512k envs sharded 8 x MI355X, TRPO outer loop, RCCL return gather"): with more than one rank every rank
+    # also runs the TRPO loop on its shard (gradient / Fisher-vector-product all-reduces, return gather); the random-policy rollout
+    # above stays the headline metric.  Collective: every rank takes part, so a failure on one rank must not leave the others waiting.
+    trpo_row = None
+    if world > 1 and not args.no_trpo:
+        try:
+            trpo_row = trpo_outer_loop(n_local, world, dev, warm=3, iters=args.trpo_iters)
+        except Exception as ex:
+            trpo_row = dict(workload="trpo_outer_loop_walk_pd", error=repr(ex))
 
     rc = 0
     if rank == 0:
@@ -594,7 +664,7 @@ def worker(args):
                                       ("configs[1] as written" if n_local == 4096 else "configs[1] workload at a non-default size")),
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
                        "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms,
-                       "preroll_steps": preroll_steps},
+                       "backend": backend, "ranks_joined": ranks_joined, "preroll_steps": preroll_steps},
             "roofline": roofline_object(n_local, kernel_ms, dominant, pmc if pmc_ok else {}),
             "physics_substeps_per_s": value * 10, "returns_checksum": float(all_returns.sum().item()), "finite": finite,
             "episodes_terminated_per_env_step": float(dones.item()) / (n_local * args.steps),
@@ -604,12 +674,16 @@ def worker(args):
         }
         if not finite or ranks_joined != max(1, args.gpus):
             rc = 4
+        if trpo_row is not None:
+            line["config"]["trpo_outer_loop"] = trpo_row
+            line["config"]["trpo_outer_loop_env_steps_per_s"] = trpo_row.get("env_steps_per_s")
         if world == 1 and not args.no_extra:
             try:
                 line["extra"] = extra_workloads(traj, n_local)
                 # the regimes where robots move, fall and lie on the ground, where the driver's record keeps them (env-steps/s)
                 line["config"]["env_steps_per_s_other_workloads"] = {
                     r["workload"]: r.get("env_steps_per_s", r.get("env_steps_equiv_per_s")) for r in line["extra"] if "workload" in r}
+                line["config"]["trpo_outer_loop_env_steps_per_s"] = line["config"]["env_steps_per_s_other_workloads"].get("trpo_outer_loop_walk_pd")
             except Exception as ex:  # the headline stays valid; say what failed
                 line["extra"] = [{"error": repr(ex)}]
         if world == 1 and not args.no_cpu_baseline:

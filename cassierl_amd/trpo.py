@@ -26,17 +26,58 @@ def _world():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_mean_(t):
+class CommTimer:
+    """Per-collective timing of the data-parallel loop without host synchronisation: a pair of HIP events on the current stream
+    around every collective (the RCCL kernel runs on the communicator's stream, which the current stream waits for), read once by
+    `summary()`.  bench.py sets `trpo.COMM = CommTimer()` for configs[3]'s line; None (default) costs nothing."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def run(self, name, fn, t):
+        if not t.is_cuda:
+            import time
+            t0 = time.perf_counter()
+            fn()
+            self.spans.setdefault(name, []).append(time.perf_counter() - t0)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {}
+        for name, sp in self.spans.items():
+            ms = [x * 1e3 if isinstance(x, float) else x[0].elapsed_time(x[1]) for x in sp]
+            out[name] = dict(calls=len(ms), total_ms=float(sum(ms)), mean_ms=float(sum(ms) / max(1, len(ms))), max_ms=float(max(ms)))
+        return out
+
+
+COMM = None
+
+
+def _all_reduce_sum(t, name):
+    if COMM is None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        COMM.run(name, lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM), t)
+
+
+def all_mean_(t, name="all_reduce"):
     """In-place mean over ranks (no-op single process)."""
     if _world() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(t, name)
         t /= _world()
     return t
 
 
-def all_sum_(t):
+def all_sum_(t, name="all_reduce"):
     if _world() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(t, name)
     return t
 
 
@@ -126,7 +167,7 @@ class LinearFeatureBaseline:
 
     def fit_normal_equations(self, A, b, solver=None):
         """coeffs from this rank's X'X [F, F] and X'y [F] (summed over ranks here).  solver(A, b, reg): the same rule on the device."""
-        A, b = all_sum_(A.contiguous()), all_sum_(b.contiguous())
+        A, b = all_sum_(A.contiguous(), "baseline_all_reduce"), all_sum_(b.contiguous(), "baseline_all_reduce")
         if solver is not None:
             self.coeffs = solver(A, b, self.reg_coeff)
             return
@@ -444,7 +485,7 @@ class FusedFisher:
         hls = self.h_ls.to(torch.float32).contiguous()
         P = lambda t: self.ct.c_void_p(t.data_ptr())
         for _ in range(iters):
-            apm = all_mean_(self.mean_product(p))
+            apm = all_mean_(self.mean_product(p), "fvp_all_reduce")
             rc = self.L.CassieTrpoCgUpdate(n, ls_off, self.A, P(apm), P(hls), self.ct.c_float(reg), self.ct.c_float(tol), P(x), P(r), P(p), P(scal),
                                            self.ct.c_void_p(torch.cuda.current_stream(self.obs.device).cuda_stream))
             if rc != 0:
@@ -545,9 +586,14 @@ class TRPO:
         P = lambda t: ct.c_void_p(t.data_ptr())
         w = [P(lin[0].weight), P(lin[0].bias), P(lin[1].weight), P(lin[1].bias), P(lin[2].weight), P(lin[2].bias), P(self.policy.log_std)]
         low, high, n = self.act_map.low, self.act_map.high, self.n_envs
+        # the kernel reads the bounds as `const double*`: anything else (NormalizedActions takes a dtype) goes the torch way
+        if not all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == A for t in (low, high)):
+            return None
 
         def step(obs, noise, obs32, mean, act):
-            assert obs.dtype == torch.float64 and obs.is_contiguous() and noise.is_contiguous() and obs32.is_contiguous()
+            if obs.dtype != torch.float64 or not obs.is_contiguous():
+                raise TypeError("CassieTrpoPolicyStep: observations must be a contiguous float64 tensor (got %s)" % obs.dtype)
+            assert noise.is_contiguous() and obs32.is_contiguous()
             rc = L.CassieTrpoPolicyStep(P(obs), n, D, A, *w, P(noise), P(low), P(high), P(obs32), P(mean), P(act), P(self._env_actions),
                                         ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             if rc != 0:
@@ -665,7 +711,7 @@ class TRPO:
             returns, adv, sums = bk.returns_advantages(batch["obs"], batch["t"], batch["rew"], batch["done"], coeffs, last_v, self.discount)
             adv = flat(adv)
             n = torch.tensor([adv.numel()], dtype=torch.float64, device=adv.device)
-            s12 = all_sum_(sums.clone()); n = all_sum_(n)
+            s12 = all_sum_(sums.clone(), "advantage_all_reduce"); n = all_sum_(n, "advantage_all_reduce")
             mean = s12[0] / n
             std = (s12[1] / n - mean * mean).clamp_min(0).sqrt()
             adv = ((adv - mean) / (std + 1e-8)).to(obs.dtype)  # center_adv
@@ -678,7 +724,7 @@ class TRPO:
         values = self.baseline.predict(obs, tt).view(T, N)
         adv = flat(returns - values)                       # gae_lambda = 1
         n = torch.tensor([adv.numel()], dtype=torch.float64, device=adv.device)
-        s1 = all_sum_(adv.sum().view(1).clone()); s2 = all_sum_((adv * adv).sum().view(1).clone()); n = all_sum_(n)
+        s1 = all_sum_(adv.sum().view(1).clone(), "advantage_all_reduce"); s2 = all_sum_((adv * adv).sum().view(1).clone(), "advantage_all_reduce"); n = all_sum_(n, "advantage_all_reduce")
         mean = s1 / n
         std = (s2 / n - mean * mean).clamp_min(0).sqrt()
         adv = ((adv - mean) / (std + 1e-8)).to(obs.dtype)  # center_adv
@@ -715,7 +761,10 @@ class TRPO:
         if fisher is not None:
             # policy gradient in closed form too: at theta = theta_old the likelihood ratio is 1, so with z = (a - mean) / std
             #   d loss / d mean = -adv z / std / N,   d loss / d log_std = -sum_s adv (z^2 - 1) / N,   loss = -mean(adv)
-            # and J' (d loss / d mean) comes from the Fisher object's reverse pass (r04: 3.9 ms of autograd -> 0.5 ms at 524 288 samples)
+            # and J' (d loss / d mean) comes from the Fisher object's reverse pass (r04: 3.9 ms of autograd -> 0.5 ms at 524 288 samples).
+            # ASSUMES the batch is exactly on-policy -- old_mean / old_lstd were produced by the CURRENT parameters (true for this
+            # sampler: optimize() runs right after the rollout that recorded them) -- and a state-independent log_std; a caller that
+            # reuses an older batch must set analytic_fisher = False (the autograd gradient below makes neither assumption).
             with torch.no_grad():
                 std = old_lstd.exp()
                 z = (act - old_mean) / std
@@ -728,16 +777,16 @@ class TRPO:
                         g[i0:i0 + p_.numel()] += g_ls.to(g.dtype)
                     i0 += p_.numel()
                 loss = -adv.mean()
-            g = all_mean_(g)
+            g = all_mean_(g, "gradient_all_reduce")
         else:
             loss, _ = surrogate()
-            g = all_mean_(flat_grad(loss, pol))
+            g = all_mean_(flat_grad(loss, pol), "gradient_all_reduce")
             _, kl0 = surrogate()
             gk = flat_grad(kl0, pol, retain_graph=True, create_graph=True)
 
         def Fvp(v):
             hv = fisher(v) if fisher is not None else flat_grad(gk @ v, pol, retain_graph=True)
-            return all_mean_(hv) + self.reg_coeff * v
+            return all_mean_(hv, "fvp_all_reduce") + self.reg_coeff * v
 
         descent = fisher.conjugate_gradient(g, self.cg_iters, self.reg_coeff) if isinstance(fisher, FusedFisher) and getattr(self, "fused_cg", True) else None
         if descent is None:
@@ -751,12 +800,12 @@ class TRPO:
         if not torch.isfinite(step).all():
             return dict(loss_before=float(loss), loss_after=float(loss), kl=0.0, backtracks=-1)
         theta = flat_params(pol)
-        loss_before = float(all_mean_(loss.detach().clone().view(1)))
+        loss_before = float(all_mean_(loss.detach().clone().view(1), "line_search_all_reduce"))
         for k in range(self.max_backtracks + 1):
             set_flat_params(pol, theta - (self.backtrack_ratio ** k) * step)
             with torch.no_grad():
                 l_new, kl_new = surrogate()
-            l_new, kl_new = all_mean_(torch.stack([l_new.detach().double().reshape(()), kl_new.detach().double().reshape(())])).tolist()   # one read-back
+            l_new, kl_new = all_mean_(torch.stack([l_new.detach().double().reshape(()), kl_new.detach().double().reshape(())]), "line_search_all_reduce").tolist()   # one read-back
             if math.isfinite(l_new) and l_new < loss_before and kl_new <= self.step_size:
                 return dict(loss_before=loss_before, loss_after=l_new, kl=kl_new, backtracks=k)
         set_flat_params(pol, theta)  # line search failed: keep the old policy
@@ -775,14 +824,23 @@ class TRPO:
         if timing:
             torch.cuda.synchronize(); t2 = time.perf_counter()
             stats.update(seconds_rollout=t1 - t0, seconds_update=t2 - t1)
-        cnt = all_sum_(torch.stack([batch["episode_count"], batch["episode_return_sum"]]))
+        cnt = all_sum_(torch.stack([batch["episode_count"], batch["episode_return_sum"]]), "stats_all_reduce")
         per_env = batch["rew"].sum(0)                       # the one gather of the rollout batch (N per rank)
         stats.update(itr=self.itr, env_steps=batch["rew"].numel() * _world(), episodes=int(cnt[0]),
                      avg_return=float(cnt[1] / cnt[0]) if cnt[0] > 0 else float("nan"),
-                     avg_reward=float(all_mean_(batch["rew"].mean().view(1).clone())),
-                     gathered=int(R.gather_returns(per_env).numel()))
+                     avg_reward=float(all_mean_(batch["rew"].mean().view(1).clone(), "stats_all_reduce")),
+                     gathered=int(self._gather_returns(per_env).numel()))
         self.itr += 1
         return stats
+
+    @staticmethod
+    def _gather_returns(per_env):
+        from . import rollout as R
+        if COMM is None or _world() == 1:
+            return R.gather_returns(per_env)
+        box = []
+        COMM.run("returns_all_gather", lambda: box.append(R.gather_returns(per_env)), per_env)
+        return box[0]
 
     # ---- snapshot_mode="last" (trpo_cassie.py:9-19,50; sim_policy.py:19-23): everything a resumed run needs to BE the
     # interrupted run -- policy, baseline, iteration, and per rank the sampler state (action-noise generator, current
@@ -855,13 +913,14 @@ def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajector
     dev = "cuda:%d" % device
     bufs = env.alloc()
     torch.manual_seed(seed)  # trpo_cassie.py:53 seed=1: every rank builds the same initial policy ...
-    policy = GaussianMLPPolicy(26, env.adim, (32, 32), init_std=2.0).to(dev)
+    obs_w = env.observation_space.shape[0]  # what step() emits (26 for both kinds); the policy is sized from the env, as trpo_cassie.py does through env.spec
+    policy = GaussianMLPPolicy(obs_w, env.adim, (32, 32), init_std=2.0).to(dev)
     if dist.is_initialized() and dist.get_world_size() > 1:  # ... and rank 0's parameters are authoritative anyway
         theta = flat_params(policy)
         dist.broadcast(theta, 0)
         set_flat_params(policy, theta)
     act_map = NormalizedActions(env.action_space.low, env.action_space.high, dev)
-    algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, 26, act_map, seed=seed,
+    algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, obs_w, act_map, seed=seed,
                 env_reset_masked=lambda m: env.reset(bufs, mask=m), **kw)
     algo.env = env
     return algo

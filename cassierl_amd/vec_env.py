@@ -29,6 +29,10 @@ class Box:
     def sample(self, rng=np.random):
         return rng.uniform(self.low, self.high)
 
+    def contains(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
 
 def action_space(control_mode):
     """cassie2d.py:343-368."""
@@ -112,14 +116,22 @@ class CassieVecEnv:
 
     @property
     def observation_space(self):
-        """cassie2d.py:337-341 declares Box(26) (17 op-space values + 9 reference-gait joints); cassie_stand2d.py:241-244 declares
-        Box(17): its step() returns the 17 op-space values only.  The batched ABI always fills [n_envs, 26] (SURVEY Q5: "return 26;
-        expose 17-view"): for kind="stand" the declared space is the 17-wide one and `obs_view()` gives the matching view."""
+        """The space of the rows step() / reset() return: Box(26) for both env kinds, because the batched ABI always fills
+        [n_envs, 26] (17 op-space values + 9 reference-gait joints, cassie2d.py:337-341; SURVEY Q5: "return 26; expose 17-view").
+        A policy sized from this space fits the observations the env emits.  cassie_stand2d.py:241-244 declares Box(17) for the
+        stand env: that is `reference_observation_space`, and `obs_view()` gives the matching 17-wide view (opt-in)."""
+        high = np.full((26,), 1e20)
+        return Box(-high, high)
+
+    @property
+    def reference_observation_space(self):
+        """The observation space the reference's env class of this kind declares: Box(26) walk, Box(17) stand."""
         high = np.full((self.obs_dim,), 1e20)
         return Box(-high, high)
 
     @property
     def obs_dim(self):
+        """Width of the reference env's own observation (17 for cassie_stand2d.py, 26 for cassie2d.py); the emitted rows are 26 wide."""
         return 17 if self.kind == "stand" else 26
 
     def obs_view(self, obs):

@@ -108,7 +108,11 @@ int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev);      /*
 int CassieVecGetOpState(CassieVec* h, double* x18_dev);                      /* [n][18], operational_state_to_array order */
 void* CassieVecStatePtr(CassieVec* h);                                       /* device pointer to [n][CASSIE_STATE_STRIDE] */
 
-/* host-pointer conveniences (synchronous) */
+/* ---- NOT PART OF THE DROP-IN CONTRACT -------------------------------------------------------------------------------------
+ * Everything below this line is test / bench plumbing exported from the same library: host-pointer conveniences (synchronous
+ * copies around the device entry points above), a per-stage debug record and a timing helper.  A maintainer binding the
+ * reference against this library needs none of them (INTEGRATION.md lists the contract); they may change between rounds. */
+/* host-pointer conveniences (synchronous); tests only */
 int CassieVecStepHost(CassieVec* h, const double* actions_host, double* obs_host, double* reward_host, uint8_t* done_host);
 int CassieVecGetStateHost(CassieVec* h, double* qpos_host, double* qvel_host);
 int CassieVecSetStateHost(CassieVec* h, const double* state_host /*[n][88]*/);

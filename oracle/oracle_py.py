@@ -34,9 +34,17 @@ def make(target, srcs, force=False):
     except OSError:
         fresh = False
     if force or not fresh:
-        subprocess.check_call(["make", "-s", "-B", "-C", HERE, target])
-        with open(so + ".stamp", "w") as f:
-            f.write(want)
+        import fcntl
+        with open(os.path.join(HERE, ".make.lock"), "w") as lock:   # two pytest processes / ranks may get here together
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                fresh = (not force) and os.path.exists(so) and open(so + ".stamp").read() == want   # built while this one waited
+            except OSError:
+                fresh = False
+            if not fresh:
+                subprocess.check_call(["make", "-s", "-B", "-C", HERE, target])
+                with open(so + ".stamp", "w") as f:
+                    f.write(want)
     return so
 
 

@@ -78,10 +78,21 @@ def test_two_ranks_sharing_one_gpu_exercise_the_n_rank_path():
     there: the self-spawning launcher, the rendezvous, global env ids per shard, the gather and the max-over-ranks timing --
     with both ranks mapped to device 0 and gloo carrying the two collectives (test hooks CASSIE_DEVICE_MAP / CASSIE_BACKEND)."""
     env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo")
-    rc, out, err = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline"], env)
+    rc, out, err = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2"], env)
     assert rc == 0, err[-2000:]
     line = _line(out)
     assert line["n_gpus"] == 2 and line["config"]["envs_total"] == 4096 and line["finite"] and "extra" not in line
+    # configs[3] as written: with N > 1 the line also carries the TRPO outer loop on the sharded envs, the backend and the collectives
+    cfg = line["config"]
+    assert cfg["backend"] == "gloo" and cfg["ranks_joined"] == 2
+    tr = cfg["trpo_outer_loop"]
+    assert "error" not in tr, tr
+    assert tr["ranks"] == 2 and tr["envs_total"] == 4096 and tr["samples_per_iteration"] == 4096 * 8 and tr["iterations"] == 2
+    assert cfg["trpo_outer_loop_env_steps_per_s"] == tr["env_steps_per_s"] > 0
+    for name in ("gradient_all_reduce", "fvp_all_reduce", "line_search_all_reduce", "returns_all_gather", "baseline_all_reduce"):
+        c = tr["collectives_ms"][name]
+        assert c["calls_per_iteration"] >= 1 and c["ms_per_iteration"] >= 0.0, (name, c)
+    assert tr["collectives_ms"]["fvp_all_reduce"]["calls_per_iteration"] == 11   # one per conjugate-gradient iteration (trpo_cassie.py: cg_iters 10) + s'Hs of the step length
     # weak scaling bookkeeping: value counts the envs of BOTH ranks
     assert abs(line["value"] - 4096 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
     # the gathered returns cover both shards: same checksum as one rank stepping all 4096 envs (actions are keyed by global id)

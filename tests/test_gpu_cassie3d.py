@@ -141,6 +141,32 @@ def test_free_running_1000_substeps_within_1e5(V3, kat, tier):
     env.close()
 
 
+def test_free_running_10000_substeps_drift_within_1e5(V3, kat, tier):
+    """The drift run of tests/parity_drift.py as a test: 10 000 FREE-RUNNING torque substeps = 1000 Env.steps of
+    cassie3d_stiff.xml, smooth random torques (a new draw every 200 substeps), HIP path against the oracle from the same state and
+    the same torques, no teacher forcing; the north_star bar (1e-5 relative) at every 100th substep.  Measured: ~2e-9."""
+    import oracle_py
+    rng = np.random.default_rng(7)
+    env = V3.Cassie3dVec(1)
+    o = oracle_py.Oracle3D()
+    q0, v0 = o.state()
+    env.set_state_host(V3.state_record(q0, v0, o.warmstart())[None])
+    worst, u = 0.0, np.zeros(10)
+    for blk in range(1000):
+        if blk % 20 == 0:
+            u = rng.uniform(-0.25, 0.25, 10) * CTRL
+        env.step_host(u[None], 10)
+        for _ in range(10):
+            o.step_torque(u)
+        if (blk + 1) % 10 == 0:
+            s = env.get_state_host()[0]
+            q1, v1 = o.state()
+            worst = max(worst, np.abs(s[:21] - q1).max() / (1.0 + np.abs(q1).max()), np.abs(s[21:41] - v1).max() / (1.0 + np.abs(v1).max()))
+            assert worst < 1e-5, ((blk + 1) * 10, worst)
+    print("cassie3d[%s] 10000 free-running substeps: worst relative deviation %.3e" % (tier, worst))
+    env.close()
+
+
 def test_reset_and_batch_independence(V3, kat, tier):
     """Every environment of a batch is independent and the default reset is the standing pose with a valid warm start."""
     import torch
