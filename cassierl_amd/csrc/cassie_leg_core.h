@@ -370,27 +370,48 @@ template <class B> struct Core {
   // commands are the record's ctrl (MODE 2, and Reset's mj_forward with the stale ctrl); otherwise MODE 0 = PD law on the step's
   // action, MODE 1 = the action itself.  Bookkeeping of a substep that is carried out (cold LDS slots): setState snapshot of the
   // pre-step state, mj_data->ctrl, env clock.
-  template <int MODE, bool HF = false>
-  static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, const Terrain* hf = nullptr) {
-    // Model constants are re-read from the constant tables in every substep through indices the optimiser cannot see through
-    // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
-    // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
-    const I leg = B::opq(B::leg());
-    const KP_ K = B::kbase(leg);
+  // What one substep carries from phase to phase (r05: the substep is three functions -- set-up, sweeps, finish -- so that the
+  // 64-environments-per-wavefront kernel, cassie_duo_core.h, can run the set-up of two groups of environments, ONE joint sweep with a lane
+  // per environment, and the two finishes; the kernels of this file call them back to back: `substep`).
+  struct Sub {
+    I leg; KP_ K;
     Fact fc;
     D p1x, p1z, p2x, p2z;       // connect anchors
-    I nlim = 0, ncon = 0;
+    I nlim, ncon;
     M go;
-    // The common configuration -- no joint limit active, at most two contact pairs per leg, in EVERY environment of the wavefront
-    // (robots on their feet) -- leaves slots 6 and 7 empty: those two row slots are not built and the sweeps touch six residuals per
-    // step instead of eight (no limit steps, no third pair).  Decided per wavefront, once per substep; the arithmetic of an
-    // environment is the same either way (the skipped work adds exact zeros to rows that nobody reads).
     bool small;
-    // ---- rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
+    // rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
     D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP];
     D Ant[3];
     I kind[CAP];
     D a0, a1, a2;
+    I niter;
+  };
+
+  template <int MODE, bool HF = false>
+  static LEG_FN void sub_setup(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, Sub& s, const Terrain* hf = nullptr) {
+    // Model constants are re-read from the constant tables in every substep through indices the optimiser cannot see through
+    // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
+    // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
+    s.leg = B::opq(B::leg());
+    s.K = B::kbase(s.leg);
+    // The common configuration -- no joint limit active, at most two contact pairs per leg, in EVERY environment of the wavefront
+    // (robots on their feet) -- leaves slots 6 and 7 empty: those two row slots are not built and the sweeps touch six residuals per
+    // step instead of eight (no limit steps, no third pair).  Decided per wavefront, once per substep; the arithmetic of an
+    // environment is the same either way (the skipped work adds exact zeros to rows that nobody reads).
+    // ---- rows: slots 0,1 connect (x, z); contact pair p at slots (2 + 2p, 3 + 2p); limit j at slot 7 - j
+    s.nlim = 0; s.ncon = 0;
+    const I leg = s.leg;
+    const KP_ K = s.K;
+    Fact& fc = s.fc;
+    D &p1x = s.p1x, &p1z = s.p1z, &p2x = s.p2x, &p2z = s.p2z;
+    I &nlim = s.nlim, &ncon = s.ncon;
+    M& go = s.go;
+    bool& small = s.small;
+    D (&r)[CAP] = s.r; D (&f)[CAP] = s.f; D (&ut)[CAP][3] = s.ut; D (&Al)[CAP * (CAP + 1) / 2] = s.Al; D (&Adiag)[CAP] = s.Adiag; D (&Ainv)[CAP] = s.Ainv;
+    D (&Ant)[3] = s.Ant;
+    I (&kind)[CAP] = s.kind;
+    D &a0 = s.a0, &a1 = s.a1, &a2 = s.a2;
     {
       D qsb[3], qsl[5];
       Mass mm;
@@ -680,9 +701,21 @@ template <class B> struct Core {
       });
       a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
     }
-    B::fence();
-    lds.mark(6);
-    // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = (a0, a1, a2) = sum_j u~_j f_j is shared by the two lanes
+  }
+
+  // ---- PGS sweeps (mj_solPGS, elliptic cones) in MuJoCo's row order; a~ = (a0, a1, a2) = sum_j u~_j f_j is shared by the two lanes
+  static LEG_FN void sub_sweeps(Sub& s) {
+    const I leg = s.leg;
+    const KP_ K = s.K;
+    Fact& fc = s.fc;
+    D &p1x = s.p1x, &p1z = s.p1z, &p2x = s.p2x, &p2z = s.p2z;
+    I &nlim = s.nlim, &ncon = s.ncon;
+    M& go = s.go;
+    bool& small = s.small;
+    D (&r)[CAP] = s.r; D (&f)[CAP] = s.f; D (&ut)[CAP][3] = s.ut; D (&Al)[CAP * (CAP + 1) / 2] = s.Al; D (&Adiag)[CAP] = s.Adiag; D (&Ainv)[CAP] = s.Ainv;
+    D (&Ant)[3] = s.Ant;
+    I (&kind)[CAP] = s.kind;
+    D &a0 = s.a0, &a1 = s.a1, &a2 = s.a2;
     {
       const D mu = CP_CONTACT_MU;
       const D scale = 1.0 / (CP_MEANINERTIA * LNV);
@@ -828,10 +861,24 @@ template <class B> struct Core {
       };
       if (small) sweeps(LI<6>{});
       else sweeps(LI<CAP>{});
-      out.niter = niter;
+      s.niter = niter;
     }
-    B::fence();
-    lds.mark(7);
+  }
+
+  // ---- after the solve: total generalised force, qacc (next warm start), mj_Euler with implicit joint damping
+  template <bool HF = false>
+  static LEG_FN void sub_finish(typename B::Lds& lds, Lane& st, bool integrate, Sub& s) {
+    const I leg = s.leg;
+    const KP_ K = s.K;
+    Fact& fc = s.fc;
+    D &p1x = s.p1x, &p1z = s.p1z, &p2x = s.p2x, &p2z = s.p2z;
+    I &nlim = s.nlim, &ncon = s.ncon;
+    M& go = s.go;
+    bool& small = s.small;
+    D (&r)[CAP] = s.r; D (&f)[CAP] = s.f; D (&ut)[CAP][3] = s.ut; D (&Al)[CAP * (CAP + 1) / 2] = s.Al; D (&Adiag)[CAP] = s.Adiag; D (&Ainv)[CAP] = s.Ainv;
+    D (&Ant)[3] = s.Ant;
+    I (&kind)[CAP] = s.kind;
+    D &a0 = s.a0, &a1 = s.a1, &a2 = s.a2;
     // ---- total generalised force g = tau + J' f, accumulated from the rows' geometry (no Jacobian rows kept across the solve):
     // a force (Fx, Fz) at point p moves dof d (origin o_d, sign sigma_d) by sigma_d (Fx (pz - oz_d) - Fz (px - ox_d))
     D gb[3], gl[5], sb[3] = {D(0.0), D(0.0), D(0.0)};
@@ -927,6 +974,19 @@ template <class B> struct Core {
       }
     });
     lds.mark(9);
+  }
+
+  template <int MODE, bool HF = false>
+  static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, const Terrain* hf = nullptr) {
+    Sub s;
+    sub_setup<MODE, HF>(lds, st, from_rec, live, integrate, out, s, hf);
+    B::fence();
+    lds.mark(6);
+    sub_sweeps(s);
+    out.niter = s.niter;
+    B::fence();
+    lds.mark(7);
+    sub_finish<HF>(lds, st, integrate, s);
   }
 
   // ------------------------------------------------------------------------------------------------ operational-space state

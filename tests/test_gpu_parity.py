@@ -607,3 +607,25 @@ def test_packed_reset_kernel_agrees_with_the_wave_per_environment_reset(vec, mon
     m = mask.astype(bool)
     np.testing.assert_allclose(obss[0][0][m], obss[1][0][m], rtol=0, atol=1e-9)
     np.testing.assert_allclose(obss[0][1][~m], obss[1][1][~m], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind,mode", [("walk", "PD"), ("stand", "Torque"), ("stand", "OSC")])
+def test_declared_observation_space_contains_the_rows_the_env_emits(kind, mode, traj):
+    """a consumer that sizes its policy from env.observation_space (as trpo_cassie.py does through env.spec) must get the
+    width step() / reset() return -- 26 for both env kinds; the reference stand env's own Box(17) is `reference_observation_space`
+    with `obs_view()` as the matching view."""
+    import torch
+    from cassierl_amd.vec_env import CassieVecEnv
+    env = CassieVecEnv(64, kind=kind, control_mode=mode, n_substeps=10)
+    if kind == "walk":
+        env.set_trajectory(traj["time"], traj["qpos"])
+    space = env.observation_space
+    obs0 = env.reset().cpu().numpy()
+    a = torch.as_tensor(np.stack([env.action_space.sample(np.random.default_rng(i)) for i in range(64)]) * 0.1, device="cuda:0")
+    obs, _, _ = env.step(a)
+    obs = obs.cpu().numpy()
+    assert obs.shape[1:] == space.shape == (26,)
+    assert all(space.contains(o) for o in obs0) and all(space.contains(o) for o in obs)
+    ref = env.reference_observation_space
+    assert ref.shape == ((17,) if kind == "stand" else (26,)) and all(ref.contains(o) for o in env.obs_view(obs))
+    env.close()
