@@ -14,10 +14,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcassie2d.so")
-UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo", "tu_trpo_baseline"]
+UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_duo", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo", "tu_trpo_baseline"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("CASSIE_HIPCC_FLAGS", "").split()
+# Units that instantiate cassie_leg_core.h (two lanes per environment: one launch, segments / reset, 64 environments per wavefront) are
+# compiled with -ffp-contract=on: a multiply-add is fused where the SOURCE writes `a * b + c` in one expression (a front-end decision),
+# not where the back end's combiner finds it profitable in the code around it (hipcc's default, `fast`).  The three units compile the same
+# source into different kernels whose results are compared bit for bit (tests/test_gpu_duo.py, the segment-order tests): with `fast` the
+# back end fused one multiply-add in one kernel and not in the other (r05: state records apart by an ulp in a handful of fields).
+UNIT_FLAGS = {"tu_leg": ["-ffp-contract=on"], "tu_leg_seg": ["-ffp-contract=on"], "tu_duo": ["-ffp-contract=on"]}
 
 
 def _deps():
@@ -57,11 +63,15 @@ def _tree_hash():
     return h.hexdigest()[:16]
 
 
+def _flags_id():
+    return " ".join(FLAGS) + " | " + " ".join("%s: %s" % (u, " ".join(f)) for u, f in sorted(UNIT_FLAGS.items()))
+
+
 def _stamp_matches():
     """The objects under lib/obj were compiled with exactly the current FLAGS (an A/B or profiling build -- CASSIE_HIPCC_FLAGS --
     leaves a different stamp, and the next plain build() then recompiles everything instead of mixing objects)."""
     try:
-        return open(STAMP).read() == " ".join(FLAGS)
+        return open(STAMP).read() == _flags_id()
     except OSError:
         return False
 
@@ -72,7 +82,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     try:
-        return open(LIBSTAMP).read() != " ".join(FLAGS) + "\n" + _tree_hash()
+        return open(LIBSTAMP).read() != _flags_id() + "\n" + _tree_hash()
     except OSError:
         return True
 
@@ -102,7 +112,7 @@ def _build_locked(force, verbose, only):
         if only is not None:
             stale = u in only or not os.path.exists(obj)
         if stale:
-            cmd = [HIPCC] + FLAGS + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
+            cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(u, []) + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=CSRC)
@@ -115,9 +125,9 @@ def _build_locked(force, verbose, only):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(STAMP, "w") as f:
-        f.write(" ".join(FLAGS))
+        f.write(_flags_id())
     with open(LIBSTAMP, "w") as f:
-        f.write(" ".join(FLAGS) + "\n" + _tree_hash())
+        f.write(_flags_id() + "\n" + _tree_hash())
     return LIB
 
 

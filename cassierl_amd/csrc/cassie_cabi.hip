@@ -43,6 +43,8 @@ struct CassieVec {
   int* pending = nullptr;                    // substeps left per env after the 4-envs-per-wave kernel
   int* pending_leg = nullptr;                // substeps left per env after the two-lanes-per-env kernel (input of the 4-envs-per-wave kernel)
   bool leg = true;                           // first tier = the two-lanes-per-environment kernel (CASSIE2D_LEG=0/1 overrides the size rule)
+  double* duo_ws = nullptr;                  // workspace of the 64-environments-per-wavefront kernel (L2::duo_workspace_bytes)
+  bool duo = false;                          // ... in its 64-environments-per-wavefront form (cassie_kernels_duo.hip; CASSIE2D_DUO=0/1 overrides the size rule)
   unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
   unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
   unsigned long long substeps_requested = 0; // host: env-substeps asked for since the counters were last cleared
@@ -93,6 +95,7 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
 constexpr unsigned SEG_MIN_HANDOVERS = 96;   // hand-overs per launch from which the Env.step runs in segments (launch_physics_tiers)
+constexpr int DUO_MIN_ENVS = 49152;  // 64 environments per wavefront: 1024 wavefronts (one per SIMD) hold 65 536 environments; the pair form's two rounds of 0.7 ms are the alternative
 constexpr int LEG_MIN_ENVS = 6144;   // measured crossover (r03, bench workload): 4096 envs 0.63 ms (g16 tier) vs 0.75 ms (leg tier), 8192 envs 0.83 vs 0.74 ms
 constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
@@ -223,7 +226,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (side_by_side) {
-    L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
     L2::classify_pending(h->n, h->stream, p, h->pending_leg);
     const bool forked = hipEventRecord(h->ev_fork, h->stream) == hipSuccess && hipStreamWaitEvent(h->side, h->ev_fork, 0) == hipSuccess;
     if (forked) {
@@ -247,7 +250,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (h->leg) {
-    L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16(mode, h->n, h->stream, p2, h->pending);
@@ -403,6 +406,13 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   { const char* e = getenv("CASSIE2D_LEG"); if (e && (e[0] == '0' || e[0] == '1')) h->leg = h->g16 && e[0] == '1'; }
   if (h->cfg.flags & CASSIE_LEG_TIER_OFF) h->leg = false;
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
+  // the joint-sweep form of that tier (64 environments per wavefront) where the batch fills the chip with it: one wavefront per SIMD is
+  // 65 536 environments; below DUO_MIN_ENVS the 32-environment wavefronts of the pair form finish earlier (twice as many SIMDs busy)
+  h->duo = h->leg && n_envs >= DUO_MIN_ENVS;
+  { const char* e = getenv("CASSIE2D_DUO"); if (e && (e[0] == '0' || e[0] == '1')) h->duo = h->leg && e[0] == '1'; }
+  if (h->cfg.flags & CASSIE_DUO_TIER_OFF) h->duo = false;
+  if (h->cfg.flags & CASSIE_DUO_TIER_ON) h->duo = h->leg;
+  if (h->duo && hipMalloc(&h->duo_ws, L2::duo_workspace_bytes(n_envs)) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
@@ -428,7 +438,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->stats); hipFree(h->phase);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->duo_ws); hipFree(h->stats); hipFree(h->phase);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);

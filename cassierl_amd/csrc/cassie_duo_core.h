@@ -1,0 +1,478 @@
+// cassie_duo_core.h -- Cassie2d Env.step with 64 ENVIRONMENTS PER WAVEFRONT: the set-up of cassie_leg_core.h (one lane per leg) for two
+// groups of 32 environments, ONE joint Gauss-Seidel sweep with a lane per ENVIRONMENT, the two finishes (r05).
+//
+// Why.  In the two-lanes-per-environment kernel a Gauss-Seidel step is executed by both lanes of an environment and kept by the leg
+// that owns the row: half of the wavefront's lanes do nothing useful in the PGS sweeps, which are 74 % of that kernel's time (r03/r04
+// PMC: issued FP64 0.35 of peak, useful 0.18).  An environment's sweep is one dependent chain (MuJoCo's row order: connect L,
+// connect R, contacts L, contacts R -- every block waits for the previous one through the shared 3-vector a~), so the instruction
+// stream of a sweep cannot be shortened; what can change is how many environments one instruction serves.  Here the lane that was
+// "left leg of environment e of group A" becomes "environment e of group A" for the duration of the sweeps (it takes the right leg's
+// row data from its partner lane by one DPP exchange per word), and its partner lane becomes "environment e of group B": the same
+// ~500 instructions per sweep now advance 64 environments instead of 32, every lane the owner of every step it executes, no a~
+// exchange at all (a~ is a lane-local 3-vector).
+//
+//   per substep:   set-up(A)  set-up(B)  | transpose (DPP, ~130 doubles per lane) | joint sweeps (<= 50) | forces back | finish(A) finish(B)
+//
+// The arithmetic of an environment is the arithmetic of cassie_leg_core.h operation for operation: the set-up and the finish ARE its
+// functions (`sub_setup`, `sub_finish`), the joint sweep executes the owner lane's sequence of the pair sweep (same step functions
+// written for one lane, same order, same fused multiply-adds), and the cost accumulators of the two legs are kept apart and added in
+// the order the pair sweep adds them -- so the state trajectories are BIT-IDENTICAL to the two-lanes-per-environment kernel
+// (tests/test_gpu_duo.py; on the CPU: tests/test_leg_host.py through oracle/leg_host).
+//
+// Capacity of the joint sweep: six rows per leg (2 connect + 2 contact pairs: robots on their feet, the bench's and TRPO's regime).
+// A group in which some environment has a joint limit active or a third contact pair on a leg runs the pair sweep of
+// cassie_leg_core.h for that substep (eight rows per leg), exactly as the two-lanes kernel would; environments over eight rows per
+// leg are handed to the lower tiers through `pending` as before.
+//
+// Storage.  Two groups share one wavefront's LDS budget (40 KB at four wavefronts per CU), so the per-lane cold block shrinks to what a
+// substep itself produces and consumes (clock, smooth force, link origins, contact descriptors; `Lds` of the backend): the setState
+// snapshot, the motor commands and qstate live in the HBM record (written when they change, read where the end of the step needs them),
+// the action is read from its row.  Reference call sites as cassie_leg_core.h (Cassie2d::Step/StepPd, Cassie2d.cpp:86-117; mj_step;
+// Cassie2dEnv.step, rllab/envs/cassie2d.py:97-225, cassie_stand2d.py:86-137).
+#ifndef CASSIE_DUO_CORE_H_
+#define CASSIE_DUO_CORE_H_
+
+#include "cassie_leg_core.h"
+
+#ifndef LEG_NOUNROLL
+#define LEG_NOUNROLL _Pragma("clang loop unroll(disable)")
+#endif
+
+namespace cassie {
+namespace leg {
+
+template <class B> struct Duo : Core<B> {
+  typedef Core<B> C;
+  typedef typename B::D D;
+  typedef typename B::I I;
+  typedef typename B::M M;
+  typedef typename C::Lane Lane;
+  typedef typename C::Sub Sub;
+  typedef typename C::SubOut SubOut;
+  typedef typename C::Out Out;
+  typedef typename C::Io Io;
+
+  static constexpr int NR = 6;                   // row slots of a leg in the joint sweep: 2 connect + 2 contact pairs
+  static constexpr int NA = NR * (NR + 1) / 2;
+  static constexpr int NP = 2;
+
+  // rows of ONE LEG of the lane's environment
+  struct LegRows {
+    D r[NR], f[NR], ut[NR][3], Al[NA], Adiag[NR], Ainv[NR], Ant[NP];
+    M pair[NP];   // contact pair P exists (its two rows are K_CN / K_CT)
+  };
+
+  // Lane roles in the joint sweep: an EVEN lane (left-leg lane of the pair set-up) holds environment e of group A, an ODD lane environment
+  // e of group B.  sa / sb = the two groups' values on THIS lane (its own leg); X = 0: the environment's LEFT leg, 1: its RIGHT leg.
+  //   even lane, left leg  = own sa           even lane, right leg = partner's sa
+  //   odd lane,  left leg  = partner's sb     odd lane,  right leg = own sb
+  template <int X> static LEG_FN D pick(M even, D sa, D sb) {
+    if constexpr (X == 0) return B::sel(even, sa, B::swap(sb));
+    else return B::sel(even, B::swap(sa), sb);
+  }
+  template <int X> static LEG_FN M pickm(M even, M ma, M mb) {
+    if constexpr (X == 0) return (even & ma) | ((!even) & B::swapm(mb));
+    else return (even & B::swapm(ma)) | ((!even) & mb);
+  }
+  template <int X> static LEG_FN void gather(M even, const Sub& sa, const Sub& sb, LegRows& g) {
+    lfor<0, NR>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      g.r[Ii] = pick<X>(even, sa.r[Ii], sb.r[Ii]);
+      g.f[Ii] = pick<X>(even, sa.f[Ii], sb.f[Ii]);
+      g.Adiag[Ii] = pick<X>(even, sa.Adiag[Ii], sb.Adiag[Ii]);
+      g.Ainv[Ii] = pick<X>(even, sa.Ainv[Ii], sb.Ainv[Ii]);
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; g.ut[Ii][Bc] = pick<X>(even, sa.ut[Ii][Bc], sb.ut[Ii][Bc]); });
+      lfor<Ii, NR>([&](auto jj) {
+        constexpr int Jj = decltype(jj)::value;
+        g.Al[symidx(NR, Ii, Jj)] = pick<X>(even, sa.Al[symidx(CAP, Ii, Jj)], sb.Al[symidx(CAP, Ii, Jj)]);
+      });
+    });
+    lfor<0, NP>([&](auto pp) {
+      constexpr int P = decltype(pp)::value;
+      g.Ant[P] = pick<X>(even, sa.Ant[P], sb.Ant[P]);
+      g.pair[P] = pickm<X>(even, sa.go & (sa.ncon > I(P)), sb.go & (sb.ncon > I(P)));
+    });
+  }
+
+  // ---- the PGS sweeps of cassie_leg_core.h (`sub_sweeps`, six-row instantiation) for a lane that holds BOTH legs of its environment.
+  // Same step functions, same order (connect L, connect R, contacts L, contacts R), every lane the owner of every step; the cost
+  // accumulators of the two legs are separate (the pair sweep keeps one per lane and adds the partner's at the end).
+  static LEG_FN void joint_sweeps(LegRows& L, LegRows& R, D& a0, D& a1, D& a2, M go, I& niter_out) {
+    const D mu = CP_CONTACT_MU;
+    const D scale = 1.0 / (CP_MEANINERTIA * LNV);
+    M sweeping = go;
+    bool anyPair[2][NP];
+    lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & L.pair[P]); anyPair[1][P] = B::any(go & R.pair[P]); });
+    D accL = 0.0, accR = 0.0;
+    D rdenL[NP], rdenR[NP];
+    auto eq_step = [&](LegRows& g, D& acc, auto ss) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int S = decltype(ss)::value;
+      const M mine = sweeping;   // slots 0, 1 are K_EQ in every environment that goes
+      const D res = B::fma(g.ut[S][2], a2, B::fma(g.ut[S][1], a1, B::fma(g.ut[S][0], a0, g.r[S])));
+      D d = -(res * g.Ainv[S]);
+      D chg = d * B::fma(0.5 * g.Adiag[S], d, res);
+      d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
+      a0 = B::fma(g.ut[S][0], d, a0); a1 = B::fma(g.ut[S][1], d, a1); a2 = B::fma(g.ut[S][2], d, a2);
+      acc = acc + chg;
+      g.f[S] = g.f[S] + d;
+      lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; g.r[Ii] = B::fma(g.Al[symidx(NR, Ii, S)], d, g.r[Ii]); });
+    };
+    auto pair_step = [&](LegRows& g, D& acc, const D (&rden)[NP], auto pp) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int P = decltype(pp)::value;
+      constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+      const M mine = sweeping & g.pair[P];
+      const D rn = B::fma(g.ut[N][2], a2, B::fma(g.ut[N][1], a1, B::fma(g.ut[N][0], a0, g.r[N])));
+      const D rt = B::fma(g.ut[T][2], a2, B::fma(g.ut[T][1], a1, B::fma(g.ut[T][0], a0, g.r[T])));
+      const D on = g.f[N], ot = g.f[T];
+      const D Ann = g.Adiag[N], Att = g.Adiag[T], Ant_ = g.Ant[P];
+      const D fn_n = B::fmax(B::fma(-rn, g.Ainv[N], on), D(0.0));
+      D x = -B::fma(ot, rt, on * rn) * rden[P];
+      x = B::fmax(x, D(-1.0));
+      const M use_n = on < LMINVAL;
+      D fn = B::sel(use_n, fn_n, B::fma(x, on, on));
+      D ft = B::sel(use_n, D(0.0), B::fma(x, ot, ot));
+      const D bc = B::fma(Ant_, fn - on, B::fma(-Att, ot, rt));
+      const D x0 = -bc * g.Ainv[T];
+      const D v1 = x0 * (1.0 / mu);
+      const D val = B::fma(v1, v1, -(fn * fn));
+      const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
+      const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
+      ft = B::sel(fn >= LMINVAL, ftc, ft);
+      D dn = fn - on, dt = ft - ot;
+      D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rt)), dn * B::fma(0.5 * Ann, dn, rn));
+      const M keep = mine & (chg <= 1e-10);
+      dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+      a0 = B::fma(g.ut[T][0], dt, B::fma(g.ut[N][0], dn, a0)); a1 = B::fma(g.ut[T][1], dt, B::fma(g.ut[N][1], dn, a1)); a2 = B::fma(g.ut[T][2], dt, B::fma(g.ut[N][2], dn, a2));
+      acc = acc + chg;
+      g.f[N] = g.f[N] + dn; g.f[T] = g.f[T] + dt;
+      lfor<0, NR>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        g.r[Ii] = B::fma(g.Al[symidx(NR, Ii, T)], dt, B::fma(g.Al[symidx(NR, Ii, N)], dn, g.r[Ii]));
+      });
+    };
+    auto ray_den = [&](const LegRows& g, D (&rden)[NP], auto pp) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int P = decltype(pp)::value;
+      constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+      const D on = g.f[N], ot = g.f[T];
+      const D denom = B::fma(ot, B::fma(g.Adiag[T], ot, g.Ant[P] * on), on * B::fma(g.Ant[P], ot, g.Adiag[N] * on));
+      rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
+    };
+    I niter = 0;
+    for (int iter = 0; iter < LEG_ITERS; iter++) {
+      if (!B::any(sweeping)) break;
+      accL = 0.0; accR = 0.0;
+      lfor<0, NP>([&](auto pp) { ray_den(L, rdenL, pp); });
+      lfor<0, NP>([&](auto pp) { ray_den(R, rdenR, pp); });
+      eq_step(L, accL, LI<0>{}); eq_step(L, accL, LI<1>{});
+      eq_step(R, accR, LI<0>{}); eq_step(R, accR, LI<1>{});
+      if (anyPair[0][0]) {
+        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[0][P]) pair_step(L, accL, rdenL, pp); });
+      }
+      if (anyPair[1][0]) {
+        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[1][P]) pair_step(R, accR, rdenR, pp); });
+      }
+      const D improvement = -(accL + accR);
+      niter = niter + B::toI(sweeping);
+      sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
+    }
+    niter_out = niter;
+  }
+
+  // ------------------------------------------------------------------------------------------------ hand-over (per-wavefront workspace)
+  // The set-up of a group needs the whole register file (it is the two-lanes kernel's: 256 + 256 registers), so nothing of group A can
+  // wait in registers while group B is set up.  Left to the register allocator the hand-over was ~650 scratch accesses per substep pass,
+  // each reload waited for where it is used (r05 PMC of the first build: 41 % of the wavefront's cycles in s_waitcnt, 1.46 ms per
+  // 65 536-env step against 1.40 for the two-lanes kernel although it issued a third fewer instructions).  So the phases of a pass --
+  // set-up(g), joint sweep, finish(g) -- are made independent: EVERYTHING a group carries from one phase to the next (state, rows,
+  // factorisation, forces) goes through a per-wavefront workspace in global memory, [slot][lane] (one coalesced 512-byte access per slot),
+  // stored at the end of a phase and loaded in ONE batch at the head of the next, and the set-up / finish code exists once, in a loop over
+  // the two groups.  ~600 accesses of 512 bytes per pass and wavefront; measured beside FP64 work in isolation (1024 wavefronts, 135 KB
+  // each, the pattern of this kernel): +0..5 % -- the workspace of a wavefront is re-used every ~80 us and lives in L2 / Infinity Cache.
+  enum {
+    W_ST = 0,                                           // 24: the lane state (q, v, warm start)
+    W_ROWS = W_ST + 24, W_NROWS = 4 * NR + 3 * NR + NA + NP + 3,   // 68: the six-row subset the joint sweep takes (the forces come back in their slots)
+    W_FC = W_ROWS + W_NROWS,                            // 36: block factorisation
+    W_ANCH = W_FC + 36,                                 // 4: connect anchors
+    W_MISC = W_ANCH + 4,                                // go, ncon, sweeps done
+    W_GROUP = W_MISC + 3,                               // slots per group
+    W_N = 2 * W_GROUP
+  };
+  typedef typename B::W W;
+  template <class F> static LEG_FN void rows_each(Sub& s, int base, F&& f) {
+    int k = base + W_ROWS;
+    lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; f(k++, s.f[Ii]); });   // forces first: slots base + W_ROWS + i
+    lfor<0, NR>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      f(k++, s.r[Ii]); f(k++, s.Adiag[Ii]); f(k++, s.Ainv[Ii]);
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; f(k++, s.ut[Ii][Bc]); });
+      lfor<Ii, NR>([&](auto jj) { constexpr int Jj = decltype(jj)::value; f(k++, s.Al[symidx(CAP, Ii, Jj)]); });
+    });
+    lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; f(k++, s.Ant[P]); });
+    f(k++, s.a0); f(k++, s.a1); f(k++, s.a2);
+  }
+  template <class F> static LEG_FN void keep_each(Sub& s, int base, F&& f) {
+    int k = base + W_FC;
+    lfor<0, 15>([&](auto ii) { constexpr int Ii = decltype(ii)::value; f(k++, s.fc.Li[Ii]); });
+    lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; f(k++, s.fc.Y[Ii][Bc]); }); });
+    lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; f(k++, s.fc.G[Ii]); });
+    f(k++, s.p1x); f(k++, s.p1z); f(k++, s.p2x); f(k++, s.p2z);
+  }
+  template <class F> static LEG_FN void lane_each(Lane& st, int base, F&& f) {
+    int k = base + W_ST;
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; f(k++, st.qb[Bc]); f(k++, st.vb[Bc]); f(k++, st.wb[Bc]); });
+    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; f(k++, st.ql[Dd]); f(k++, st.vl[Dd]); f(k++, st.wl[Dd]); });
+  }
+  static LEG_FN void put_rows(W ws, int base, Sub& s) { rows_each(s, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
+  static LEG_FN void get_rows(W ws, int base, Sub& s) { rows_each(s, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
+  static LEG_FN void put_keep(W ws, int base, Sub& s) { keep_each(s, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
+  static LEG_FN void get_keep(W ws, int base, Sub& s) { keep_each(s, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
+  static LEG_FN void put_lane(W ws, int base, Lane& st) { lane_each(st, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
+  static LEG_FN void get_lane(W ws, int base, Lane& st) { lane_each(st, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
+  // masks and counts travel as doubles
+  static LEG_FN void put_misc(W ws, int base, M go, I ncon) { B::wst(ws, base + W_MISC, B::sel(go, D(1.0), D(0.0))); B::wst(ws, base + W_MISC + 1, B::toD(ncon)); }
+  static LEG_FN void get_misc(W ws, int base, M& go, I& ncon) { go = B::wld(ws, base + W_MISC) > D(0.5); ncon = B::toint(B::wld(ws, base + W_MISC + 1)); }
+
+  // rows of a group that does not run in this pass (no environment of it is live): defined values for the lanes the joint sweep masks off
+  static LEG_FN void idle_rows(Sub& s) {
+    const M none = (B::leg() == I(0)) & !(B::leg() == I(0));
+    s.go = none; s.ncon = 0; s.nlim = 0; s.niter = 0;
+    s.a0 = 0.0; s.a1 = 0.0; s.a2 = 0.0;
+    lfor<0, NR>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      s.r[Ii] = 0.0; s.f[Ii] = 0.0; s.Adiag[Ii] = 1.0; s.Ainv[Ii] = 1.0;
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; s.ut[Ii][Bc] = 0.0; });
+      lfor<Ii, NR>([&](auto jj) { constexpr int Jj = decltype(jj)::value; s.Al[symidx(CAP, Ii, Jj)] = 0.0; });
+    });
+    lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; s.Ant[P] = 0.0; });
+  }
+
+  // One joint solve for the groups of `join` (wave-uniform flags): rows in, forces and iteration counts back in the groups' Sub.
+  static LEG_FN void joint_solve(Sub (&S)[2], const bool (&join)[2]) {
+    const M even = B::leg() == I(0);
+    const M none = even & !even;
+    // environments of a group that does not take part never sweep (their lanes hold whatever that group's set-up left)
+    const M goA = join[0] ? S[0].go : none, goB = join[1] ? S[1].go : none;
+    LegRows L, R;
+    gather<0>(even, S[0], S[1], L);
+    gather<1>(even, S[0], S[1], R);
+    D a0 = B::sel(even, S[0].a0, S[1].a0), a1 = B::sel(even, S[0].a1, S[1].a1), a2 = B::sel(even, S[0].a2, S[1].a2);   // a~ is the same on both lanes of a pair
+    const M go = (even & goA) | ((!even) & goB);
+    I niter;
+    B::fence();
+    joint_sweeps(L, R, a0, a1, a2, go, niter);
+    B::fence();
+    // forces back to the leg lanes: group A's left legs sit on the even lanes (own L), its right legs on the odd lanes (partner's R);
+    // group B's left legs on the even lanes (partner's L), its right legs on the odd lanes (own R)
+    const I nsw = B::swapi(niter);
+    if (join[0]) {
+      lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S[0].f[Ii] = B::sel(even, L.f[Ii], B::swap(R.f[Ii])); });
+      S[0].niter = B::seli(even, niter, nsw);
+    }
+    if (join[1]) {
+      lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S[1].f[Ii] = B::sel(even, B::swap(L.f[Ii]), R.f[Ii]); });
+      S[1].niter = B::seli(even, nsw, niter);
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------------ fused Env.step, two groups
+  // io_of(g): the group's per-lane pointers (record, action row, observation row ...), g wave-uniform at run time; valid / o: per group.
+  // The backend's Lds is switched to a group with lds.select(g, io) before any of that group's code runs; lds.snapshot(bool): stores to the
+  // setState slots (C_KQ / C_KV) reach the record (the last substep of the step, and the end-of-step section), or are dropped (every
+  // earlier substep: only the LAST setState of a step is ever read -- by this step's observation, by the reset pass, by the next launch's
+  // controllers; an environment that leaves this tier is finished by a lower tier, which does its own setState on every substep it
+  // carries out).
+  template <int MODE, class IoOf>
+  static LEG_FN void env_step2(const EnvCfg& cfg, typename B::Lds& lds, W ws, IoOf&& io_of, const M (&valid)[2], Out (&o)[2]) {
+    const I leg = B::leg();
+    const I lo = leg * 5 + 3, ao = leg * 3;
+    const M left = leg == 0;
+    const M none = left & !left;
+    M live[2];
+    lfor<0, 2>([&](auto gg) {
+      constexpr int G = decltype(gg)::value;
+      const Io io = io_of(G);
+      lds.select(G, io);
+      Lane st;
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        st.qb[Bc] = B::pld(io.rec, I(ES_Q + Bc)); st.vb[Bc] = B::pld(io.rec, I(ES_V + Bc)); st.wb[Bc] = B::pld(io.rec, I(ES_WS + Bc));
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        st.ql[Dd] = B::pld(io.rec, lo + (ES_Q + Dd)); st.vl[Dd] = B::pld(io.rec, lo + (ES_V + Dd)); st.wl[Dd] = B::pld(io.rec, lo + (ES_WS + Dd));
+      });
+      put_lane(ws, G * W_GROUP, st);
+      const M all = valid[G] | !valid[G];
+      lds.cst(C::C_TIME, B::pld(io.rec, I(ES_TIME)), all);
+      {
+        D a2own = 0.0;
+        if (io.has_act && cfg.env_kind != 0) {
+          lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; const D a = B::pld(io.act, ao + A_); a2own += a * a; });
+          if (cfg.adim == 7) { const D a = B::pld(io.act, I(6)); a2own += B::sel(left, a * a, D(0.0)); }
+        }
+        lds.cst(C::C_A2, a2own, all);
+      }
+      live[G] = valid[G];
+      o[G].set_state = none;
+      o[G].pend = 0; o[G].niter = 0;
+      o[G].do_reset = none; o[G].bad = none;
+    });
+    B::fence();
+    bool reset_pass = false;
+    int sub = 0;
+    while (true) {
+      bool join[2] = {false, false}, ran[2] = {false, false};
+      M ovf[2] = {none, none};
+      I nit[2] = {I(0), I(0)};
+      lds.snapshot(reset_pass || sub == cfg.n_sub - 1);
+      const M lv0 = reset_pass ? o[0].do_reset : live[0], lv1 = reset_pass ? o[1].do_reset : live[1];
+      // ---- phase 1, per group: set-up; a group on its feet hands rows / factorisation to the workspace; a group that needs the eight-row
+      // sweep is carried through at once (pair layout), finish included
+      LEG_NOUNROLL
+      for (int g = 0; g < 2; g++) {
+        const M lv = g == 0 ? lv0 : lv1;
+        bool ran_ = false, join_ = false;
+        M ovf_ = none;
+        I nit_ = 0;
+        if (B::any(lv)) {
+          ran_ = true;
+          const Io io = io_of(g);
+          lds.select(g, io);
+          const int base = g * W_GROUP;
+          Lane st;
+          get_lane(ws, base, st);
+          B::fence();
+          Sub S;
+          SubOut so;
+          C::template sub_setup<MODE, false>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S);
+          ovf_ = so.overflow;
+          B::fence();
+          if (S.small) {
+            join_ = true;
+            put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
+          } else {
+            C::sub_sweeps(S);
+            B::fence();
+            nit_ = S.niter;
+            C::template sub_finish<false>(lds, st, !reset_pass, S);
+            put_lane(ws, base, st);
+          }
+          B::fence();
+        }
+        if (g == 0) { ran[0] = ran_; join[0] = join_; ovf[0] = ovf_; nit[0] = nit_; } else { ran[1] = ran_; join[1] = join_; ovf[1] = ovf_; nit[1] = nit_; }
+      }
+      // ---- phase 2: one joint sweep for the groups on their feet; the forces go back into the rows' force slots
+      if (join[0] || join[1]) {
+        Sub S[2];
+        lfor<0, 2>([&](auto gg) {
+          constexpr int G = decltype(gg)::value;
+          if (join[G]) { get_rows(ws, G * W_GROUP, S[G]); get_misc(ws, G * W_GROUP, S[G].go, S[G].ncon); }
+          else idle_rows(S[G]);
+        });
+        B::fence();
+        joint_solve(S, join);
+        B::fence();
+        lfor<0, 2>([&](auto gg) {
+          constexpr int G = decltype(gg)::value;
+          if (join[G]) {
+            lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::wst(ws, G * W_GROUP + W_ROWS + Ii, S[G].f[Ii]); });
+            B::wst(ws, G * W_GROUP + W_MISC + 2, B::toD(S[G].niter));
+          }
+        });
+        B::fence();
+        // ---- phase 3, per group: finish
+        LEG_NOUNROLL
+        for (int g = 0; g < 2; g++) {
+          if (!(g == 0 ? join[0] : join[1])) continue;
+          const Io io = io_of(g);
+          lds.select(g, io);
+          const int base = g * W_GROUP;
+          Sub S1;
+          Lane st;
+          get_lane(ws, base, st);
+          get_keep(ws, base, S1);
+          lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = B::wld(ws, base + W_ROWS + Ii); });
+          lfor<NR, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = 0.0; });   // slots 6, 7 are empty in a group on its feet
+          get_misc(ws, base, S1.go, S1.ncon);
+          const I nit_ = B::toint(B::wld(ws, base + W_MISC + 2));
+          S1.nlim = 0;
+          S1.leg = B::opq(B::leg());
+          S1.K = B::kbase(S1.leg);
+          // row kinds of a group on its feet: slots 0, 1 connect, pair P at slots 2 + 2P / 3 + 2P, no joint limit
+          S1.kind[0] = B::seli(S1.go, I(K_EQ), I(K_NONE)); S1.kind[1] = S1.kind[0];
+          lfor<0, NP>([&](auto pp) {
+            constexpr int P = decltype(pp)::value;
+            const M has = S1.go & (S1.ncon > I(P));
+            S1.kind[2 + 2 * P] = B::seli(has, I(K_CN), I(K_NONE)); S1.kind[3 + 2 * P] = B::seli(has, I(K_CT), I(K_NONE));
+          });
+          S1.kind[6] = I(K_NONE); S1.kind[7] = I(K_NONE);
+          B::fence();
+          C::template sub_finish<false>(lds, st, !reset_pass, S1);
+          put_lane(ws, base, st);
+          B::fence();
+          if (g == 0) nit[0] = nit_; else nit[1] = nit_;
+        }
+      }
+      if (!reset_pass) {
+        bool more = false;
+        lfor<0, 2>([&](auto gg) {
+          constexpr int G = decltype(gg)::value;
+          if (ran[G]) {
+            const M ov = live[G] & ovf[G];
+            o[G].pend = B::seli(ov, I(cfg.n_sub - sub + cfg.pend_extra), o[G].pend);
+            live[G] = live[G] & !ov;
+            o[G].niter = o[G].niter + B::seli(live[G], nit[G], I(0));
+            o[G].set_state = o[G].set_state | live[G];
+            more = more || B::any(live[G]);
+          }
+        });
+        sub++;
+        if (sub < cfg.n_sub && more) continue;
+      }
+      if (!cfg.want_obs) break;
+      lds.snapshot(true);
+      bool again = false;
+      lfor<0, 2>([&](auto gg) {
+        constexpr int G = decltype(gg)::value;
+        const Io io = io_of(G);
+        lds.select(G, io);
+        Lane st;
+        get_lane(ws, G * W_GROUP, st);
+        if (C::step_outputs(cfg, lds, io, st, live[G], o[G], reset_pass)) again = true;
+        put_lane(ws, G * W_GROUP, st);
+        B::fence();
+      });
+      if (reset_pass || !again) break;
+      reset_pass = true;
+    }
+    // ---- state write-back: q, v, warm start, clock, iteration count; the setState snapshot, the motor commands and qstate are in
+    // the record already (written where they changed)
+    lfor<0, 2>([&](auto gg) {
+      constexpr int G = decltype(gg)::value;
+      const Io io = io_of(G);
+      lds.select(G, io);
+      Lane st;
+      get_lane(ws, G * W_GROUP, st);
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        const M lv = valid[G] & left;
+        B::pst(io.rec, I(ES_Q + Bc), st.qb[Bc], lv); B::pst(io.rec, I(ES_V + Bc), st.vb[Bc], lv); B::pst(io.rec, I(ES_WS + Bc), st.wb[Bc], lv);
+        B::pst(io.rec, I(ES_QSTATE + Bc), D(cp_env_qinit[Bc]), lv & o[G].do_reset);
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        B::pst(io.rec, lo + (ES_Q + Dd), st.ql[Dd], valid[G]); B::pst(io.rec, lo + (ES_V + Dd), st.vl[Dd], valid[G]); B::pst(io.rec, lo + (ES_WS + Dd), st.wl[Dd], valid[G]);
+      });
+      B::pst(io.rec, I(ES_TIME), lds.cld(C::C_TIME), valid[G] & left);
+      B::pst(io.rec, I(ES_NITER), B::toD(o[G].niter), valid[G] & left);
+      B::pst(io.rec, I(ES_QPWSET), D(0.0), valid[G] & left & o[G].do_reset);
+    });
+  }
+};
+
+}  // namespace leg
+}  // namespace cassie
+#endif

@@ -1,0 +1,165 @@
+// cassie_kernels_duo.hip -- gfx950 backend and kernel of the 64-environments-per-wavefront Env.step (cassie_duo_core.h): the lane-per-leg
+// set-up of cassie_leg_core.h for two groups of 32 environments, one joint PGS sweep with a lane per environment.
+//
+//   workgroup b (one wavefront), lane 2e + k:  leg k of environment 64 b + e (group A) AND of environment 64 b + 32 + e (group B)
+//   in the sweeps:  even lane 2e = environment 64 b + e, odd lane 2e + 1 = environment 64 b + 32 + e  (both legs each)
+//
+// LDS (39 168 B per wavefront, four wavefronts per CU -- the budget of the two-lanes kernel, now for twice the environments): per group the
+// per-lane slots a substep itself produces and consumes (clock, sum of squared actions, smooth force, link origins, two contact-pair
+// descriptors); the third pair and the joint-limit descriptors exist once (a group that needs them is solved before the other group's
+// set-up begins).  What the two-lanes kernel kept in LDS for the whole step and touched once -- setState snapshot, qstate, motor commands,
+// action -- is read from / written to the HBM record and the action row where it is used (`DuoLds::cld / cst` route the slot numbers).
+#ifndef CASSIE_KERNELS_DUO_HIP_
+#define CASSIE_KERNELS_DUO_HIP_
+#include "cassie_kernels_leg.hip"
+#include "cassie_duo_core.h"
+
+namespace cassie {
+namespace leg {
+
+struct DuoShared {
+  double cold[2][20][64];    // per group: clock, a2, tau_b 3, tau_l 5, link origins x 5, z 5 (the pelvis origin is the constant 0)
+  double pr[2][2][4][64];    // per group: contact pairs 0, 1
+  double pr2[4][64];         // third pair (eight-row path only)
+  double lm[4][3][64];       // joint limits (eight-row path only)
+  int pdepth[2][2][64];
+  int pdepth2[64];
+  int lmj[4][64];
+};
+static_assert(sizeof(DuoShared) == 39168, "LDS budget of four wavefronts per CU");
+
+struct DevDuoB : DevB {
+  // per-wavefront workspace in global memory (Duo::W_*): [slot][lane], the lane's pointer is the base of its column
+  // Buffer addressing: one resource descriptor per wavefront (SGPRs), the lane's byte offset in ONE VGPR, the slot as the scalar offset
+  // of the instruction -- so a slot costs an s_mov, not a 64-bit per-lane pointer (with plain pointers the compiler materialises one
+  // pointer per slot beyond the 4 KB immediate range, ~150 of them, and spills them: first build of this path).
+  struct W { __amdgpu_buffer_rsrc_t r; unsigned voff; };
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  static LEG_FN double wld(W ws, int slot) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ws.r, ws.voff, slot * 512, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+  }
+  static LEG_FN void wst(W ws, int slot, double v) {
+    u32x2 w; w.x = (unsigned)__double2loint(v); w.y = (unsigned)__double2hiint(v);
+    __builtin_amdgcn_raw_buffer_store_b64(w, ws.r, ws.voff, slot * 512, 0);
+  }
+  struct Lds {
+    DuoShared* sh;
+    int g;
+    double* rec;
+    const double* act;
+    bool has_act, snap;
+    int lo, ao;
+    LEG_FN void mark(int) {}
+    template <class IoT> LEG_FN void select(int group, const IoT& io) { g = group; rec = io.rec; act = io.act; has_act = io.has_act; }
+    LEG_FN void snapshot(bool on) { snap = on; }
+    // slot of the group's cold block, or -1: not in LDS
+    static LEG_FN constexpr int slot(int i) {
+      return i == 24 ? 0 : i == 28 ? 1 : (i >= 29 && i < 37) ? i - 27 : (i >= 38 && i < 43) ? i - 28 : (i >= 44 && i < 49) ? i - 29 : -1;
+    }
+    LEG_FN double cld(int i) const {
+      const int l = threadIdx.x;
+      if (i < 8) return rec[ES_KQ + (i < 3 ? i : lo + (i - 3))];
+      if (i < 16) return rec[ES_KV + (i - 8 < 3 ? i - 8 : lo + (i - 11))];
+      if (i < 21) return rec[ES_QSTATE + lo + (i - 16)];
+      if (i < 24) return rec[ES_CTRL + ao + (i - 21)];
+      if (i >= 25 && i < 28) return has_act ? act[ao + (i - 25)] : 0.0;
+      if (i == 37 || i == 43) return 0.0;   // origin of the pelvis link relative to the pelvis origin
+      return sh->cold[g][slot(i)][l];
+    }
+    LEG_FN void cst(int i, double v, bool m) {
+      const int l = threadIdx.x;
+      if (i < 16) {
+        if (snap && m) { if (i < 8) rec[ES_KQ + (i < 3 ? i : lo + (i - 3))] = v; else rec[ES_KV + (i - 8 < 3 ? i - 8 : lo + (i - 11))] = v; }
+      } else if (i < 21) { if (m) rec[ES_QSTATE + lo + (i - 16)] = v; }
+      else if (i < 24) { if (m) rec[ES_CTRL + ao + (i - 21)] = v; }
+      else if (i >= 25 && i < 28) {}
+      else if (i == 37 || i == 43) {}
+      else { if (m) sh->cold[g][slot(i)][l] = v; }
+    }
+    LEG_FN void st_pair(int s, double px, double pz, double dist, double invw, int depth, bool m) {
+      if (m) {
+        const int l = threadIdx.x;
+        double* p = s < 2 ? &sh->pr[g][s][0][l] : &sh->pr2[0][l];
+        p[0] = px; p[64] = pz; p[128] = dist; p[192] = invw;
+        *(s < 2 ? &sh->pdepth[g][s][l] : &sh->pdepth2[l]) = depth;
+      }
+    }
+    LEG_FN void ld_pair(int s, double& px, double& pz, double& dist, double& invw, int& depth) const {
+      const int l = threadIdx.x;
+      if (s < 2) { px = sh->pr[g][s][0][l]; pz = sh->pr[g][s][1][l]; dist = sh->pr[g][s][2][l]; invw = sh->pr[g][s][3][l]; depth = sh->pdepth[g][s][l]; }
+      else { px = sh->pr2[0][l]; pz = sh->pr2[1][l]; dist = sh->pr2[2][l]; invw = sh->pr2[3][l]; depth = sh->pdepth2[l]; }
+    }
+    LEG_FN void st_lim(int slot_, double pos, double sgn, double invw, int j, bool m) {
+      if (m) {
+        const int l = threadIdx.x;
+        sh->lm[slot_][0][l] = pos; sh->lm[slot_][1][l] = sgn; sh->lm[slot_][2][l] = invw; sh->lmj[slot_][l] = j;
+      }
+    }
+    LEG_FN void ld_lim(int s, double& pos, double& sgn, double& invw, int& j) const {
+      const int l = threadIdx.x;
+      pos = sh->lm[s][0][l]; sgn = sh->lm[s][1][l]; invw = sh->lm[s][2][l]; j = sh->lmj[s][l];
+    }
+  };
+};
+
+typedef Duo<DevDuoB> DDuo;
+static_assert(DDuo::C::C_TIME == 24 && DDuo::C::C_A2 == 28 && DDuo::C::C_TAUB == 29 && DDuo::C::C_OX == 37 && DDuo::C::C_OZ == 43 && DDuo::C::C_N == 49 &&
+              DDuo::C::C_KQ == 0 && DDuo::C::C_KV == 8 && DDuo::C::C_QST == 16 && DDuo::C::C_CTRL == 21 && DDuo::C::C_ACT == 25, "DuoLds routes these slot numbers");
+
+// MODE: 0 PD, 1 torque, 2 motor commands from the state record.  pending[env] as env_step_leg_kernel.  workspace: duo_workspace_doubles(n)
+// doubles (W_N slots x 64 lanes per wavefront; contents only live inside one launch).
+constexpr size_t duo_workspace_doubles_per_wave = (size_t)DDuo::W_N * 64;
+template <int MODE>
+__global__ void __launch_bounds__(64, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace) {
+  __shared__ DuoShared sh;
+  const int lane = threadIdx.x;
+  EnvCfg cfg;
+  cfg.n_sub = p.n_sub; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
+  cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
+  bool valid[2];
+  size_t e[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int env = blockIdx.x * 64 + g * 32 + (lane >> 1);
+    valid[g] = env < p.n_envs;
+    e[g] = valid[g] ? (size_t)env : 0;
+  }
+  // the group's per-lane pointers, rebuilt where a phase needs them (held for the whole kernel they are 24 registers the allocator spills)
+  auto io_of = [&](int g) {
+    const int env = blockIdx.x * 64 + g * 32 + (lane >> 1);
+    const size_t eg = env < p.n_envs ? (size_t)env : 0;
+    DDuo::Io io;
+    io.rec = p.state + eg * ENV_STRIDE;
+    io.has_act = p.actions != nullptr;
+    io.act = const_cast<double*>(p.actions) + (io.has_act ? eg * p.adim : 0);
+    io.obs = p.obs + (cfg.want_obs ? eg * 26 : 0);
+    io.has_tobs = p.terminal_obs != nullptr;
+    io.tobs = p.terminal_obs + (io.has_tobs ? eg * 26 : 0);
+    io.rew = p.reward + (cfg.want_obs ? eg : 0);
+    io.done = p.done + (cfg.want_obs ? eg : 0);
+    return io;
+  };
+  DevDuoB::Lds lds;
+  lds.sh = &sh; lds.g = 0; lds.rec = p.state; lds.act = p.actions; lds.has_act = false; lds.snap = true;
+  lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
+  DDuo::Out o[2];
+  DevDuoB::W ws;   // raw buffer over this wavefront's W_N x 512 bytes (word 3: 32-bit data format, gfx9 encoding)
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)blockIdx.x * (DDuo::W_N * 64), 0, DDuo::W_N * 512, 0x00020000);
+  ws.voff = (unsigned)lane * 8u;
+  DDuo::env_step2<MODE>(cfg, lds, ws, io_of, valid, o);
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    if (valid[g] && (lane & 1) == 0) {
+      pending[e[g]] = o[g].pend;
+      if (p.stats) {
+        if (o[g].pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o[g].pend);
+        if (o[g].bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      }
+    }
+  }
+}
+
+}  // namespace leg
+}  // namespace cassie
+#endif

@@ -1093,6 +1093,135 @@ template <class B> struct Core {
     B::pst(io.rec, I(ES_QPWSET), D(0.0), live & left);
   }
 
+  // ------------------------------------------------------------------------------------------------ end of an Env.step
+  // Observation / reward / termination of the environments of `live`, stores, and the state of a terminated environment set to the
+  // reset pose.  Returns true when the caller has to run the reset pass (mj_forward only, for o.do_reset) and call this again with
+  // reset_pass = true, which stores the reset observation (and returns false).
+  static LEG_FN bool step_outputs(const EnvCfg& cfg, typename B::Lds& lds, const Io& io, Lane& st, M live, Out& o, bool reset_pass) {
+    const I leg = B::leg();
+    const I lo = leg * 5 + 3;
+    const M left = leg == 0;
+    const bool fix_kin = (cfg.flags & FLAG_FIX_STALE_KIN) != 0;
+    // ---- end-of-step section: operational-space state from the kinematics of the last setState (quirks Q1/Q2)
+    D body[4], foot[4];
+    {
+      D kqb[3], kql[5], kvb[3], kvl[5];
+      // (both sources are read and the VALUE is chosen: with a backend whose snapshot slots are plain memory -- cassie_duo_core.h: the
+      // HBM record -- "flag ? st.x : slot" becomes a load through a chosen POINTER, which keeps the whole lane state in scratch)
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        const D sq = st.qb[Bc], sv = st.vb[Bc], lq = lds.cld(C_KQ + Bc), lv = lds.cld(C_KV + Bc);
+        kqb[Bc] = fix_kin ? sq : lq; kvb[Bc] = fix_kin ? sv : lv;
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        const D sq = st.ql[Dd], sv = st.vl[Dd], lq = lds.cld(C_KQ + 3 + Dd), lv = lds.cld(C_KV + 3 + Dd);
+        kql[Dd] = fix_kin ? sq : lq; kvl[Dd] = fix_kin ? sv : lv;
+      });
+      opstate(kqb, kql, kvb, kvl, body, foot);
+    }
+    const D bodyx = body[0], zz = body[1], pitch = st.qb[2];
+    // obs[0..4] = z, pitch, xd, zd, pitchd ; own foot at obs[5 + 6 leg ..]: x - bodyx, z, 0 (Q4), xd, zd, 0 (Q4)
+    D ob[5], of[6];
+    ob[0] = zz; ob[1] = pitch; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
+    of[0] = foot[0] - bodyx; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
+    auto put = [&](typename B::P row, M m) {
+      lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, I(Ii), ob[Ii], m & left); });
+      lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, leg * 6 + (5 + Ii), of[Ii], m); });
+    };
+    if (reset_pass) {
+      // Cassie2dEnv.reset returns the 17 op-space values; the trajectory slots of the observation are zero there
+      put(io.obs, o.do_reset);
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), o.do_reset & !left); });
+      return false;
+    }
+    D ref[9];
+    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = 0.0; });
+    D reward = 0.0;
+    M done;
+    if (cfg.env_kind == 0) {
+      // reference-gait lookup (cassie2d_trajectory.py:16-19), reward (cassie2d.py:197-218); qstate is the reset pose unless
+      // FLAG_FIX_STALE_QSTATE (quirk Q3)
+      const double tmax = cfg.traj_tmax;
+      const I idx = B::toint(B::fmod(lds.cld(C_TIME), tmax) / tmax * (double)cfg.traj_n);
+      constexpr int COLS[9] = {0, 1, 2, 3, 4, 6, 8, 9, 11};
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::ldg(cfg.traj_qpos, idx * LNV + COLS[Ii]); });
+      const bool fixq = (cfg.flags & FLAG_FIX_STALE_QSTATE) != 0;
+      // joints 3,4,6 (left) and 8,9,11 (right): own hip + knee + toe, partner's by exchange; left first as in the reference
+      const D mine3 = fixq ? st.ql[0] + st.ql[1] + st.ql[3] : lds.cld(C_QST + 0) + lds.cld(C_QST + 1) + lds.cld(C_QST + 3);
+      const D other3 = B::swap(mine3);
+      D j = B::sel(left, mine3, other3);
+      j = j + B::sel(left, other3, mine3);
+      D sum = 0.0;
+      lfor<3, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; sum += ref[Ii]; });
+      j = j - sum; j = B::exp(-(j * j));
+      D pp = bodyx + zz;
+      pp = pp - (ref[0] + ref[1]); pp = B::exp(-(pp * pp));
+      D oo = pitch;
+      oo = oo - ref[2]; oo = B::exp(-(oo * oo));
+      reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
+      done = (zz < 0.6) | (zz > 1.2) | (reward < 0.6);
+    } else {
+      const D a2own = lds.cld(C_A2);
+      const D a2 = a2own + B::swap(a2own);
+      // m = (left foot x - bodyx + right foot x - bodyx) / 2, left first
+      const D fo = B::swap(of[0]);
+      const D m = (B::sel(left, of[0], fo) + B::sel(left, fo, of[0])) / 2.0;
+      reward = 0.0;
+      reward = reward - 2.0 * (0.9 - zz) * (0.9 - zz);
+      reward = reward - 2.0 * m * m;
+      reward = reward + 1.0;
+      reward = reward - 0.001 * a2;
+      done = zz < 0.5;
+    }
+    // failure guard (MuJoCo's mj_checkPos / mj_checkVel): a state outside the finite range terminates the episode
+    M okl = in_range(st.qb[0]) & in_range(st.qb[1]) & in_range(st.qb[2]) & in_range(st.vb[0]) & in_range(st.vb[1]) & in_range(st.vb[2]);
+    lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; okl = okl & in_range(st.ql[Dd]) & in_range(st.vl[Dd]); });
+    okl = okl & B::swapm(okl);
+    const M bad = live & ((!okl) | (!in_range(reward)));
+    o.bad = bad;
+    lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ob[Ii] = B::sel(bad, D(0.0), ob[Ii]); });
+    lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; of[Ii] = B::sel(bad, D(0.0), of[Ii]); });
+    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::sel(bad, D(0.0), ref[Ii]); });
+    reward = B::sel(bad, D(0.0), reward);
+    done = done | bad;
+    if (cfg.auto_reset) {
+      // the reset below also clears every NaN carrier (warm start, ctrl, setState copies)
+      lfor<0, 3>([&](auto bb) {
+        constexpr int Bc = decltype(bb)::value;
+        st.wb[Bc] = B::sel(bad, D(0.0), st.wb[Bc]);
+        lds.cst(C_KQ + Bc, D(cp_env_qinit[Bc]), bad); lds.cst(C_KV + Bc, D(0.0), bad);
+        lds.cst(C_CTRL + Bc, D(0.0), bad);
+      });
+      lfor<0, 5>([&](auto dd) {
+        constexpr int Dd = decltype(dd)::value;
+        st.wl[Dd] = B::sel(bad, D(0.0), st.wl[Dd]);
+        lds.cst(C_KQ + 3 + Dd, ldc(cp_env_qinit, lo + Dd), bad); lds.cst(C_KV + 3 + Dd, D(0.0), bad);
+      });
+      o.set_state = o.set_state | bad;
+    }
+    if (io.has_tobs) {
+      put(io.tobs, live);
+      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.tobs, I(17 + Ii), ref[Ii], live & !left); });
+    }
+    put(io.obs, live);
+    lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), ref[Ii], live & !left); });
+    B::pst(io.rew, I(0), reward, live & left);
+    B::pst8(io.done, done, live & left);
+    o.do_reset = live & done & (cfg.auto_reset != 0);
+    if (!B::any(o.do_reset)) return false;
+    // ---- Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
+    lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.qb[Bc] = B::sel(o.do_reset, D(cp_env_qinit[Bc]), st.qb[Bc]); st.vb[Bc] = B::sel(o.do_reset, D(0.0), st.vb[Bc]); });
+    lfor<0, 5>([&](auto dd) {
+      constexpr int Dd = decltype(dd)::value;
+      const D qi = ldc(cp_env_qinit, lo + Dd);
+      st.ql[Dd] = B::sel(o.do_reset, qi, st.ql[Dd]); st.vl[Dd] = B::sel(o.do_reset, D(0.0), st.vl[Dd]);
+      lds.cst(C_QST + Dd, qi, o.do_reset);
+    });
+    lds.cst(C_TIME, D(0.0), o.do_reset);
+    return true;   // the reset pose on the flat floor has 12 rows: never an overflow
+  }
+
   // ------------------------------------------------------------------------------------------------ fused Env.step
   // MODE: 0 PD (Cassie2d::StepPd), 1 torque (Cassie2d::Step), 2 motor commands from the state record (StepOsc / StepJacobian:
   // the controller kernel wrote them).  valid: the lane's environment exists.  One loop, ONE copy of the substep code: passes
@@ -1151,114 +1280,8 @@ template <class B> struct Core {
         if (sub < cfg.n_sub && B::any(live)) continue;
       }
       if (!cfg.want_obs) break;
-      // ---- end-of-step section: operational-space state from the kinematics of the last setState (quirks Q1/Q2)
-      D body[4], foot[4];
-      {
-        D kqb[3], kql[5], kvb[3], kvl[5];
-        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; kqb[Bc] = fix_kin ? st.qb[Bc] : lds.cld(C_KQ + Bc); kvb[Bc] = fix_kin ? st.vb[Bc] : lds.cld(C_KV + Bc); });
-        lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; kql[Dd] = fix_kin ? st.ql[Dd] : lds.cld(C_KQ + 3 + Dd); kvl[Dd] = fix_kin ? st.vl[Dd] : lds.cld(C_KV + 3 + Dd); });
-        opstate(kqb, kql, kvb, kvl, body, foot);
-      }
-      const D bodyx = body[0], zz = body[1], pitch = st.qb[2];
-      // obs[0..4] = z, pitch, xd, zd, pitchd ; own foot at obs[5 + 6 leg ..]: x - bodyx, z, 0 (Q4), xd, zd, 0 (Q4)
-      D ob[5], of[6];
-      ob[0] = zz; ob[1] = pitch; ob[2] = body[2]; ob[3] = body[3]; ob[4] = st.vb[2];
-      of[0] = foot[0] - bodyx; of[1] = foot[1]; of[2] = 0.0; of[3] = foot[2]; of[4] = foot[3]; of[5] = 0.0;
-      auto put = [&](typename B::P row, M m) {
-        lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, I(Ii), ob[Ii], m & left); });
-        lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(row, leg * 6 + (5 + Ii), of[Ii], m); });
-      };
-      if (reset_pass) {
-        // Cassie2dEnv.reset returns the 17 op-space values; the trajectory slots of the observation are zero there
-        put(io.obs, o.do_reset);
-        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), D(0.0), o.do_reset & !left); });
-        break;
-      }
-      D ref[9];
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = 0.0; });
-      D reward = 0.0;
-      M done;
-      if (cfg.env_kind == 0) {
-        // reference-gait lookup (cassie2d_trajectory.py:16-19), reward (cassie2d.py:197-218); qstate is the reset pose unless
-        // FLAG_FIX_STALE_QSTATE (quirk Q3)
-        const double tmax = cfg.traj_tmax;
-        const I idx = B::toint(B::fmod(lds.cld(C_TIME), tmax) / tmax * (double)cfg.traj_n);
-        constexpr int COLS[9] = {0, 1, 2, 3, 4, 6, 8, 9, 11};
-        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::ldg(cfg.traj_qpos, idx * LNV + COLS[Ii]); });
-        const bool fixq = (cfg.flags & FLAG_FIX_STALE_QSTATE) != 0;
-        // joints 3,4,6 (left) and 8,9,11 (right): own hip + knee + toe, partner's by exchange; left first as in the reference
-        const D mine3 = fixq ? st.ql[0] + st.ql[1] + st.ql[3] : lds.cld(C_QST + 0) + lds.cld(C_QST + 1) + lds.cld(C_QST + 3);
-        const D other3 = B::swap(mine3);
-        D j = B::sel(left, mine3, other3);
-        j = j + B::sel(left, other3, mine3);
-        D sum = 0.0;
-        lfor<3, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; sum += ref[Ii]; });
-        j = j - sum; j = B::exp(-(j * j));
-        D pp = bodyx + zz;
-        pp = pp - (ref[0] + ref[1]); pp = B::exp(-(pp * pp));
-        D oo = pitch;
-        oo = oo - ref[2]; oo = B::exp(-(oo * oo));
-        reward = 0.5 * j + 0.3 * pp + 0.1 * oo;
-        done = (zz < 0.6) | (zz > 1.2) | (reward < 0.6);
-      } else {
-        const D a2own = lds.cld(C_A2);
-        const D a2 = a2own + B::swap(a2own);
-        // m = (left foot x - bodyx + right foot x - bodyx) / 2, left first
-        const D fo = B::swap(of[0]);
-        const D m = (B::sel(left, of[0], fo) + B::sel(left, fo, of[0])) / 2.0;
-        reward = 0.0;
-        reward = reward - 2.0 * (0.9 - zz) * (0.9 - zz);
-        reward = reward - 2.0 * m * m;
-        reward = reward + 1.0;
-        reward = reward - 0.001 * a2;
-        done = zz < 0.5;
-      }
-      // failure guard (MuJoCo's mj_checkPos / mj_checkVel): a state outside the finite range terminates the episode
-      M okl = in_range(st.qb[0]) & in_range(st.qb[1]) & in_range(st.qb[2]) & in_range(st.vb[0]) & in_range(st.vb[1]) & in_range(st.vb[2]);
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; okl = okl & in_range(st.ql[Dd]) & in_range(st.vl[Dd]); });
-      okl = okl & B::swapm(okl);
-      const M bad = live & ((!okl) | (!in_range(reward)));
-      o.bad = bad;
-      lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ob[Ii] = B::sel(bad, D(0.0), ob[Ii]); });
-      lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; of[Ii] = B::sel(bad, D(0.0), of[Ii]); });
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; ref[Ii] = B::sel(bad, D(0.0), ref[Ii]); });
-      reward = B::sel(bad, D(0.0), reward);
-      done = done | bad;
-      if (cfg.auto_reset) {
-        // the reset below also clears every NaN carrier (warm start, ctrl, setState copies)
-        lfor<0, 3>([&](auto bb) {
-          constexpr int Bc = decltype(bb)::value;
-          st.wb[Bc] = B::sel(bad, D(0.0), st.wb[Bc]);
-          lds.cst(C_KQ + Bc, D(cp_env_qinit[Bc]), bad); lds.cst(C_KV + Bc, D(0.0), bad);
-          lds.cst(C_CTRL + Bc, D(0.0), bad);
-        });
-        lfor<0, 5>([&](auto dd) {
-          constexpr int Dd = decltype(dd)::value;
-          st.wl[Dd] = B::sel(bad, D(0.0), st.wl[Dd]);
-          lds.cst(C_KQ + 3 + Dd, ldc(cp_env_qinit, lo + Dd), bad); lds.cst(C_KV + 3 + Dd, D(0.0), bad);
-        });
-        o.set_state = o.set_state | bad;
-      }
-      if (io.has_tobs) {
-        put(io.tobs, live);
-        lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.tobs, I(17 + Ii), ref[Ii], live & !left); });
-      }
-      put(io.obs, live);
-      lfor<0, 9>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::pst(io.obs, I(17 + Ii), ref[Ii], live & !left); });
-      B::pst(io.rew, I(0), reward, live & left);
-      B::pst8(io.done, done, live & left);
-      o.do_reset = live & done & (cfg.auto_reset != 0);
-      if (!B::any(o.do_reset)) break;
-      // ---- Cassie2dEnv.reset for the terminated environments: qinit, mj_forward with the stale ctrl, no setState
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; st.qb[Bc] = B::sel(o.do_reset, D(cp_env_qinit[Bc]), st.qb[Bc]); st.vb[Bc] = B::sel(o.do_reset, D(0.0), st.vb[Bc]); });
-      lfor<0, 5>([&](auto dd) {
-        constexpr int Dd = decltype(dd)::value;
-        const D qi = ldc(cp_env_qinit, lo + Dd);
-        st.ql[Dd] = B::sel(o.do_reset, qi, st.ql[Dd]); st.vl[Dd] = B::sel(o.do_reset, D(0.0), st.vl[Dd]);
-        lds.cst(C_QST + Dd, qi, o.do_reset);
-      });
-      lds.cst(C_TIME, D(0.0), o.do_reset);
-      reset_pass = true;   // the reset pose on the flat floor has 12 rows: never an overflow
+      if (!step_outputs(cfg, lds, io, st, live, o, reset_pass)) break;
+      reset_pass = true;
     }
     // ---- state write-back
     lfor<0, 3>([&](auto bb) {

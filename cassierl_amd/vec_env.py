@@ -16,6 +16,7 @@ CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2, "Jacobian": 3}
 ENV_KINDS = {"walk": 0, "stand": 1}
 FIX_STALE_KIN, FIX_STALE_QSTATE, WAVE_PER_ENV, NO_PINV_SHORTCUT = 1, 2, 4, 8  # 8: tests only (literal SVD route)
 LEG_TIER_OFF, LEG_TIER_ON = 16, 32  # first kernel tier: never / always the two-lanes-per-environment kernel (default: by batch size)
+DUO_TIER_OFF, DUO_TIER_ON = 64, 128  # ... never / always in its 64-environments-per-wavefront form (default: from 49 152 envs)
 STATE_STRIDE = 88
 
 

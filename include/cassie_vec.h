@@ -43,6 +43,8 @@ extern "C" {
                                     certified inverse / normal-equations shortcut applies (same result) */
 #define CASSIE_LEG_TIER_OFF 16 /* never start with the two-lanes-per-environment kernel (A/B, cross-check) */
 #define CASSIE_LEG_TIER_ON 32  /* always start with it, also below the batch size where it pays (tests) */
+#define CASSIE_DUO_TIER_OFF 64 /* never run that tier in its 64-environments-per-wavefront form (A/B, cross-check) */
+#define CASSIE_DUO_TIER_ON 128 /* always run it in that form when it is the first tier (tests) */
 
 #define CASSIE_NQ 13
 #define CASSIE_NOBS 26

@@ -18,7 +18,7 @@ dp = ct.POINTER(ct.c_double)
 def _srcs():
     c = os.path.join(ROOT, "cassierl_amd", "csrc")
     return [os.path.join(HERE, "leg_host", "leg_host.cpp")] + [os.path.join(c, f) for f in (
-        "cassie_leg_core.h", "cassie2d_planar.h", "cassie2d_legk.h", "cassie_vec_layout.h", "cassie_terrain.h")]
+        "cassie_leg_core.h", "cassie_duo_core.h", "cassie2d_planar.h", "cassie2d_legk.h", "cassie_vec_layout.h", "cassie_terrain.h")]
 
 
 def lib(fast=False):
@@ -42,7 +42,8 @@ def _p(a):
 
 
 class LegHostEnv:
-    def __init__(self, n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True, flags=0):
+    def __init__(self, n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True, flags=0, duo=False):
+        self.duo = duo   # the 64-environments-per-wavefront form of the kernel (cassie_duo_core.h) instead of the two-lanes one
         self.n, self.kind, self.mode, self.n_sub, self.auto_reset, self.flags = n, kind, control_mode, n_substeps, auto_reset, flags
         self.adim = 6
         self.state = np.zeros((n, 88))
@@ -77,7 +78,7 @@ class LegHostEnv:
                                    self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)
             self.nonfinite += bad.value
             return obs, rew, done.astype(bool)
-        lib().leg_host_step(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
+        (lib().leg_host_step_duo if self.duo else lib().leg_host_step)(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
                             0 if self.kind == "walk" else 1, int(self.auto_reset), _p(self.traj_q), ct.c_double(self.traj_tmax), self.traj_n,
                             _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None, None,
                             self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)

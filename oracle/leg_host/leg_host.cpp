@@ -15,8 +15,10 @@
 #define __constant__
 #define __forceinline__ inline
 #define LEG_FN inline
+#define LEG_NOUNROLL
 #define LEG_FP_CONTRACT_OFF   /* the whole file is compiled with -ffp-contract=off; the step functions write their FMAs out */
 #include "../../cassierl_amd/csrc/cassie_leg_core.h"
+#include "../../cassierl_amd/csrc/cassie_duo_core.h"
 
 #include "lane_types.h"
 
@@ -63,6 +65,77 @@ struct HostBHF : HostB {
   }
 };
 typedef cassie::leg::Core<HostBHF> HCoreHF;
+
+
+// 64-environments-per-wavefront form (cassie_duo_core.h; the counterpart of DevDuoB in cassie_kernels_duo.hip): NL lanes carry NL / 2
+// environments of group A and NL / 2 of group B; in the joint sweep every lane holds one environment.  The cold slots are routed as on the
+// device: setState snapshot / qstate / motor commands to the record, the action from its row, the rest to per-group arrays.
+struct HostDuoB : HostB {
+  struct W { double (*p)[NL]; };
+  static VD wld(W ws, int slot) { VD r; LANES r.v[l] = ws.p[slot][l]; return r; }
+  static void wst(W ws, int slot, VD v) { LANES ws.p[slot][l] = v.v[l]; }
+  struct Lds {
+    double cold[2][20][NL];
+    double pr[2][2][4][NL], pr2[4][NL], lm[4][3][NL];
+    i64 pdepth[2][2][NL], pdepth2[NL], lmj[4][NL];
+    int g;
+    double* rec[NL];
+    const double* act[NL];
+    bool has_act, snap;
+    void mark(int) {}
+    template <class IoT> void select(int group, const IoT& io) { g = group; LANES { rec[l] = io.rec.p[l]; act[l] = io.act.p[l]; } has_act = io.has_act; }
+    void snapshot(bool on) { snap = on; }
+    static constexpr int slot(int i) {
+      return i == 24 ? 0 : i == 28 ? 1 : (i >= 29 && i < 37) ? i - 27 : (i >= 38 && i < 43) ? i - 28 : (i >= 44 && i < 49) ? i - 29 : -1;
+    }
+    static int lo(int l) { return (l & 1) * 5 + 3; }
+    static int ao(int l) { return (l & 1) * 3; }
+    VD cld(int i) const {
+      VD r;
+      LANES {
+        if (i < 8) r.v[l] = rec[l][cassie::ES_KQ + (i < 3 ? i : lo(l) + (i - 3))];
+        else if (i < 16) r.v[l] = rec[l][cassie::ES_KV + (i - 8 < 3 ? i - 8 : lo(l) + (i - 11))];
+        else if (i < 21) r.v[l] = rec[l][cassie::ES_QSTATE + lo(l) + (i - 16)];
+        else if (i < 24) r.v[l] = rec[l][cassie::ES_CTRL + ao(l) + (i - 21)];
+        else if (i >= 25 && i < 28) r.v[l] = has_act ? act[l][ao(l) + (i - 25)] : 0.0;
+        else if (i == 37 || i == 43) r.v[l] = 0.0;
+        else r.v[l] = cold[g][slot(i)][l];
+      }
+      return r;
+    }
+    void cst(int i, VD v, VM m) {
+      LANES {
+        if (!m.v[l]) continue;
+        if (i < 8) { if (snap) rec[l][cassie::ES_KQ + (i < 3 ? i : lo(l) + (i - 3))] = v.v[l]; }
+        else if (i < 16) { if (snap) rec[l][cassie::ES_KV + (i - 8 < 3 ? i - 8 : lo(l) + (i - 11))] = v.v[l]; }
+        else if (i < 21) rec[l][cassie::ES_QSTATE + lo(l) + (i - 16)] = v.v[l];
+        else if (i < 24) rec[l][cassie::ES_CTRL + ao(l) + (i - 21)] = v.v[l];
+        else if (i >= 25 && i < 28) {}
+        else if (i == 37 || i == 43) {}
+        else cold[g][slot(i)][l] = v.v[l];
+      }
+    }
+    void st_pair(VI slot_, VD px, VD pz, VD dist, VD invw, VI depth, VM m) {
+      LANES if (m.v[l]) {
+        const int s = (int)slot_.v[l];
+        double (*q)[NL] = s < 2 ? pr[g][s] : pr2;
+        q[0][l] = px.v[l]; q[1][l] = pz.v[l]; q[2][l] = dist.v[l]; q[3][l] = invw.v[l];
+        (s < 2 ? pdepth[g][s] : pdepth2)[l] = depth.v[l];
+      }
+    }
+    void ld_pair(int s, VD& px, VD& pz, VD& dist, VD& invw, VI& depth) {
+      const double (*q)[NL] = s < 2 ? pr[g][s] : pr2;
+      LANES { px.v[l] = q[0][l]; pz.v[l] = q[1][l]; dist.v[l] = q[2][l]; invw.v[l] = q[3][l]; depth.v[l] = (s < 2 ? pdepth[g][s] : pdepth2)[l]; }
+    }
+    void st_lim(VI slot_, VD pos, VD sgn, VD invw, VI j, VM m) {
+      LANES if (m.v[l]) { const int s = (int)slot_.v[l]; lm[s][0][l] = pos.v[l]; lm[s][1][l] = sgn.v[l]; lm[s][2][l] = invw.v[l]; lmj[s][l] = j.v[l]; }
+    }
+    void ld_lim(int s, VD& pos, VD& sgn, VD& invw, VI& j) {
+      LANES { pos.v[l] = lm[s][0][l]; sgn.v[l] = lm[s][1][l]; invw.v[l] = lm[s][2][l]; j.v[l] = lmj[s][l]; }
+    }
+  };
+};
+typedef cassie::leg::Duo<HostDuoB> HDuo;
 
 // lanes of the group that starts at environment e0: lane l works on environment e0 + l / 2 (a lane past the end reads the group's
 // first environment and writes nothing)
@@ -120,6 +193,65 @@ int run(double* state, const double* actions, int n, int adim, int mode, int n_s
   return 0;
 }
 
+
+// The 64-environments-per-wavefront form: one call group = NL lanes = NL / 2 environments of group A and the next NL / 2 of group B.
+int run_duo(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
+            const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
+            int* pending, int* nonfinite, int threads) {
+  cassie::leg::EnvCfg cfg;
+  cfg.n_sub = n_sub; cfg.flags = flags; cfg.env_kind = env_kind; cfg.auto_reset = auto_reset; cfg.adim = adim;
+  cfg.want_obs = obs != nullptr; cfg.traj_qpos = traj_qpos; cfg.traj_tmax = traj_tmax; cfg.traj_n = traj_n;
+  constexpr int EPG = NL / 2;
+  const int calls = (n + 2 * EPG - 1) / (2 * EPG);
+  int bad = 0;
+  (void)threads;
+#ifdef LEG_HOST_FAST
+#pragma omp parallel for schedule(static) reduction(+ : bad) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int c = 0; c < calls; c++) {
+    double dummy[32] = {0};
+    uint8_t dummy8 = 0;
+    HostDuoB::Lds lds;
+    std::memset(&lds, 0, sizeof lds);
+    lds.snap = true;
+    HDuo::Io io[2];
+    VM valid[2];
+    for (int g = 0; g < 2; g++) {
+      const int e0 = c * 2 * EPG + g * EPG;
+      const int eb = e0 < n ? e0 : 0;   // a group past the end reads environment 0 and writes nothing
+      point(io[g].rec, state, cassie::ENV_STRIDE, eb, n);
+      io[g].has_act = actions != nullptr;
+      if (actions) point(io[g].act, const_cast<double*>(actions), adim, eb, n); else LANES io[g].act.p[l] = dummy;
+      if (obs) point(io[g].obs, obs, 26, eb, n); else LANES io[g].obs.p[l] = dummy;
+      io[g].has_tobs = terminal_obs != nullptr;
+      if (terminal_obs) point(io[g].tobs, terminal_obs, 26, eb, n); else LANES io[g].tobs.p[l] = dummy;
+      if (reward) point(io[g].rew, reward, 1, eb, n); else LANES io[g].rew.p[l] = dummy;
+      LANES { const int e = e0 + (l >> 1); io[g].done.p[l] = done && e < n ? done + e : &dummy8; }
+      LANES valid[g].v[l] = e0 + (l >> 1) < n ? -1 : 0;
+    }
+    lds.select(0, io[0]);
+    HDuo::Out o[2];
+    double wsmem[HDuo::W_N][NL];
+    for (int k = 0; k < HDuo::W_N; k++) LANES wsmem[k][l] = std::nan("");   // whatever a launch finds there
+    HostDuoB::W ws; ws.p = wsmem;
+    auto io_of = [&](int g) -> const HDuo::Io& { return io[g]; };
+    if (mode == 0) HDuo::env_step2<0>(cfg, lds, ws, io_of, valid, o);
+    else if (mode == 1) HDuo::env_step2<1>(cfg, lds, ws, io_of, valid, o);
+#ifndef LEG_HOST_FAST
+    else HDuo::env_step2<2>(cfg, lds, ws, io_of, valid, o);
+#endif
+    for (int g = 0; g < 2; g++)
+      for (int k = 0; k < EPG; k++) {
+        const int e = c * 2 * EPG + g * EPG + k;
+        if (e >= n) break;
+        if (pending) pending[e] = (int)o[g].pend.v[2 * k];
+        if (o[g].bad.v[2 * k]) bad++;
+      }
+  }
+  if (nonfinite) *nonfinite += bad;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -146,6 +278,14 @@ int leg_host_step_hf(double* state, const double* actions, int n, int adim, int 
                                           obs, reward, done, nullptr, pending, nonfinite, threads);
 }
 #endif
+
+// ... through the 64-environments-per-wavefront form of the kernel (cassie_duo_core.h): same arguments, bit-identical results
+int leg_host_step_duo(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
+                      const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
+                      int* pending, int* nonfinite, int threads) {
+  return run_duo(state, actions, n, adim, mode, n_sub, flags, env_kind, auto_reset, traj_qpos, traj_tmax, traj_n, obs, reward, done, terminal_obs,
+                 pending, nonfinite, threads);
+}
 
 int leg_host_lanes(void) { return NL; }
 

@@ -20,14 +20,15 @@ def pytest_configure(config):
         config.option.durations_min = 1.0
 
 
-@pytest.fixture(params=["g16", "leg"])
+@pytest.fixture(params=["g16", "leg", "duo"])
 def vec_tier(request):
     """CassieVecEnv with the FIRST physics tier pinned: "g16" = four environments per wavefront (what a small batch gets by the
     size rule), "leg" = the two-lanes-per-environment kernel (`env_step_leg_kernel`, the kernel behind the bench headline, which
     the size rule only selects from 6144 environments up).  The oracle / golden-stream tests take this fixture so that the
-    driver's plain `pytest -m gpu` run pins BOTH against the oracle, whatever the batch size of the test."""
-    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_OFF, LEG_TIER_ON
-    add = LEG_TIER_ON if request.param == "leg" else LEG_TIER_OFF
+    driver's plain `pytest -m gpu` run pins BOTH against the oracle, whatever the batch size of the test.  "duo" (r05) = that tier in its
+    64-environments-per-wavefront form (`env_step_duo_kernel`: the kernel behind the headline from 49 152 environments up)."""
+    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_OFF, LEG_TIER_ON, DUO_TIER_ON, DUO_TIER_OFF
+    add = {"leg": LEG_TIER_ON | DUO_TIER_OFF, "duo": LEG_TIER_ON | DUO_TIER_ON, "g16": LEG_TIER_OFF}[request.param]
 
     def make(*a, flags=0, **k):
         return CassieVecEnv(*a, flags=flags | add, **k)

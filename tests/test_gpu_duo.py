@@ -1,0 +1,107 @@
+"""The 64-environments-per-wavefront form of the first physics tier (cassierl_amd/csrc/cassie_duo_core.h, env_step_duo_kernel) on the
+GPU against the two-lanes-per-environment form (env_step_leg_kernel): BIT-IDENTICAL state records, observations, rewards, done flags
+-- also where environments leave the tier and are finished by the lower tiers.  (Against the oracle: the `[duo]` ids of the vec_tier
+fixture in test_gpu_parity.py / test_gpu_ctrl.py.)  -m gpu only."""
+import numpy as np
+import pytest
+
+from conftest import state_vec
+
+pytestmark = pytest.mark.gpu
+PD_LO, PD_HI = np.radians([-50, -164, -140] * 2), np.radians([80, -37, -30] * 2)
+TQ = np.array([12.0, 12.0, 0.9] * 2)
+
+
+def _envs(n, **kw):
+    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_ON, DUO_TIER_ON, DUO_TIER_OFF
+    flags = kw.pop("flags", 0)
+    return (CassieVecEnv(n, flags=flags | LEG_TIER_ON | DUO_TIER_OFF, **kw), CassieVecEnv(n, flags=flags | LEG_TIER_ON | DUO_TIER_ON, **kw))
+
+
+def _same(a, b, what):
+    assert np.array_equal(a, b, equal_nan=True), (what, np.argwhere(a != b)[:6].tolist())
+
+
+def _close(a, b, what, tol=1e-13):
+    """Observation / reward: the end-of-step arithmetic (operational-space state, reward) is compiled with floating-point contraction
+    on in both kernels, and the compiler fuses a multiply-add here and not there: values within an ulp or two, flags identical.  The
+    STATE (everything the next step depends on) must be bit-identical."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), what
+    d = np.nanmax(np.abs(a - b) / (1.0 + np.abs(b))) if a.size else 0.0
+    assert d <= tol, (what, d)
+
+
+@pytest.mark.parametrize("n", [8, 37, 4096 + 45, 65536])
+def test_walk_pd_rollout_with_resets_is_bit_identical(n, traj):
+    """The bench's regime (walk env, PD, random targets, every step resets): set-up of two groups, joint sweep, reset pass; batch
+    sizes with an empty group B (8), a partly filled one (37), a partly filled last wavefront, the bench's own."""
+    import torch
+    from cassierl_amd import rollout as R
+    pair, duo = _envs(n, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True)
+    ids = torch.arange(n, device="cuda:0")
+    outs = []
+    for env in (pair, duo):
+        env.set_trajectory(traj["time"], traj["qpos"])
+        bufs = env.alloc()
+        env.reset(bufs)
+        rows = []
+        for t in range(12 if n > 10000 else 25):
+            o, r, d = env.step(R.random_actions(1, ids, t, PD_LO, PD_HI), bufs)
+            rows.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+        outs.append((rows, env.get_full_state_host(), env.counters()))
+    for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        _close(a[0], b[0], (t, "obs")); _close(a[1], b[1], (t, "reward")); _same(a[2], b[2], (t, "done"))
+    _same(outs[0][1], outs[1][1], "state records")
+    assert outs[0][2]["cleanup_substeps"] == outs[1][2]["cleanup_substeps"] == 0
+    pair.close(); duo.close()
+
+
+@pytest.mark.parametrize("kind,mode,auto_reset", [("stand", "Torque", False), ("stand", "PD", True), ("stand", "Torque", True)])
+def test_falling_robots_through_the_tiers_are_bit_identical(kind, mode, auto_reset, traj):
+    """Robots that fall, hit their joint limits and lie on the ground: eight-row sweeps inside the kernel, groups of a wavefront that
+    differ in which sweep they take, environments handed to the lower tiers (which finish the step: the records are compared AFTER
+    them, setState snapshot included)."""
+    import torch
+    from cassierl_amd import rollout as R
+    n = 8192 + 19
+    pair, duo = _envs(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=auto_reset)
+    ids = torch.arange(n, device="cuda:0")
+    lo, hi = (-TQ, TQ) if mode == "Torque" else (PD_LO, PD_HI)
+    outs = []
+    for env in (pair, duo):
+        bufs = env.alloc()
+        env.reset(bufs)
+        rows = []
+        for t in range(60):
+            o, r, d = env.step(R.random_actions(3, ids, t, lo, hi), bufs)
+            if t % 6 == 5:
+                rows.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+        outs.append((rows, env.get_full_state_host(), env.counters()))
+    for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        _close(a[0], b[0], (t, "obs")); _close(a[1], b[1], (t, "reward")); _same(a[2], b[2], (t, "done"))
+    _same(outs[0][1], outs[1][1], "state records")
+    assert outs[0][2]["cleanup_substeps"] == outs[1][2]["cleanup_substeps"]
+    if not auto_reset:
+        assert outs[0][2]["cleanup_substeps"] > 0, "the run must include hand-overs"
+    pair.close(); duo.close()
+
+
+def test_osc_controller_in_the_loop_is_bit_identical():
+    """configs[2]: the OSC controller kernel writes the motor commands, the physics substep is this tier in MODE 2 (one substep per launch)."""
+    import torch
+    from cassierl_amd import rollout as R
+    n = 4096 + 3
+    pair, duo = _envs(n, kind="stand", control_mode="OSC", n_substeps=10, auto_reset=True)
+    ids = torch.arange(n, device="cuda:0")
+    lo, hi = np.array([-2.0, -2.0, -2.0, 0.0, -2.0, 0.0, -2.0]), np.full(7, 2.0)
+    outs = []
+    for env in (pair, duo):
+        bufs = env.alloc()
+        env.reset(bufs)
+        for t in range(8):
+            o, r, d = env.step(R.random_actions(4, ids, t, lo, hi), bufs)
+        outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), env.get_full_state_host()))
+    _close(outs[0][0], outs[1][0], "obs"); _close(outs[0][1], outs[1][1], "reward")
+    _same(outs[0][2], outs[1][2], "state records")
+    pair.close(); duo.close()
