@@ -30,7 +30,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
-DOMINANT_KERNEL = "cassie::leg::env_step_leg_kernel<0>"  # the kernel one bench step launches (PD mode, flat floor, >= 6144 envs)
+def dominant_kernel(n_envs):
+    """The kernel one bench step launches (PD mode, flat floor), by the library's size rule (cassie_cabi.hip: DUO_MIN_ENVS, LEG_MIN_ENVS)."""
+    return ("cassie::leg::env_step_duo_kernel<0>" if n_envs >= 49152 else
+            "cassie::leg::env_step_leg_kernel<0>" if n_envs >= 6144 else "cassie::g16::env_step_g16_kernel<0, false>")
+
+
+# Schema of the JSON line (ADVICE r4: the meaning of `roofline` and `cpu_baseline` changed between rounds; a reader comparing BENCH_rNN
+# files must not mix them): r01-r03 roofline = HBM (GB/s); from r04 roofline.bound = fp64_valu (useful TFLOP/s; HBM under roofline.hbm)
+# and cpu_baseline.value = the same-source AVX-512 leg (the oracle's leg under cpu_baseline.oracle).
+BENCH_SCHEMA = "r05 (roofline: fp64_valu useful flops, hbm sub-object; cpu_baseline: same-source leg with per_threads / cpu_quota, oracle nested)"
 PREROLL_STEPS_AT_64K = int(os.environ.get("CASSIE_BENCH_PREROLL_STEPS", "300"))     # untimed Env.steps before the timed region at 65 536 envs, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # SURVEY.md 8(d): state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
@@ -464,6 +473,16 @@ def extra_workloads(traj, n):
     dt = time.perf_counter() - t0
     row = dict(workload="configs[4]_cassie3d_torque_random", note="cassie3d_stiff.xml physics, random torques, robots fall during the run",
                envs=n3, warmup_steps=30, steps=30, env_steps_per_s=n3 * 30 / dt, ms_per_step=dt / 30 * 1e3)
+    try:   # roofline of configs[4]: counted useful FP64 flops of exactly this workload (tests/count_flops.py, op-counting CPU build of
+        # the lane-per-leg kernel's source) / the measured step time, against the FP64 vector peak
+        uf = json.load(open(os.path.join(ROOT, "profiles", "useful_flops.json")))["cassie3d_torque_random"]["flop_per_env_step"]
+        ach = uf * n3 * 30 / dt / 1e12
+        row["roofline"] = dict(bound="fp64_valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_VALU_PEAK_TFLOPS,
+                               useful_flop_per_env_step=uf, kernel="cassie3d::leg::env_step3d_leg_kernel<32> (+ its hand-over tier)",
+                               note="16 environments per wavefront, one wavefront per SIMD at 16 384 envs: the step time is ONE wavefront's dependent chain "
+                                    "(500 Gauss-Seidel sweeps of ~11 us), not throughput; issued FP64 and HBM bytes: profiles/<tag>_pmc.json, section cassie3d")
+    except Exception:
+        pass
     if hasattr(e3, "counters"):
         row.update(e3.counters())
     e3.close()
@@ -653,11 +672,11 @@ def worker(args):
             pmc = {}
         from cassierl_amd.build import source_hash
         pmc_ok = pmc.get("envs") == n_local and pmc.get("csrc_sha16") == source_hash()
-        dominant = (pmc.get("dominant_kernel") if pmc_ok else None) or DOMINANT_KERNEL
+        dominant = (pmc.get("dominant_kernel") if pmc_ok else None) or dominant_kernel(n_local)
         line = {
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "schema": BENCH_SCHEMA,
             "config": {"workload": "%d parallel Cassie2d envs per GPU (%s), random-policy rollout, PD mode, 10 substeps/step, walk env "
                                    "reward/done/auto-reset, reference semantics (flags=0)"
                                    % (n_local, "BASELINE north_star target size; configs[1] workload" if n_local == ENVS_PER_GPU else

@@ -30,6 +30,7 @@ namespace leg {
 // the whole chip (r04: 7.55 -> ... ms per step).  The idle lanes cost nothing: a wave instruction takes the same time either way.
 template <int LANES>
 struct DevB3 {
+  struct OwnerScope { LEG_FN OwnerScope(bool) {} };   // (operation counting exists in the CPU emulation only)
   typedef double D;
   typedef int I;
   typedef bool M;

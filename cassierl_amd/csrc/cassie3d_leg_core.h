@@ -768,6 +768,7 @@ template <class B> struct Core3 {
         lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::fma(ut[Bc], d, at[Bc]); });
       };
       auto eq_step = [&](auto ss, M mine) {   // a connect row: unclamped
+        typename B::OwnerScope scope_(mine);   // op-counting builds of the CPU emulation only (tests/count_flops.py); empty on the device
         constexpr int S = decltype(ss)::value;
         const D res = (B::fma(eq[S].R, eq[S].f, eq[S].b) + dot_c(eq[S].jl)) + dot_a(eq[S].ut);
         D d = -(res * eq[S].ai);
@@ -779,6 +780,7 @@ template <class B> struct Core3 {
         eq[S].f = eq[S].f + d;
       };
       auto lim_step = [&](I base_, M mine) {   // a joint limit: f >= 0
+        typename B::OwnerScope scope_(mine);
         LEG3_STAT(1);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
         LRow r; lload(base, r);
@@ -794,6 +796,7 @@ template <class B> struct Core3 {
         lds.stv(base + R3_F, r.f + d, keep);
       };
       auto contact = [&](I base_, M mine) {
+        typename B::OwnerScope scope_(mine);
         LEG3_STAT(2);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
         CRow r0, r1, r2;

@@ -105,24 +105,29 @@ template <class B> struct Duo : Core<B> {
     lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & L.pair[P]); anyPair[1][P] = B::any(go & R.pair[P]); });
     D accL = 0.0, accR = 0.0;
     D rdenL[NP], rdenR[NP];
-    auto eq_step = [&](LegRows& g, D& acc, auto ss) {
+    // FULL (compile time): every lane of the wavefront is sweeping and has both contact pairs on both legs (64 robots on their feet, none
+    // converged yet: the common case) -- the ownership / "still sweeping" selects are identities and are left out.  Same arithmetic.
+    auto eq_step = [&](LegRows& g, D& acc, auto ss, auto full_) {
       LEG_FP_CONTRACT_OFF
       constexpr int S = decltype(ss)::value;
-      const M mine = sweeping;   // slots 0, 1 are K_EQ in every environment that goes
+      constexpr bool FULL = decltype(full_)::value != 0;
       const D res = B::fma(g.ut[S][2], a2, B::fma(g.ut[S][1], a1, B::fma(g.ut[S][0], a0, g.r[S])));
       D d = -(res * g.Ainv[S]);
       D chg = d * B::fma(0.5 * g.Adiag[S], d, res);
-      d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
+      if constexpr (!FULL) {
+        const M mine = sweeping;   // slots 0, 1 are K_EQ in every environment that goes
+        d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
+      }
       a0 = B::fma(g.ut[S][0], d, a0); a1 = B::fma(g.ut[S][1], d, a1); a2 = B::fma(g.ut[S][2], d, a2);
       acc = acc + chg;
       g.f[S] = g.f[S] + d;
       lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; g.r[Ii] = B::fma(g.Al[symidx(NR, Ii, S)], d, g.r[Ii]); });
     };
-    auto pair_step = [&](LegRows& g, D& acc, const D (&rden)[NP], auto pp) {
+    auto pair_step = [&](LegRows& g, D& acc, const D (&rden)[NP], auto pp, auto full_) {
       LEG_FP_CONTRACT_OFF
       constexpr int P = decltype(pp)::value;
+      constexpr bool FULL = decltype(full_)::value != 0;
       constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
-      const M mine = sweeping & g.pair[P];
       const D rn = B::fma(g.ut[N][2], a2, B::fma(g.ut[N][1], a1, B::fma(g.ut[N][0], a0, g.r[N])));
       const D rt = B::fma(g.ut[T][2], a2, B::fma(g.ut[T][1], a1, B::fma(g.ut[T][0], a0, g.r[T])));
       const D on = g.f[N], ot = g.f[T];
@@ -142,7 +147,8 @@ template <class B> struct Duo : Core<B> {
       ft = B::sel(fn >= LMINVAL, ftc, ft);
       D dn = fn - on, dt = ft - ot;
       D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rt)), dn * B::fma(0.5 * Ann, dn, rn));
-      const M keep = mine & (chg <= 1e-10);
+      M keep = chg <= 1e-10;
+      if constexpr (!FULL) keep = keep & (sweeping & g.pair[P]);
       dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
       a0 = B::fma(g.ut[T][0], dt, B::fma(g.ut[N][0], dn, a0)); a1 = B::fma(g.ut[T][1], dt, B::fma(g.ut[N][1], dn, a1)); a2 = B::fma(g.ut[T][2], dt, B::fma(g.ut[N][2], dn, a2));
       acc = acc + chg;
@@ -161,18 +167,36 @@ template <class B> struct Duo : Core<B> {
       rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
     };
     I niter = 0;
-    for (int iter = 0; iter < LEG_ITERS; iter++) {
+    int iter = 0;
+    // two loops, not one loop with two bodies (one loop with both bodies: the allocator shuffles the row data between the register files,
+    // 228 moves per pass instead of 80): sweeps while every lane is a sweeping robot with two pairs per leg, then the general sweeps
+    if (!B::any(!(go & L.pair[0] & L.pair[1] & R.pair[0] & R.pair[1]))) {
+      for (; iter < LEG_ITERS; iter++) {
+        if (B::any(!sweeping)) break;
+        accL = 0.0; accR = 0.0;
+        lfor<0, NP>([&](auto pp) { ray_den(L, rdenL, pp); });
+        lfor<0, NP>([&](auto pp) { ray_den(R, rdenR, pp); });
+        eq_step(L, accL, LI<0>{}, LI<1>{}); eq_step(L, accL, LI<1>{}, LI<1>{});
+        eq_step(R, accR, LI<0>{}, LI<1>{}); eq_step(R, accR, LI<1>{}, LI<1>{});
+        lfor<0, NP>([&](auto pp) { pair_step(L, accL, rdenL, pp, LI<1>{}); });
+        lfor<0, NP>([&](auto pp) { pair_step(R, accR, rdenR, pp, LI<1>{}); });
+        const D improvement = -(accL + accR);
+        niter = niter + 1;
+        sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
+      }
+    }
+    for (; iter < LEG_ITERS; iter++) {
       if (!B::any(sweeping)) break;
       accL = 0.0; accR = 0.0;
       lfor<0, NP>([&](auto pp) { ray_den(L, rdenL, pp); });
       lfor<0, NP>([&](auto pp) { ray_den(R, rdenR, pp); });
-      eq_step(L, accL, LI<0>{}); eq_step(L, accL, LI<1>{});
-      eq_step(R, accR, LI<0>{}); eq_step(R, accR, LI<1>{});
+      eq_step(L, accL, LI<0>{}, LI<0>{}); eq_step(L, accL, LI<1>{}, LI<0>{});
+      eq_step(R, accR, LI<0>{}, LI<0>{}); eq_step(R, accR, LI<1>{}, LI<0>{});
       if (anyPair[0][0]) {
-        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[0][P]) pair_step(L, accL, rdenL, pp); });
+        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[0][P]) pair_step(L, accL, rdenL, pp, LI<0>{}); });
       }
       if (anyPair[1][0]) {
-        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[1][P]) pair_step(R, accR, rdenR, pp); });
+        lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[1][P]) pair_step(R, accR, rdenR, pp, LI<0>{}); });
       }
       const D improvement = -(accL + accR);
       niter = niter + B::toI(sweeping);

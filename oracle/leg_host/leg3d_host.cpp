@@ -62,6 +62,14 @@ int leg3d_host_step(double* state, const double* torques, int n, int n_sub, int 
 }
 
 int leg3d_host_lanes(void) { return NL; }
+// arithmetic operations counted since the last call (lane_types.h: g_ops; 0 in the LEG_HOST_FAST builds)
+double leg3d_host_ops(void) {
+#ifdef LEG_HOST_FAST
+  return 0.0;
+#else
+  double r = g_ops; g_ops = 0.0; return r;
+#endif
+}
 #ifdef LEG3_STATS
 void leg3d_host_stats(long long* out4) { for (int i = 0; i < 4; i++) { out4[i] = g_leg3_stat[i]; g_leg3_stat[i] = 0; } }
 #endif

@@ -85,9 +85,9 @@ def workload(src, wl, want, envs, units_per_launch_name):
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", tag)
-    pd = workload(src, "pd", ("env_step_leg_kernel", "env_step_g16_kernel", "env_step_kernel"), 65536, "one Env.step of 65 536 envs (10 substeps), walk env / PD, reference semantics")
-    osc = workload(src, "osc", ("env_ctrl_g16_kernel", "env_ctrl_kernel", "env_step_leg_kernel<2", "env_step_g16_kernel<2", "env_step_kernel<2"), 65536, "one Env.step of 65 536 envs = 10 x (controller kernel + physics kernel + hand-over pass), stand env / OSC QP in every substep; per-dispatch means, i.e. per SUBSTEP for these kernels")
-    c3 = workload(src, "c3", ("env_step3d_kernel",), 16384, "one 10-substep step of 16 384 Cassie3d envs, torque mode")
+    pd = workload(src, "pd", ("env_step_duo_kernel", "env_step_leg_kernel", "env_step_g16_kernel", "env_step_kernel"), 65536, "one Env.step of 65 536 envs (10 substeps), walk env / PD, reference semantics")
+    osc = workload(src, "osc", ("env_ctrl_g16_kernel", "env_ctrl_kernel", "env_step_duo_kernel<2", "env_step_leg_kernel<2", "env_step_g16_kernel<2", "env_step_kernel<2", "env_osc_fused"), 65536, "one Env.step of 65 536 envs = 10 x (controller kernel + physics kernel + hand-over pass), stand env / OSC QP in every substep; per-dispatch means, i.e. per SUBSTEP for these kernels")
+    c3 = workload(src, "c3", ("env_step3d_leg_kernel", "env_step3d_kernel", "env_step3d_pair_kernel"), 16384, "one 10-substep step of 16 384 Cassie3d envs, torque mode")
     summary = dict(source="profiles/collect_pmc.sh %s: rocprofv3 --pmc, one run per counter group, no tracing; see the docstring of profiles/summarize_pmc.py "
                           "for units and the gfx950 FETCH_SIZE correction" % tag, pd=pd, osc=osc, cassie3d=c3)
     with open(os.path.join(HERE, tag + "_pmc.json"), "w") as f:

@@ -18,6 +18,44 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+def count_cassie3d(n=16, warm=30, steps=30):
+    """configs[4] as the bench line runs it: Cassie3d, torque mode, U(+-ctrlrange) redrawn every env-step (stream 5 of rollout.random_actions),
+    30 env-steps of warm-up from the standing pose, 30 counted (the robots fall during the run), no reset.  Source of the lane-per-leg kernel
+    (cassierl_amd/csrc/cassie3d_leg_core.h) through oracle/leg_host/leg3d_host.cpp with the counting lane type; inside a Gauss-Seidel step
+    only the owner leg's lane counts.  An environment that leaves the row capacity of the kernel is frozen here (the lower tier of the GPU
+    path finishes it there): its substeps are not counted, their share is reported."""
+    import ctypes as ct
+    import subprocess
+    import torch
+    import oracle_py as O
+    from cassierl_amd import rollout as R
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libleg3d_host_count.so"])
+    L = ct.CDLL(os.path.join(ROOT, "oracle", "libleg3d_host_count.so"))
+    L.leg3d_host_ops.restype = ct.c_double
+    assert L.leg3d_host_lanes() == 2
+    CTRL = np.array([4.5, 4.5, 12.2, 12.2, 0.9] * 2)
+    o = O.Oracle3D()
+    q, v = o.state()
+    rec = np.zeros(80)
+    rec[:21], rec[21:41], rec[41:61] = q, v, o.warmstart()
+    state = np.tile(rec, (n, 1)).copy()
+    dp, ip = ct.POINTER(ct.c_double), ct.POINTER(ct.c_int)
+    pend, nit = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    ids = torch.arange(n)
+    sweeps, frozen, done = 0.0, 0, 0
+    for t in range(warm + steps):
+        if t == warm:
+            L.leg3d_host_ops()
+        a = np.ascontiguousarray(R.random_actions(5, ids, t, -CTRL, CTRL).numpy())
+        L.leg3d_host_step(state.ctypes.data_as(dp), a.ctypes.data_as(dp), n, 10, 1, pend.ctypes.data_as(ip), nit.ctypes.data_as(ip), None)
+        if t >= warm:
+            sweeps += nit.sum(); frozen += int(pend.sum()); done += 10 * n - int(pend.sum())
+    ops = L.leg3d_host_ops()
+    return dict(flop_per_env_step=ops / max(1, done) * 10.0, pgs_sweeps_per_env_step=float(sweeps) / max(1, done) * 10.0, envs=n, env_steps=steps,
+                substeps_not_counted_frac=frozen / (10.0 * n * steps),
+                convention="as pd_bench; per env-step of 10 substeps CARRIED OUT by this kernel; robots fall during the counted steps")
+
+
 def main():
     import torch
     import oracle_py as O
@@ -50,6 +88,8 @@ def main():
                          convention="+,-,* = 1 (a*b+c = 2); /, sqrt, 1/x, exp = 1; sincos = 2; compare/select/move = 0; in a Gauss-Seidel step only "
                                     "the owner leg's lane counts; the reset pass of a terminated environment is included")
         print(name, json.dumps(out[name]))
+    out["cassie3d_torque_random"] = count_cassie3d()
+    print("cassie3d_torque_random", json.dumps(out["cassie3d_torque_random"]))
     with open(os.path.join(ROOT, "profiles", "useful_flops.json"), "w") as f:
         json.dump(out, f, indent=1)
 

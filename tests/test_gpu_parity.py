@@ -445,7 +445,9 @@ def test_g16_and_wave_per_env_kernels_agree(vec, traj):
     rng = np.random.default_rng(17)
     a = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True)
     b = vec(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
-    np.testing.assert_array_equal(a.reset_host(), b.reset_host())
+    # (the packed reset runs the two-lanes-per-environment core, the other handle the wave-per-environment reset kernel: two formulations of the
+    # same mj_forward, equal to rounding -- bitwise only by accident of how the compiler fused their multiply-adds)
+    np.testing.assert_allclose(a.reset_host(), b.reset_host(), rtol=0, atol=1e-13)
     saw_overflow = False
     for t in range(150):
         acts = rng.uniform(-1, 1, (n, 6)) * TQ * (0.2 if t < 100 else 1.0)
