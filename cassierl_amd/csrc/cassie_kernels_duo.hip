@@ -17,6 +17,14 @@
 namespace cassie {
 namespace leg {
 
+#ifndef DUO_WAVES
+#define DUO_WAVES 2   // independent wavefronts per workgroup (no barrier, no shared data).  A/B r05, 65 536 envs: 1 -> 1.146 ms, 2 -> 1.125, 4 -> 1.129
+#endif
+#if DUO_WAVES == 1
+#define DUO_LANE ((int)threadIdx.x)
+#else
+#define DUO_LANE ((int)threadIdx.x & 63)
+#endif
 struct DuoShared {
   double cold[2][20][64];    // per group: clock, a2, tau_b 3, tau_l 5, link origins x 5, z 5 (the pelvis origin is the constant 0)
   double pr[2][2][4][64];    // per group: contact pairs 0, 1
@@ -58,7 +66,7 @@ struct DevDuoB : DevB {
       return i == 24 ? 0 : i == 28 ? 1 : (i >= 29 && i < 37) ? i - 27 : (i >= 38 && i < 43) ? i - 28 : (i >= 44 && i < 49) ? i - 29 : -1;
     }
     LEG_FN double cld(int i) const {
-      const int l = threadIdx.x;
+      const int l = DUO_LANE;
       if (i < 8) return rec[ES_KQ + (i < 3 ? i : lo + (i - 3))];
       if (i < 16) return rec[ES_KV + (i - 8 < 3 ? i - 8 : lo + (i - 11))];
       if (i < 21) return rec[ES_QSTATE + lo + (i - 16)];
@@ -68,7 +76,7 @@ struct DevDuoB : DevB {
       return sh->cold[g][slot(i)][l];
     }
     LEG_FN void cst(int i, double v, bool m) {
-      const int l = threadIdx.x;
+      const int l = DUO_LANE;
       if (i < 16) {
         if (snap && m) { if (i < 8) rec[ES_KQ + (i < 3 ? i : lo + (i - 3))] = v; else rec[ES_KV + (i - 8 < 3 ? i - 8 : lo + (i - 11))] = v; }
       } else if (i < 21) { if (m) rec[ES_QSTATE + lo + (i - 16)] = v; }
@@ -79,25 +87,25 @@ struct DevDuoB : DevB {
     }
     LEG_FN void st_pair(int s, double px, double pz, double dist, double invw, int depth, bool m) {
       if (m) {
-        const int l = threadIdx.x;
+        const int l = DUO_LANE;
         double* p = s < 2 ? &sh->pr[g][s][0][l] : &sh->pr2[0][l];
         p[0] = px; p[64] = pz; p[128] = dist; p[192] = invw;
         *(s < 2 ? &sh->pdepth[g][s][l] : &sh->pdepth2[l]) = depth;
       }
     }
     LEG_FN void ld_pair(int s, double& px, double& pz, double& dist, double& invw, int& depth) const {
-      const int l = threadIdx.x;
+      const int l = DUO_LANE;
       if (s < 2) { px = sh->pr[g][s][0][l]; pz = sh->pr[g][s][1][l]; dist = sh->pr[g][s][2][l]; invw = sh->pr[g][s][3][l]; depth = sh->pdepth[g][s][l]; }
       else { px = sh->pr2[0][l]; pz = sh->pr2[1][l]; dist = sh->pr2[2][l]; invw = sh->pr2[3][l]; depth = sh->pdepth2[l]; }
     }
     LEG_FN void st_lim(int slot_, double pos, double sgn, double invw, int j, bool m) {
       if (m) {
-        const int l = threadIdx.x;
+        const int l = DUO_LANE;
         sh->lm[slot_][0][l] = pos; sh->lm[slot_][1][l] = sgn; sh->lm[slot_][2][l] = invw; sh->lmj[slot_][l] = j;
       }
     }
     LEG_FN void ld_lim(int s, double& pos, double& sgn, double& invw, int& j) const {
-      const int l = threadIdx.x;
+      const int l = DUO_LANE;
       pos = sh->lm[s][0][l]; sgn = sh->lm[s][1][l]; invw = sh->lm[s][2][l]; j = sh->lmj[s][l];
     }
   };
@@ -111,9 +119,18 @@ static_assert(DDuo::C::C_TIME == 24 && DDuo::C::C_A2 == 28 && DDuo::C::C_TAUB ==
 // doubles (W_N slots x 64 lanes per wavefront; contents only live inside one launch).
 constexpr size_t duo_workspace_doubles_per_wave = (size_t)DDuo::W_N * 64;
 template <int MODE>
-__global__ void __launch_bounds__(64, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace) {
+__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace) {
+#if DUO_WAVES == 1
   __shared__ DuoShared sh;
   const int lane = threadIdx.x;
+  const int wave_id = blockIdx.x;
+#else
+  __shared__ DuoShared shs[DUO_WAVES];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // wave-uniform: LDS addressing stays on a scalar base
+  DuoShared& sh = shs[wv];
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * DUO_WAVES + wv;
+#endif
   EnvCfg cfg;
   cfg.n_sub = p.n_sub; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
   cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
@@ -121,13 +138,13 @@ __global__ void __launch_bounds__(64, 1) env_step_duo_kernel(VecParams p, int* p
   size_t e[2];
 #pragma unroll
   for (int g = 0; g < 2; g++) {
-    const int env = blockIdx.x * 64 + g * 32 + (lane >> 1);
+    const int env = wave_id * 64 + g * 32 + (lane >> 1);
     valid[g] = env < p.n_envs;
     e[g] = valid[g] ? (size_t)env : 0;
   }
   // the group's per-lane pointers, rebuilt where a phase needs them (held for the whole kernel they are 24 registers the allocator spills)
   auto io_of = [&](int g) {
-    const int env = blockIdx.x * 64 + g * 32 + (lane >> 1);
+    const int env = wave_id * 64 + g * 32 + (lane >> 1);
     const size_t eg = env < p.n_envs ? (size_t)env : 0;
     DDuo::Io io;
     io.rec = p.state + eg * ENV_STRIDE;
@@ -145,7 +162,7 @@ __global__ void __launch_bounds__(64, 1) env_step_duo_kernel(VecParams p, int* p
   lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
   DDuo::Out o[2];
   DevDuoB::W ws;   // raw buffer over this wavefront's W_N x 512 bytes (word 3: 32-bit data format, gfx9 encoding)
-  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)blockIdx.x * (DDuo::W_N * 64), 0, DDuo::W_N * 512, 0x00020000);
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * (DDuo::W_N * 64), 0, DDuo::W_N * 512, 0x00020000);
   ws.voff = (unsigned)lane * 8u;
   DDuo::env_step2<MODE>(cfg, lds, ws, io_of, valid, o);
 #pragma unroll

@@ -54,6 +54,9 @@ constexpr double LH = CP_TIMESTEP;
 constexpr double LMINVAL = 1e-15;
 constexpr int CAP = 8;  // constraint rows per leg
 #define LEG_NPAIR_SLOTS 3   // contact-pair descriptor slots per lane
+#ifndef LEG_STAT_SMALL   // instrumented CPU builds only (tests/small_stats.py): how often a wavefront's group takes the eight-row sweep, and why
+#define LEG_STAT_SMALL(small, go, nlim, ncon)
+#endif
 #ifndef LEG_ITERS
 #define LEG_ITERS CP_ITERATIONS   // (timing experiments only: -DLEG_ITERS=n)
 #endif
@@ -476,6 +479,7 @@ template <class B> struct Core {
       go = live & !ovf;
       out.go = go;
       small = !B::any(go & ((nlim > 0) | (ncon > 2)));
+      LEG_STAT_SMALL(small, go, nlim, ncon);
       {
         // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
         D cu[3];

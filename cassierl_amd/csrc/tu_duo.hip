@@ -5,10 +5,11 @@
 namespace cassie {
 namespace launch {
 
-size_t duo_workspace_bytes(int n_envs) { return (size_t)((n_envs + 63) / 64) * leg::duo_workspace_doubles_per_wave * sizeof(double); }
+size_t duo_workspace_bytes(int n_envs) { return (size_t)(((n_envs + 63) / 64 + DUO_WAVES - 1) / DUO_WAVES * DUO_WAVES) * leg::duo_workspace_doubles_per_wave * sizeof(double); }
 
 void step_duo(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace) {
-  dim3 grid((n_envs + 63) / 64), block(64);
+  const int waves = (n_envs + 63) / 64;
+  dim3 grid((waves + DUO_WAVES - 1) / DUO_WAVES), block(64 * DUO_WAVES);
   if (mode == 0) hipLaunchKernelGGL((leg::env_step_duo_kernel<0>), grid, block, 0, s, p, pending, workspace);
   else if (mode == 1) hipLaunchKernelGGL((leg::env_step_duo_kernel<1>), grid, block, 0, s, p, pending, workspace);
   else hipLaunchKernelGGL((leg::env_step_duo_kernel<2>), grid, block, 0, s, p, pending, workspace);

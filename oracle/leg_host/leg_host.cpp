@@ -17,6 +17,12 @@
 #define LEG_FN inline
 #define LEG_NOUNROLL
 #define LEG_FP_CONTRACT_OFF   /* the whole file is compiled with -ffp-contract=off; the step functions write their FMAs out */
+#ifdef LEG_STATS   // tests/small_stats.py: per set-up of a lane group: [0] set-ups, [1] not "small", [2] lanes with a joint limit, [3] lanes with a third pair
+#include <atomic>
+static std::atomic<long long> g_small_stat[4];
+#define LEG_STAT_SMALL(small, go, nlim, ncon) do { g_small_stat[0]++; if (!(small)) g_small_stat[1]++; \
+  for (int l_ = 0; l_ < LEG_HOST_LANES; l_++) { if ((go).v[l_] && (nlim).v[l_] > 0) g_small_stat[2]++; if ((go).v[l_] && (ncon).v[l_] > 2) g_small_stat[3]++; } } while (0)
+#endif
 #include "../../cassierl_amd/csrc/cassie_leg_core.h"
 #include "../../cassierl_amd/csrc/cassie_duo_core.h"
 
@@ -288,6 +294,9 @@ int leg_host_step_duo(double* state, const double* actions, int n, int adim, int
 }
 
 int leg_host_lanes(void) { return NL; }
+#ifdef LEG_STATS
+void leg_host_small_stats(long long* out4) { for (int i = 0; i < 4; i++) { out4[i] = g_small_stat[i]; g_small_stat[i] = 0; } }
+#endif
 
 // arithmetic operations counted since the last call (see the note at g_ops); 0 in the timing build
 double leg_host_ops(void) {
