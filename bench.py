@@ -30,10 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
-def dominant_kernel(n_envs):
-    """The kernel one bench step launches (PD mode, flat floor), by the library's size rule (cassie_cabi.hip: DUO_MIN_ENVS, LEG_MIN_ENVS)."""
-    return ("cassie::leg::env_step_duo_kernel<0>" if n_envs >= 49152 else
-            "cassie::leg::env_step_leg_kernel<0>" if n_envs >= 6144 else "cassie::g16::env_step_g16_kernel<0, false>")
+def dominant_kernel(n_envs, simds=1024):
+    """The kernel one bench step launches (PD mode, flat floor), by the library's rule (cassie_cabi.hip, CassieVecCreate: whole rounds of one
+    wavefront per SIMD -- 64 environments per wavefront at ~1.05 ms a round against 32 at ~0.65 ms; LEG_MIN_ENVS below that)."""
+    rp, rj = -(-(-(-n_envs // 32)) // simds), -(-(-(-n_envs // 64)) // simds)
+    if n_envs > 32768 and 1.05 * rj < 0.65 * rp:
+        return "cassie::leg::env_step_duo_kernel<0>"
+    return "cassie::leg::env_step_leg_kernel<0>" if n_envs >= 6144 else "cassie::g16::env_step_g16_kernel<0, false>"
 
 
 # Schema of the JSON line (ADVICE r4: the meaning of `roofline` and `cpu_baseline` changed between rounds; a reader comparing BENCH_rNN

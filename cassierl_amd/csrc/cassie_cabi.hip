@@ -95,7 +95,7 @@ int fail(CassieVec* h, int code, const char* fmt, ...) {
 int adim_of(int mode) { return mode == CASSIE_CTRL_OSC ? 7 : 6; }
 
 constexpr unsigned SEG_MIN_HANDOVERS = 96;   // hand-overs per launch from which the Env.step runs in segments (launch_physics_tiers)
-constexpr int DUO_MIN_ENVS = 49152;  // 64 environments per wavefront: 1024 wavefronts (one per SIMD) hold 65 536 environments; the pair form's two rounds of 0.7 ms are the alternative
+constexpr int DUO_MIN_ENVS = 32768;  // 64 environments per wavefront: never below one full round of the pair form (CassieVecCreate weighs whole rounds above it)
 constexpr int LEG_MIN_ENVS = 6144;   // measured crossover (r03, bench workload): 4096 envs 0.63 ms (g16 tier) vs 0.75 ms (leg tier), 8192 envs 0.83 vs 0.74 ms
 constexpr int MAXACT = L2::K1_MAXACT;                   // register-resident active constraint columns per row lane
 constexpr int OVF_STRIDE = (cassie::NSLOT - MAXACT) * 64;  // doubles per env in the overflow workspace
@@ -408,7 +408,16 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
   // the joint-sweep form of that tier (64 environments per wavefront) where the batch fills the chip with it: one wavefront per SIMD is
   // 65 536 environments; below DUO_MIN_ENVS the 32-environment wavefronts of the pair form finish earlier (twice as many SIMDs busy)
-  h->duo = h->leg && n_envs >= DUO_MIN_ENVS;
+  {
+    // both forms run one wavefront per SIMD, so a launch takes whole ROUNDS of the chip's SIMDs: per round the pair form's wavefront
+    // (32 environments) lives ~0.65 ms, the joint form's (64 environments) ~1.05 ms (r05, MI355X).  65 536 envs: 2 x 0.65 against 1 x 1.05;
+    // 32 768: one round either way, the pair form's is shorter; 98 304: 3 x 0.65 against 2 x 1.05.
+    int simds = 1024;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+    const int rounds_pair = ((n_envs + 31) / 32 + simds - 1) / simds, rounds_joint = ((n_envs + 63) / 64 + simds - 1) / simds;
+    h->duo = h->leg && n_envs > DUO_MIN_ENVS && 1.05 * rounds_joint < 0.65 * rounds_pair;
+  }
   { const char* e = getenv("CASSIE2D_DUO"); if (e && (e[0] == '0' || e[0] == '1')) h->duo = h->leg && e[0] == '1'; }
   if (h->cfg.flags & CASSIE_DUO_TIER_OFF) h->duo = false;
   if (h->cfg.flags & CASSIE_DUO_TIER_ON) h->duo = h->leg;
