@@ -426,6 +426,19 @@ def extra_workloads(traj, n):
     rows.append(run_env_workload("configs[2]_stand_osc_in_loop", n, "stand", "OSC", 0, traj, 20, 30,
                                  lambda t: R.random_actions(4, ids, t, osc_lo, osc_hi),
                                  "OSC_RBDL QP + mj_step per substep, 10 substeps per Env.step, random accelerations targets in +-2 m/s^2"))
+    try:   # roofline of configs[2]: ISSUED FP64 lane-flops of the controller + physics kernels (PMC; an upper bound of the useful ones --
+        # the controller's source has no op-counting build) and the HBM-side bytes of the 20+ launches of an Env.step, when the counters describe this tree
+        o2 = pmc_for_this_tree().get("osc")
+        r2 = rows[-1]
+        if o2 and o2.get("envs") == n and "env_steps_per_s" in r2:
+            ach = o2["valu_flop_issued_per_env_step"] * r2["env_steps_per_s"] / 1e12
+            r2["roofline"] = dict(bound="fp64_valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_VALU_PEAK_TFLOPS, flops="issued (upper bound of useful)",
+                                  traffic=o2["hbm_bytes_per_env_step_batch"], algorithmic_bytes=o2["algorithmic_bytes_per_env_step_batch"],
+                                  kernel="cassie::g16::env_ctrl_g16_kernel<2,false> + cassie::leg::env_step_duo_kernel<2> per substep (+ hand-over passes)",
+                                  note="two launches per substep, each re-staging the state records (and the physics kernel its hand-over workspace): latency- and "
+                                       "launch-bound, not a throughput ceiling")
+    except Exception:
+        pass
     # (c') the scripted standing controller of squatting.py-style loops: substeps/s (one controller call per substep)
     env = VE.CassieVecEnv(n, kind="stand", control_mode="OSC", n_substeps=1, auto_reset=False, device=0)
     env.use_torch_stream()
@@ -482,6 +495,8 @@ def extra_workloads(traj, n):
         ach = uf * n3 * 30 / dt / 1e12
         row["roofline"] = dict(bound="fp64_valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_VALU_PEAK_TFLOPS,
                                useful_flop_per_env_step=uf, kernel="cassie3d::leg::env_step3d_leg_kernel<32> (+ its hand-over tier)",
+                               issued_flop_per_env_step=(pmc_for_this_tree().get("cassie3d") or {}).get("valu_flop_issued_per_env_step"),
+                               traffic=(pmc_for_this_tree().get("cassie3d") or {}).get("hbm_bytes_per_launch"),
                                note="16 environments per wavefront, one wavefront per SIMD at 16 384 envs: the step time is ONE wavefront's dependent chain "
                                     "(500 Gauss-Seidel sweeps of ~11 us), not throughput; issued FP64 and HBM bytes: profiles/<tag>_pmc.json, section cassie3d")
     except Exception:
@@ -528,6 +543,16 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6):
                 envs=n, envs_total=n * world, ranks=world, iterations=iters, env_steps_per_s=iters * n * world * 8 / dt, ms_per_iteration=dt / iters * 1e3,
                 samples_per_iteration=n * world * 8, kl=st.get("kl"), backtracks=st.get("backtracks"),
                 collectives_ms=per_iter, collective_ms_per_iteration=sum(v["ms_per_iteration"] for v in per_iter.values()))
+
+
+def pmc_for_this_tree():
+    """profiles/pmc_traffic.json (profiles/summarize_pmc.py) if it describes THIS source tree (hash of cassierl_amd/csrc), else {}."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        from cassierl_amd.build import source_hash
+        return pmc if pmc.get("csrc_sha16") == source_hash() else {}
+    except Exception:
+        return {}
 
 
 def roofline_object(n_local, kernel_ms, dominant, pmc):

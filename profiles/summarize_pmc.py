@@ -105,6 +105,11 @@ def main():
                        useful_flop_per_env_step=useful, hbm_bytes_per_launch=int(pd["hbm_bytes_per_launch"]),
                        algorithmic_bytes_per_launch=ALGO_BYTES_PER_ENV_STEP * 65536,
                        valu_flop_per_env_step=pd["fp64_lane_flops_issued_per_env_step"],
+                       # the other configs the bench line attaches a roofline object to (per Env.step of 10 substeps: the OSC kernels are
+                       # profiled per substep, hence x 10)
+                       osc=dict(envs=65536, valu_flop_issued_per_env_step=10.0 * osc["fp64_lane_flops_issued_per_env_step"],
+                                hbm_bytes_per_env_step_batch=int(10.0 * osc["hbm_bytes_per_launch"]), algorithmic_bytes_per_env_step_batch=(ALGO_BYTES_PER_ENV_STEP + 8) * 65536),
+                       cassie3d=dict(envs=16384, valu_flop_issued_per_env_step=c3["fp64_lane_flops_issued_per_env_step"], hbm_bytes_per_launch=int(c3["hbm_bytes_per_launch"])),
                        note="bench workload at 65 536 envs: packed kernel + its hand-over pass per Env.step.  valu_flop_per_env_step = ISSUED FP64 lane-flops "
                             "(64 x (ADD + MUL + TRANS + 2 FMA) wave-instructions) / envs: an upper bound of the useful flops"), f, indent=1)
     for name, w in (("pd", pd), ("osc", osc), ("cassie3d", c3)):
