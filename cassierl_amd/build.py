@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcassie2d.so")
-UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_duo", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo", "tu_trpo_baseline"]
+UNITS = ["cassie_cabi", "tu_base", "tu_g16", "tu_leg", "tu_leg_seg", "tu_duo", "tu_duo_hf", "tu_hf", "tu_ctrl", "tu_ctrl_g16", "tu_3d", "tu_trpo", "tu_trpo_baseline"]
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("CASSIE_HIPCC_FLAGS", "").split()
@@ -23,7 +23,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # not where the back end's combiner finds it profitable in the code around it (hipcc's default, `fast`).  The three units compile the same
 # source into different kernels whose results are compared bit for bit (tests/test_gpu_duo.py, the segment-order tests): with `fast` the
 # back end fused one multiply-add in one kernel and not in the other (r05: state records apart by an ulp in a handful of fields).
-UNIT_FLAGS = {"tu_leg": ["-ffp-contract=on"], "tu_leg_seg": ["-ffp-contract=on"], "tu_duo": ["-ffp-contract=on"]}
+UNIT_FLAGS = {"tu_leg": ["-ffp-contract=on"], "tu_leg_seg": ["-ffp-contract=on"], "tu_duo": ["-ffp-contract=on"], "tu_duo_hf": ["-ffp-contract=on"],
+              "tu_hf": ["-ffp-contract=on"]}   # (holds the height-field form of the two-lanes kernel, which env_step_duo_hf_kernel is compared with bit for bit)
 
 
 def _deps():

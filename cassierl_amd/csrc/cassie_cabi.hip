@@ -261,7 +261,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
 void launch_physics_tiers_hf(CassieVec* h, int mode, const cassie::VecParams& p) {
   cassie::VecParams p2 = p, p3 = p;
   if (h->leg) {
-    L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo_hf(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16_hf(mode, h->n, h->stream, p2, h->pending);

@@ -308,8 +308,10 @@ template <class B> struct Duo : Core<B> {
   // earlier substep: only the LAST setState of a step is ever read -- by this step's observation, by the reset pass, by the next launch's
   // controllers; an environment that leaves this tier is finished by a lower tier, which does its own setState on every substep it
   // carries out).
-  template <int MODE, class IoOf>
-  static LEG_FN void env_step2(const EnvCfg& cfg, typename B::Lds& lds, W ws, IoOf&& io_of, const M (&valid)[2], Out (&o)[2]) {
+  // HF: the height-field instantiation (terrain collision stage in the set-up, contact frames along the local normal; the joint sweep itself does
+  // not know: rows are rows).
+  template <int MODE, bool HF = false, class IoOf>
+  static LEG_FN void env_step2(const EnvCfg& cfg, typename B::Lds& lds, W ws, IoOf&& io_of, const M (&valid)[2], Out (&o)[2], const Terrain* hf = nullptr) {
     const I leg = B::leg();
     const I lo = leg * 5 + 3, ao = leg * 3;
     const M left = leg == 0;
@@ -371,7 +373,7 @@ template <class B> struct Duo : Core<B> {
           B::fence();
           Sub S;
           SubOut so;
-          C::template sub_setup<MODE, false>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S);
+          C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf);
           ovf_ = so.overflow;
           B::fence();
           if (S.small) {
@@ -381,7 +383,7 @@ template <class B> struct Duo : Core<B> {
             C::sub_sweeps(S);
             B::fence();
             nit_ = S.niter;
-            C::template sub_finish<false>(lds, st, !reset_pass, S);
+            C::template sub_finish<HF>(lds, st, !reset_pass, S);
             put_lane(ws, base, st);
           }
           B::fence();
@@ -434,7 +436,7 @@ template <class B> struct Duo : Core<B> {
           });
           S1.kind[6] = I(K_NONE); S1.kind[7] = I(K_NONE);
           B::fence();
-          C::template sub_finish<false>(lds, st, !reset_pass, S1);
+          C::template sub_finish<HF>(lds, st, !reset_pass, S1);
           put_lane(ws, base, st);
           B::fence();
           if (g == 0) nit[0] = nit_; else nit[1] = nit_;

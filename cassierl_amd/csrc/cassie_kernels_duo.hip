@@ -177,6 +177,99 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecPara
   }
 }
 
+
+#ifdef CASSIE_LEG_HF
+// ---------------------------------------------------------------- height-field instantiation (tu_duo_hf.hip)
+// One more per-lane word per contact pair (the x component of the local terrain normal).  LDS stays at four wavefronts per CU: pair 0's normal
+// takes the slot of the sum of squared actions (which this backend keeps in two registers instead), pair 1's and the third pair's get three new
+// slots: 39 168 + 1536 = 40 704 B.
+struct DuoSharedHF : DuoShared {
+  double nrm1[2][64];
+  double nrm2[64];
+};
+static_assert(sizeof(DuoSharedHF) == 40704, "LDS budget of four wavefronts per CU");
+
+struct DevDuoBHF : DevDuoB {
+  struct Lds : DevDuoB::Lds {
+    DuoSharedHF* shf;
+    double a2[2];
+    LEG_FN double cld(int i) const { return i == 28 ? (g == 0 ? a2[0] : a2[1]) : DevDuoB::Lds::cld(i); }
+    LEG_FN void cst(int i, double v, bool m) {
+      if (i == 28) { if (m) { if (g == 0) a2[0] = v; else a2[1] = v; } }
+      else DevDuoB::Lds::cst(i, v, m);
+    }
+    LEG_FN void st_nrm(int slot, double nx, bool m) {
+      if (m) { const int l = DUO_LANE; *(slot == 0 ? &shf->cold[g][1][l] : slot == 1 ? &shf->nrm1[g][l] : &shf->nrm2[l]) = nx; }
+    }
+    LEG_FN double ld_nrm(int s) const { const int l = DUO_LANE; return s == 0 ? shf->cold[g][1][l] : s == 1 ? shf->nrm1[g][l] : shf->nrm2[l]; }
+  };
+  static LEG_FN void hf_sphere(const Terrain& t, double wx, double wy, double wz, double radius, double& dist, double& nx, double& nz) {
+    cassie::terrain_sphere(t, wx, wy, wz, radius, dist, nx, nz);
+  }
+};
+typedef Duo<DevDuoBHF> DDuoHF;
+static_assert(DDuoHF::W_N == DDuo::W_N, "one workspace size for both instantiations");
+
+template <int MODE>
+__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_hf_kernel(VecParams p, int* pending, double* workspace) {
+#if DUO_WAVES == 1
+  __shared__ DuoSharedHF sh;
+  const int lane = threadIdx.x;
+  const int wave_id = blockIdx.x;
+#else
+  __shared__ DuoSharedHF shs[DUO_WAVES];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  DuoSharedHF& sh = shs[wv];
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * DUO_WAVES + wv;
+#endif
+  EnvCfg cfg;
+  cfg.n_sub = p.n_sub; cfg.flags = p.flags; cfg.env_kind = p.env_kind; cfg.auto_reset = p.auto_reset; cfg.adim = p.adim;
+  cfg.want_obs = p.obs != nullptr; cfg.traj_qpos = p.traj_qpos; cfg.traj_tmax = p.traj_tmax; cfg.traj_n = p.traj_n;
+  bool valid[2];
+  size_t e[2];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const int env = wave_id * 64 + g * 32 + (lane >> 1);
+    valid[g] = env < p.n_envs;
+    e[g] = valid[g] ? (size_t)env : 0;
+  }
+  auto io_of = [&](int g) {
+    const int env = wave_id * 64 + g * 32 + (lane >> 1);
+    const size_t eg = env < p.n_envs ? (size_t)env : 0;
+    DDuoHF::Io io;
+    io.rec = p.state + eg * ENV_STRIDE;
+    io.has_act = p.actions != nullptr;
+    io.act = const_cast<double*>(p.actions) + (io.has_act ? eg * p.adim : 0);
+    io.obs = p.obs + (cfg.want_obs ? eg * 26 : 0);
+    io.has_tobs = p.terminal_obs != nullptr;
+    io.tobs = p.terminal_obs + (io.has_tobs ? eg * 26 : 0);
+    io.rew = p.reward + (cfg.want_obs ? eg : 0);
+    io.done = p.done + (cfg.want_obs ? eg : 0);
+    return io;
+  };
+  DevDuoBHF::Lds lds;
+  lds.sh = &sh; lds.shf = &sh; lds.g = 0; lds.rec = p.state; lds.act = p.actions; lds.has_act = false; lds.snap = true;
+  lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
+  lds.a2[0] = 0.0; lds.a2[1] = 0.0;
+  DevDuoBHF::W ws;
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * (DDuoHF::W_N * 64), 0, DDuoHF::W_N * 512, 0x00020000);
+  ws.voff = (unsigned)lane * 8u;
+  DDuoHF::Out o[2];
+  DDuoHF::env_step2<MODE, true>(cfg, lds, ws, io_of, valid, o, &p.hf);
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    if (valid[g] && (lane & 1) == 0) {
+      pending[e[g]] = o[g].pend;
+      if (p.stats) {
+        if (o[g].pend > 0) atomicAdd(p.stats + STAT_CLEANUP_SUBSTEPS, (unsigned long long)o[g].pend);
+        if (o[g].bad) atomicAdd(p.stats + STAT_NONFINITE, 1ull);
+      }
+    }
+  }
+}
+#endif
+
 }  // namespace leg
 }  // namespace cassie
 #endif

@@ -36,6 +36,7 @@ void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 // tu_duo.hip: the same tier with 64 environments per wavefront (two groups set up lane-per-leg, one joint sweep with a lane per
 // environment; cassie_duo_core.h): bit-identical results, same hand-over through `pending`
 void step_duo(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace);
+void step_duo_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace);   // tu_duo_hf.hip: ... on the height field (p.hf)
 size_t duo_workspace_bytes(int n_envs);   // per handle: what group A of a wavefront hands from its set-up to the joint sweep and its finish, and group B's state
 // ... for a SEGMENT of the Env.step's substeps (p.n_sub = its length; `later` = substeps of the segments behind it; gone[env]: the
 // environment left this tier in an earlier segment; see env_step_leg_seg_kernel)

@@ -72,7 +72,7 @@ class LegHostEnv:
         bad = ct.c_int(0)
         if getattr(self, "hf", None) is not None:
             hm, sx, sy = self.hf
-            lib().leg_host_step_hf(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
+            (lib().leg_host_step_duo_hf if self.duo else lib().leg_host_step_hf)(_p(self.state), _p(acts), self.n, acts.shape[1] if acts is not None else 6, MODES[mode], n_sub, self.flags,
                                    0 if self.kind == "walk" else 1, int(self.auto_reset), _p(hm), hm.shape[0], hm.shape[1], ct.c_double(sx), ct.c_double(sy),
                                    _p(obs), _p(rew), done.ctypes.data_as(ct.POINTER(ct.c_ubyte)) if want_obs else None,
                                    self.pending.ctypes.data_as(ct.POINTER(ct.c_int)), ct.byref(bad), 1)

@@ -19,9 +19,11 @@
 #define LEG_FP_CONTRACT_OFF   /* the whole file is compiled with -ffp-contract=off; the step functions write their FMAs out */
 #ifdef LEG_STATS   // tests/small_stats.py: per set-up of a lane group: [0] set-ups, [1] not "small", [2] lanes with a joint limit, [3] lanes with a third pair
 #include <atomic>
-static std::atomic<long long> g_small_stat[4];
-#define LEG_STAT_SMALL(small, go, nlim, ncon) do { g_small_stat[0]++; if (!(small)) g_small_stat[1]++; \
-  for (int l_ = 0; l_ < LEG_HOST_LANES; l_++) { if ((go).v[l_] && (nlim).v[l_] > 0) g_small_stat[2]++; if ((go).v[l_] && (ncon).v[l_] > 2) g_small_stat[3]++; } } while (0)
+static std::atomic<long long> g_small_stat[8];   // [4] set-ups whose worst lane has <= 1 limit and <= 2 pairs, [5] lanes with >= 2 limits, [6] set-ups with any lane over 8 rows
+#define LEG_STAT_SMALL(small, go, nlim, ncon) do { g_small_stat[0]++; if (!(small)) g_small_stat[1]++; bool one_ = true, ovf_ = false; \
+  for (int l_ = 0; l_ < LEG_HOST_LANES; l_++) { if ((go).v[l_] && (nlim).v[l_] > 0) g_small_stat[2]++; if ((go).v[l_] && (ncon).v[l_] > 2) g_small_stat[3]++; \
+    if ((go).v[l_] && (nlim).v[l_] > 1) g_small_stat[5]++; if ((go).v[l_] && ((nlim).v[l_] > 1 || (ncon).v[l_] > 2)) one_ = false; } \
+  if (one_) g_small_stat[4]++; } while (0)
 #endif
 #include "../../cassierl_amd/csrc/cassie_leg_core.h"
 #include "../../cassierl_amd/csrc/cassie_duo_core.h"
@@ -142,6 +144,18 @@ struct HostDuoB : HostB {
   };
 };
 typedef cassie::leg::Duo<HostDuoB> HDuo;
+// ... on a height field (the counterpart of DevDuoBHF): one more per-lane word per contact pair
+struct HostDuoBHF : HostDuoB {
+  struct Lds : HostDuoB::Lds {
+    double nrm[2][2][NL], nrm2[NL];
+    void st_nrm(VI slot_, VD nx, VM m) { LANES if (m.v[l]) { const int s = (int)slot_.v[l]; (s < 2 ? nrm[g][s] : nrm2)[l] = nx.v[l]; } }
+    VD ld_nrm(int s) const { VD r; LANES r.v[l] = (s < 2 ? nrm[g][s] : nrm2)[l]; return r; }
+  };
+  static void hf_sphere(const cassie::Terrain& t, VD wx, VD wy, VD wz, VD radius, VD& dist, VD& nx, VD& nz) {
+    LANES cassie::terrain_sphere(t, wx.v[l], wy.v[l], wz.v[l], radius.v[l], dist.v[l], nx.v[l], nz.v[l]);
+  }
+};
+typedef cassie::leg::Duo<HostDuoBHF> HDuoHF;
 
 // lanes of the group that starts at environment e0: lane l works on environment e0 + l / 2 (a lane past the end reads the group's
 // first environment and writes nothing)
@@ -201,8 +215,9 @@ int run(double* state, const double* actions, int n, int adim, int mode, int n_s
 
 
 // The 64-environments-per-wavefront form: one call group = NL lanes = NL / 2 environments of group A and the next NL / 2 of group B.
+template <class DuoT, class BT, bool HF>
 int run_duo(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
-            const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
+            const double* traj_qpos, double traj_tmax, int traj_n, const cassie::Terrain* hf, double* obs, double* reward, uint8_t* done, double* terminal_obs,
             int* pending, int* nonfinite, int threads) {
   cassie::leg::EnvCfg cfg;
   cfg.n_sub = n_sub; cfg.flags = flags; cfg.env_kind = env_kind; cfg.auto_reset = auto_reset; cfg.adim = adim;
@@ -217,10 +232,11 @@ int run_duo(double* state, const double* actions, int n, int adim, int mode, int
   for (int c = 0; c < calls; c++) {
     double dummy[32] = {0};
     uint8_t dummy8 = 0;
-    HostDuoB::Lds lds;
+    typename BT::Lds lds;
     std::memset(&lds, 0, sizeof lds);
     lds.snap = true;
-    HDuo::Io io[2];
+    if constexpr (HF) { for (auto& a : lds.nrm) for (auto& b : a) LANES b[l] = std::nan(""); LANES lds.nrm2[l] = std::nan(""); }   // an unused slot holds anything
+    typename DuoT::Io io[2];
     VM valid[2];
     for (int g = 0; g < 2; g++) {
       const int e0 = c * 2 * EPG + g * EPG;
@@ -236,15 +252,15 @@ int run_duo(double* state, const double* actions, int n, int adim, int mode, int
       LANES valid[g].v[l] = e0 + (l >> 1) < n ? -1 : 0;
     }
     lds.select(0, io[0]);
-    HDuo::Out o[2];
-    double wsmem[HDuo::W_N][NL];
-    for (int k = 0; k < HDuo::W_N; k++) LANES wsmem[k][l] = std::nan("");   // whatever a launch finds there
-    HostDuoB::W ws; ws.p = wsmem;
-    auto io_of = [&](int g) -> const HDuo::Io& { return io[g]; };
-    if (mode == 0) HDuo::env_step2<0>(cfg, lds, ws, io_of, valid, o);
-    else if (mode == 1) HDuo::env_step2<1>(cfg, lds, ws, io_of, valid, o);
+    typename DuoT::Out o[2];
+    double wsmem[DuoT::W_N][NL];
+    for (int k = 0; k < DuoT::W_N; k++) LANES wsmem[k][l] = std::nan("");   // whatever a launch finds there
+    typename BT::W ws; ws.p = wsmem;
+    auto io_of = [&](int g) -> const typename DuoT::Io& { return io[g]; };
+    if (mode == 0) DuoT::template env_step2<0, HF>(cfg, lds, ws, io_of, valid, o, hf);
+    else if (mode == 1) DuoT::template env_step2<1, HF>(cfg, lds, ws, io_of, valid, o, hf);
 #ifndef LEG_HOST_FAST
-    else HDuo::env_step2<2>(cfg, lds, ws, io_of, valid, o);
+    else DuoT::template env_step2<2, HF>(cfg, lds, ws, io_of, valid, o, hf);
 #endif
     for (int g = 0; g < 2; g++)
       for (int k = 0; k < EPG; k++) {
@@ -289,13 +305,24 @@ int leg_host_step_hf(double* state, const double* actions, int n, int adim, int 
 int leg_host_step_duo(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
                       const double* traj_qpos, double traj_tmax, int traj_n, double* obs, double* reward, uint8_t* done, double* terminal_obs,
                       int* pending, int* nonfinite, int threads) {
-  return run_duo(state, actions, n, adim, mode, n_sub, flags, env_kind, auto_reset, traj_qpos, traj_tmax, traj_n, obs, reward, done, terminal_obs,
-                 pending, nonfinite, threads);
+  return run_duo<HDuo, HostDuoB, false>(state, actions, n, adim, mode, n_sub, flags, env_kind, auto_reset, traj_qpos, traj_tmax, traj_n, nullptr, obs, reward, done,
+                                        terminal_obs, pending, nonfinite, threads);
 }
+#ifndef LEG_HOST_FAST
+int leg_host_step_duo_hf(double* state, const double* actions, int n, int adim, int mode, int n_sub, int flags, int env_kind, int auto_reset,
+                         const double* heights, int nrow, int ncol, double sx, double sy, double* obs, double* reward, uint8_t* done, int* pending,
+                         int* nonfinite, int threads) {
+  cassie::Terrain hf; hf.h = heights; hf.nrow = nrow; hf.ncol = ncol; hf.sx = sx; hf.sy = sy;
+  hf.hmax = heights[0];
+  for (size_t i = 1; i < (size_t)nrow * ncol; i++) hf.hmax = heights[i] > hf.hmax ? heights[i] : hf.hmax;
+  return run_duo<HDuoHF, HostDuoBHF, true>(state, actions, n, adim, mode, n_sub, flags, env_kind, auto_reset, nullptr, 0.0, 0, &hf, obs, reward, done, nullptr,
+                                           pending, nonfinite, threads);
+}
+#endif
 
 int leg_host_lanes(void) { return NL; }
 #ifdef LEG_STATS
-void leg_host_small_stats(long long* out4) { for (int i = 0; i < 4; i++) { out4[i] = g_small_stat[i]; g_small_stat[i] = 0; } }
+void leg_host_small_stats(long long* out8) { for (int i = 0; i < 8; i++) { out8[i] = g_small_stat[i]; g_small_stat[i] = 0; } }
 #endif
 
 // arithmetic operations counted since the last call (see the note at g_ops); 0 in the timing build

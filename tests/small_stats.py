@@ -27,7 +27,7 @@ for kind, seed in ((0, 1), (1, 2)):
     state = np.tile(state_vec(q, v, oe.oracle.warmstart(), kq=ctor.state()[0], kv=ctor.state()[1], qstate=q), (n, 1)).copy()
     obs, rew, done, pend, bad = np.zeros((n, 26)), np.zeros(n), np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32), ct.c_int(0)
     ids = torch.arange(n)
-    st = (ct.c_longlong * 4)()
+    st = (ct.c_longlong * 8)()
     for blk in range(3):
         for t in range(10):
             a = np.ascontiguousarray(R.random_actions(seed, ids, blk * 10 + t, low, high).numpy())

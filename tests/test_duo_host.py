@@ -98,3 +98,34 @@ def test_record_command_mode_is_bit_identical(oracle_mod):
         pair.set_full_state_host(s); duo.set_full_state_host(s)
         pair.substep_host("Record", None, 1); duo.substep_host("Record", None, 1)
         _same(pair.get_full_state_host(), duo.get_full_state_host(), (t, "state"))
+
+
+@pytest.mark.parametrize("mode", ["Torque", "PD"])
+def test_height_field_is_bit_identical(oracle_mod, mode):
+    """The height-field instantiation (terrain collision stage, contact frames along the local normal: cassie_leg_core.h with HF = true)
+    through both forms: robots on the flat part of a ramp, across its kink and on the 10 % slope, stand env with resets."""
+    from cassierl_amd import terrain as T
+    hm = T.ramp(nrow=64, ncol=2001, size_x=10.0, slope=0.1, x0=0.5)
+    rng = np.random.default_rng(21)
+    n = 5
+    pair, duo = _pair_and_duo(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True)
+    o = oracle_mod.Oracle()
+    q, v = o.state()
+    s0 = np.tile(state_vec(q, v, np.zeros(13), qstate=q), (n, 1))
+    s0[:, 0] += np.array([-1.0, 0.45, 1.0, 3.3, 2.0]); s0[:, 1] += np.array([0.0, 0.002, 0.05, 0.28, 0.15])
+    for e in (pair, duo):
+        e.set_heightfield(hm, 10.0, 10.0)
+        e.set_full_state_host(s0)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 6)) * TQ * 0.4 if mode == "Torque" else rng.uniform(PD_LO, PD_HI, (n, 6))
+        rp, rd = pair.step_host(a), duo.step_host(a)
+        _same(pair.pending, duo.pending, (t, "pending"))
+        stay = pair.pending == 0
+        for x, y, w in zip(rp, rd, ("obs", "reward", "done")):
+            _same(x[stay], y[stay], (t, w))
+        sp, sd = pair.get_full_state_host(), duo.get_full_state_host()
+        _same(sp[stay], sd[stay], (t, "state"))
+        assert pair.nonfinite == duo.nonfinite == 0
+        if (~stay).any():
+            sp[~stay] = s0[~stay]
+            pair.set_full_state_host(sp); duo.set_full_state_host(sp)

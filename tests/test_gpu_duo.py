@@ -105,3 +105,37 @@ def test_osc_controller_in_the_loop_is_bit_identical():
     _close(outs[0][0], outs[1][0], "obs"); _close(outs[0][1], outs[1][1], "reward")
     _same(outs[0][2], outs[1][2], "state records")
     pair.close(); duo.close()
+
+
+@pytest.mark.parametrize("mode", ["PD", "Torque"])
+def test_height_field_rollout_is_bit_identical(mode):
+    """N4: the same kernels on terrain (env_step_duo_hf_kernel against env_step_leg_hf_kernel): a 3 cm rolling relief, stand env with resets,
+    robots spread along x so that they meet different facets."""
+    import torch
+    from cassierl_amd import rollout as R
+    n = 8192 + 77
+    xs = np.linspace(-10.0, 10.0, 2001)
+    relief = np.tile(0.015 * (1.0 - np.cos(2.0 * np.pi * xs / 1.5)), (64, 1))
+    pair, duo = _envs(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True)
+    ids = torch.arange(n, device="cuda:0")
+    lo, hi = (-TQ * 0.5, TQ * 0.5) if mode == "Torque" else (PD_LO, PD_HI)
+    outs = []
+    for env in (pair, duo):
+        env.set_heightfield(relief, 10.0, 10.0)
+        bufs = env.alloc()
+        env.reset(bufs)
+        s = env.get_full_state_host()
+        s[:, 0] += np.linspace(-6.0, 6.0, n)                      # along the relief
+        s[:, 1] += 0.03
+        env.set_full_state_host(s)
+        rows = []
+        for t in range(30):
+            o, r, d = env.step(R.random_actions(6, ids, t, lo, hi), bufs)
+            if t % 5 == 4:
+                rows.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+        outs.append((rows, env.get_full_state_host(), env.counters()))
+    for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        _close(a[0], b[0], (t, "obs")); _close(a[1], b[1], (t, "reward")); _same(a[2], b[2], (t, "done"))
+    _same(outs[0][1], outs[1][1], "state records")
+    assert outs[0][2]["nonfinite_resets"] == outs[1][2]["nonfinite_resets"] == 0
+    pair.close(); duo.close()
