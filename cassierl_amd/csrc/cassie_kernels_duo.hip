@@ -20,6 +20,9 @@ namespace leg {
 #ifndef DUO_WAVES
 #define DUO_WAVES 2   // independent wavefronts per workgroup (no barrier, no shared data).  A/B r05, 65 536 envs: 1 -> 1.146 ms, 2 -> 1.125, 4 -> 1.129
 #endif
+#ifndef DUO_STAGGER
+#define DUO_STAGGER 0
+#endif
 #if DUO_WAVES == 1
 #define DUO_LANE ((int)threadIdx.x)
 #else
@@ -58,7 +61,18 @@ struct DevDuoB : DevB {
     const double* act;
     bool has_act, snap;
     int lo, ao;
+#ifdef CASSIE_PHASE_TIMING   // profiling builds (tests/phase_profile.py duo): shader cycles per phase of this wavefront; the time up to mark(k) goes to bucket k
+    unsigned long long t_last, acc[16];
+    LEG_FN void mark(int k) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long n = __builtin_readcyclecounter();
+      acc[k] += n - t_last; t_last = n;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     LEG_FN void mark(int) {}
+#endif
     template <class IoT> LEG_FN void select(int group, const IoT& io) { g = group; rec = io.rec; act = io.act; has_act = io.has_act; }
     LEG_FN void snapshot(bool on) { snap = on; }
     // slot of the group's cold block, or -1: not in LDS
@@ -160,11 +174,32 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecPara
   DevDuoB::Lds lds;
   lds.sh = &sh; lds.g = 0; lds.rec = p.state; lds.act = p.actions; lds.has_act = false; lds.snap = true;
   lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
+#if DUO_STAGGER > 0
+  // Stagger: every wavefront runs the same phases for the same time, so all 128 wavefronts of an XCD hit its L2 with their hand-over bursts at
+  // once (phase clocks, r05: 16 % of a wavefront's time in the hand-over, at ~60 cycles per 512-byte access = the L2's bandwidth shared by 128).
+  // Eight start classes DUO_STAGGER x 3.4 us apart keep the bursts of most wavefronts apart for the whole launch.
+  {
+#if DUO_WAVES == 1
+    const int cls = (blockIdx.x >> 3) & 7;
+#else
+    const int cls = (((blockIdx.x >> 3) & 3) * 2 + (wv & 1)) & 7;
+#endif
+    for (int i = 0; i < cls * DUO_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   DDuo::Out o[2];
   DevDuoB::W ws;   // raw buffer over this wavefront's W_N x 512 bytes (word 3: 32-bit data format, gfx9 encoding)
   ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * (DDuo::W_N * 64), 0, DDuo::W_N * 512, 0x00020000);
   ws.voff = (unsigned)lane * 8u;
+#ifdef CASSIE_PHASE_TIMING
+  for (int i = 0; i < 16; i++) lds.acc[i] = 0;
+  lds.t_last = __builtin_readcyclecounter();
+#endif
   DDuo::env_step2<MODE>(cfg, lds, ws, io_of, valid, o);
+#ifdef CASSIE_PHASE_TIMING
+  lds.mark(0);
+  if (lane == 0 && p.phase) for (int i = 0; i < 16; i++) atomicAdd(p.phase + i, lds.acc[i]);
+#endif
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     if (valid[g] && (lane & 1) == 0) {
