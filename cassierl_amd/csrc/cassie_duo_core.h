@@ -369,16 +369,20 @@ template <class B> struct Duo : Core<B> {
           lds.select(g, io);
           const int base = g * W_GROUP;
           Lane st;
+          lds.mark(0);    // (profiling builds: the time up to a mark goes to its bucket; 0 = glue, bookkeeping, outputs)
           get_lane(ws, base, st);
           B::fence();
+          lds.mark(15);   // 15 = state in, before the set-up (sub_setup's own marks: 1 kinematics .. 5 rows)
           Sub S;
           SubOut so;
           C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf);
           ovf_ = so.overflow;
           B::fence();
+          lds.mark(6);    // 6 = warm start
           if (S.small) {
             join_ = true;
             put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
+            lds.mark(10);   // 10 = rows / factorisation out
           } else {
             C::sub_sweeps(S);
             B::fence();
@@ -393,14 +397,17 @@ template <class B> struct Duo : Core<B> {
       // ---- phase 2: one joint sweep for the groups on their feet; the forces go back into the rows' force slots
       if (join[0] || join[1]) {
         Sub S[2];
+        lds.mark(0);
         lfor<0, 2>([&](auto gg) {
           constexpr int G = decltype(gg)::value;
           if (join[G]) { get_rows(ws, G * W_GROUP, S[G]); get_misc(ws, G * W_GROUP, S[G].go, S[G].ncon); }
           else idle_rows(S[G]);
         });
         B::fence();
+        lds.mark(11);   // 11 = rows of both groups in
         joint_solve(S, join);
         B::fence();
+        lds.mark(7);    // 7 = transpose + joint sweeps + forces back
         lfor<0, 2>([&](auto gg) {
           constexpr int G = decltype(gg)::value;
           if (join[G]) {
@@ -409,6 +416,7 @@ template <class B> struct Duo : Core<B> {
           }
         });
         B::fence();
+        lds.mark(12);   // 12 = forces out
         // ---- phase 3, per group: finish
         LEG_NOUNROLL
         for (int g = 0; g < 2; g++) {
@@ -436,9 +444,11 @@ template <class B> struct Duo : Core<B> {
           });
           S1.kind[6] = I(K_NONE); S1.kind[7] = I(K_NONE);
           B::fence();
+          lds.mark(13);   // 13 = state / factorisation / forces in, before the finish (sub_finish's own marks: 8 generalised force, 9 M^-1, damping, integration)
           C::template sub_finish<HF>(lds, st, !reset_pass, S1);
           put_lane(ws, base, st);
           B::fence();
+          lds.mark(14);   // 14 = state out
           if (g == 0) nit[0] = nit_; else nit[1] = nit_;
         }
       }
