@@ -75,3 +75,20 @@ def test_pd_targets_match_step_traj_export_csv(traj):
     for t, row in zip(traj["pd_t"], traj["pd_rows"]):
         ang, vel = pd_targets(tr, t)
         np.testing.assert_allclose(np.concatenate([ang, vel]), row, rtol=0, atol=1e-14)
+
+
+def test_bench_tier_rule_and_cpu_limit_helpers():
+    """bench.py's host-side helpers: the first-tier rule it mirrors from the library (whole rounds of one wavefront per SIMD), the thread
+    ladder of the CPU-baseline leg and the cgroup probe (no GPU, no oracle)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert "g16" in b.dominant_kernel(4096) and "env_step_leg_kernel" in b.dominant_kernel(8192) and "env_step_leg_kernel" in b.dominant_kernel(32768)
+    assert "env_step_duo_kernel" in b.dominant_kernel(40000) and "env_step_duo_kernel" in b.dominant_kernel(65536)
+    assert "env_step_leg_kernel" in b.dominant_kernel(98304) and "env_step_duo_kernel" in b.dominant_kernel(131072) and "env_step_duo_kernel" in b.dominant_kernel(524288)
+    assert b.thread_ladder(256) == [256, 128, 64, 32, 16, 8, 4, 2, 1] and b.thread_ladder(1) == [1] and b.thread_ladder(6) == [6, 3, 1]
+    lim = b.cpu_limits()
+    assert set(lim) == {"cpu_count", "affinity", "cpu_quota", "cpu_quota_source"} and (lim["cpu_quota"] is None or lim["cpu_quota"] > 0)
+    assert b.preroll_count(65536) == 300 and b.preroll_count(4096) == 1000
