@@ -13,11 +13,17 @@
 //
 //   per substep:   set-up(A)  set-up(B)  | transpose (DPP, ~130 doubles per lane) | joint sweeps (<= 50) | forces back | finish(A) finish(B)
 //
+// The phases are INDEPENDENT: everything a group carries from its set-up to the joint sweep and on to its finish (state, rows, factorisation,
+// forces) goes through a per-wavefront workspace in global memory, stored at the end of a phase and loaded in one batch at the head of the next
+// (the set-up needs the whole register file; see "hand-over" below and DESIGN.md section 5 K1d for the builds that tried otherwise).  Set-up and
+// finish exist once, in a loop over the two groups.
+//
 // The arithmetic of an environment is the arithmetic of cassie_leg_core.h operation for operation: the set-up and the finish ARE its
 // functions (`sub_setup`, `sub_finish`), the joint sweep executes the owner lane's sequence of the pair sweep (same step functions
 // written for one lane, same order, same fused multiply-adds), and the cost accumulators of the two legs are kept apart and added in
 // the order the pair sweep adds them -- so the state trajectories are BIT-IDENTICAL to the two-lanes-per-environment kernel
-// (tests/test_gpu_duo.py; on the CPU: tests/test_leg_host.py through oracle/leg_host).
+// (tests/test_gpu_duo.py; on the CPU: tests/test_duo_host.py through oracle/leg_host).  The translation units that instantiate the two cores are
+// compiled with -ffp-contract=on for that (cassierl_amd/build.py: UNIT_FLAGS).
 //
 // Capacity of the joint sweep: six rows per leg (2 connect + 2 contact pairs: robots on their feet, the bench's and TRPO's regime).
 // A group in which some environment has a joint limit active or a third contact pair on a leg runs the pair sweep of
