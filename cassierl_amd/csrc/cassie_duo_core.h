@@ -227,9 +227,10 @@ template <class B> struct Duo : Core<B> {
     W_FC = W_ROWS + W_NROWS,                            // 36: block factorisation
     W_ANCH = W_FC + 36,                                 // 4: connect anchors
     W_MISC = W_ANCH + 4,                                // go, ncon, sweeps done
-    W_GROUP = W_MISC + 3,                               // slots per group
+    W_GROUP = W_MISC + 4,                               // slots per group (even: every block starts on an even slot, see put_block)
     W_N = 2 * W_GROUP
   };
+  static_assert(W_ROWS % 2 == 0 && W_FC % 2 == 0 && W_ANCH == W_FC + 36 && W_MISC % 2 == 0 && W_GROUP % 2 == 0, "blocks start on even slots; the anchors follow the factorisation");
   typedef typename B::W W;
   template <class F> static LEG_FN void rows_each(Sub& s, int base, F&& f) {
     int k = base + W_ROWS;
@@ -255,15 +256,29 @@ template <class B> struct Duo : Core<B> {
     lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; f(k++, st.qb[Bc]); f(k++, st.vb[Bc]); f(k++, st.wb[Bc]); });
     lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; f(k++, st.ql[Dd]); f(k++, st.vl[Dd]); f(k++, st.wl[Dd]); });
   }
-  static LEG_FN void put_rows(W ws, int base, Sub& s) { rows_each(s, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
-  static LEG_FN void get_rows(W ws, int base, Sub& s) { rows_each(s, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
-  static LEG_FN void put_keep(W ws, int base, Sub& s) { keep_each(s, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
-  static LEG_FN void get_keep(W ws, int base, Sub& s) { keep_each(s, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
-  static LEG_FN void put_lane(W ws, int base, Lane& st) { lane_each(st, base, [&](int k, D& v) { B::wst(ws, k, v); }); }
-  static LEG_FN void get_lane(W ws, int base, Lane& st) { lane_each(st, base, [&](int k, D& v) { v = B::wld(ws, k); }); }
+  // A block of N consecutive slots (first slot even) moves as N / 2 sixteen-byte accesses per lane (B::wld2 / wst2: the slots 2p, 2p + 1 of
+  // a lane are adjacent in the workspace) + one eight-byte access if N is odd.  Why pairs: a wavefront has at most 63 memory instructions
+  // in flight (vmcnt), the workspace answers from the Infinity Cache in ~1 us, and at 512 bytes per instruction that is ~10 bytes per
+  // cycle and wavefront -- what the eight-byte form of this hand-over measured (r05 phase clocks: ~60 cycles per access).
+  template <int N> static LEG_FN void put_block(W ws, int first, D (&t)[N]) {
+    lfor<0, N / 2>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::wst2(ws, first + 2 * Ii, t[2 * Ii], t[2 * Ii + 1]); });
+    if constexpr (N & 1) B::wst(ws, first + N - 1, t[N - 1]);
+  }
+  template <int N> static LEG_FN void get_block(W ws, int first, D (&t)[N]) {
+    lfor<0, N / 2>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::wld2(ws, first + 2 * Ii, t[2 * Ii], t[2 * Ii + 1]); });
+    if constexpr (N & 1) t[N - 1] = B::wld(ws, first + N - 1);
+  }
+  static LEG_FN void put_rows(W ws, int base, Sub& s) { D t[W_NROWS]; rows_each(s, 0, [&](int k, D& v) { t[k - W_ROWS] = v; }); put_block(ws, base + W_ROWS, t); }
+  static LEG_FN void get_rows(W ws, int base, Sub& s) { D t[W_NROWS]; get_block(ws, base + W_ROWS, t); rows_each(s, 0, [&](int k, D& v) { v = t[k - W_ROWS]; }); }
+  static LEG_FN void put_keep(W ws, int base, Sub& s) { D t[40]; keep_each(s, 0, [&](int k, D& v) { t[k - W_FC] = v; }); put_block(ws, base + W_FC, t); }
+  static LEG_FN void get_keep(W ws, int base, Sub& s) { D t[40]; get_block(ws, base + W_FC, t); keep_each(s, 0, [&](int k, D& v) { v = t[k - W_FC]; }); }
+  static LEG_FN void put_lane(W ws, int base, Lane& st) { D t[24]; lane_each(st, 0, [&](int k, D& v) { t[k - W_ST] = v; }); put_block(ws, base + W_ST, t); }
+  static LEG_FN void get_lane(W ws, int base, Lane& st) { D t[24]; get_block(ws, base + W_ST, t); lane_each(st, 0, [&](int k, D& v) { v = t[k - W_ST]; }); }
+  static LEG_FN void put_forces(W ws, int base, Sub& s) { D t[NR]; lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; t[Ii] = s.f[Ii]; }); put_block(ws, base + W_ROWS, t); }
+  static LEG_FN void get_forces(W ws, int base, Sub& s) { D t[NR]; get_block(ws, base + W_ROWS, t); lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; s.f[Ii] = t[Ii]; }); }
   // masks and counts travel as doubles
-  static LEG_FN void put_misc(W ws, int base, M go, I ncon) { B::wst(ws, base + W_MISC, B::sel(go, D(1.0), D(0.0))); B::wst(ws, base + W_MISC + 1, B::toD(ncon)); }
-  static LEG_FN void get_misc(W ws, int base, M& go, I& ncon) { go = B::wld(ws, base + W_MISC) > D(0.5); ncon = B::toint(B::wld(ws, base + W_MISC + 1)); }
+  static LEG_FN void put_misc(W ws, int base, M go, I ncon) { B::wst2(ws, base + W_MISC, B::sel(go, D(1.0), D(0.0)), B::toD(ncon)); }
+  static LEG_FN void get_misc(W ws, int base, M& go, I& ncon) { D a, b; B::wld2(ws, base + W_MISC, a, b); go = a > D(0.5); ncon = B::toint(b); }
 
   // rows of a group that does not run in this pass (no environment of it is live): defined values for the lanes the joint sweep masks off
   static LEG_FN void idle_rows(Sub& s) {
@@ -417,7 +432,7 @@ template <class B> struct Duo : Core<B> {
         lfor<0, 2>([&](auto gg) {
           constexpr int G = decltype(gg)::value;
           if (join[G]) {
-            lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; B::wst(ws, G * W_GROUP + W_ROWS + Ii, S[G].f[Ii]); });
+            put_forces(ws, G * W_GROUP, S[G]);
             B::wst(ws, G * W_GROUP + W_MISC + 2, B::toD(S[G].niter));
           }
         });
@@ -434,7 +449,7 @@ template <class B> struct Duo : Core<B> {
           Lane st;
           get_lane(ws, base, st);
           get_keep(ws, base, S1);
-          lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = B::wld(ws, base + W_ROWS + Ii); });
+          get_forces(ws, base, S1);
           lfor<NR, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = 0.0; });   // slots 6, 7 are empty in a group on its feet
           get_misc(ws, base, S1.go, S1.ncon);
           const I nit_ = B::toint(B::wld(ws, base + W_MISC + 2));

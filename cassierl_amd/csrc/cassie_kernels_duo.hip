@@ -23,11 +23,21 @@ namespace leg {
 #ifndef DUO_STAGGER
 #define DUO_STAGGER 0
 #endif
+#ifndef DUO_WS_PAD
+#define DUO_WS_PAD 0     // slots of padding between the workspaces of two wavefronts (A/B: an odd number of 512-byte slots per wavefront)
+#endif
+#ifndef DUO_WS_LD_AUX
+#define DUO_WS_LD_AUX 0  // cache-policy bits of the workspace loads / stores (A/B: 2 = nt)
+#endif
+#ifndef DUO_WS_ST_AUX
+#define DUO_WS_ST_AUX 0
+#endif
 #if DUO_WAVES == 1
 #define DUO_LANE ((int)threadIdx.x)
 #else
 #define DUO_LANE ((int)threadIdx.x & 63)
 #endif
+__device__ const double duo_zero_action[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // the action row of a step without actions
 struct DuoShared {
   double cold[2][20][64];    // per group: clock, a2, tau_b 3, tau_l 5, link origins x 5, z 5 (the pelvis origin is the constant 0)
   double pr[2][2][4][64];    // per group: contact pairs 0, 1
@@ -46,13 +56,24 @@ struct DevDuoB : DevB {
   // pointer per slot beyond the 4 KB immediate range, ~150 of them, and spills them: first build of this path).
   struct W { __amdgpu_buffer_rsrc_t r; unsigned voff; };
   typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  // slots 2p and 2p + 1 of a lane are adjacent: [p][lane][2] -- a pair of slots is ONE sixteen-byte access per lane (1 KB per wavefront)
+  static LEG_FN constexpr int wofs(int slot) { return (slot >> 1) * 1024 + (slot & 1) * 8; }
   static LEG_FN double wld(W ws, int slot) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ws.r, ws.voff, slot * 512, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ws.r, ws.voff, wofs(slot), DUO_WS_LD_AUX);
     return __hiloint2double((int)v.y, (int)v.x);
   }
   static LEG_FN void wst(W ws, int slot, double v) {
     u32x2 w; w.x = (unsigned)__double2loint(v); w.y = (unsigned)__double2hiint(v);
-    __builtin_amdgcn_raw_buffer_store_b64(w, ws.r, ws.voff, slot * 512, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, ws.r, ws.voff, wofs(slot), DUO_WS_ST_AUX);
+  }
+  static LEG_FN void wld2(W ws, int slot, double& a, double& b) {   // slot even
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ws.r, ws.voff, wofs(slot), DUO_WS_LD_AUX);
+    a = __hiloint2double((int)v.y, (int)v.x); b = __hiloint2double((int)v.w, (int)v.z);
+  }
+  static LEG_FN void wst2(W ws, int slot, double a, double b) {
+    u32x4 w; w.x = (unsigned)__double2loint(a); w.y = (unsigned)__double2hiint(a); w.z = (unsigned)__double2loint(b); w.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(w, ws.r, ws.voff, wofs(slot), DUO_WS_ST_AUX);
   }
   struct Lds {
     DuoShared* sh;
@@ -85,7 +106,7 @@ struct DevDuoB : DevB {
       if (i < 16) return rec[ES_KV + (i - 8 < 3 ? i - 8 : lo + (i - 11))];
       if (i < 21) return rec[ES_QSTATE + lo + (i - 16)];
       if (i < 24) return rec[ES_CTRL + ao + (i - 21)];
-      if (i >= 25 && i < 28) return has_act ? act[ao + (i - 25)] : 0.0;
+      if (i >= 25 && i < 28) return (has_act ? act : duo_zero_action)[ao + (i - 25)];   // (one unconditional load: three of them go out in one batch)
       if (i == 37 || i == 43) return 0.0;   // origin of the pelvis link relative to the pelvis origin
       return sh->cold[g][slot(i)][l];
     }
@@ -131,7 +152,7 @@ static_assert(DDuo::C::C_TIME == 24 && DDuo::C::C_A2 == 28 && DDuo::C::C_TAUB ==
 
 // MODE: 0 PD, 1 torque, 2 motor commands from the state record.  pending[env] as env_step_leg_kernel.  workspace: duo_workspace_doubles(n)
 // doubles (W_N slots x 64 lanes per wavefront; contents only live inside one launch).
-constexpr size_t duo_workspace_doubles_per_wave = (size_t)DDuo::W_N * 64;
+constexpr size_t duo_workspace_doubles_per_wave = (size_t)(DDuo::W_N + DUO_WS_PAD) * 64;
 template <int MODE>
 __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace) {
 #if DUO_WAVES == 1
@@ -189,8 +210,8 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecPara
 #endif
   DDuo::Out o[2];
   DevDuoB::W ws;   // raw buffer over this wavefront's W_N x 512 bytes (word 3: 32-bit data format, gfx9 encoding)
-  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * (DDuo::W_N * 64), 0, DDuo::W_N * 512, 0x00020000);
-  ws.voff = (unsigned)lane * 8u;
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * duo_workspace_doubles_per_wave, 0, DDuo::W_N * 512, 0x00020000);
+  ws.voff = (unsigned)lane * 16u;
 #ifdef CASSIE_PHASE_TIMING
   for (int i = 0; i < 16; i++) lds.acc[i] = 0;
   lds.t_last = __builtin_readcyclecounter();
@@ -288,8 +309,8 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_hf_kernel(VecP
   lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
   lds.a2[0] = 0.0; lds.a2[1] = 0.0;
   DevDuoBHF::W ws;
-  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * (DDuoHF::W_N * 64), 0, DDuoHF::W_N * 512, 0x00020000);
-  ws.voff = (unsigned)lane * 8u;
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * duo_workspace_doubles_per_wave, 0, DDuoHF::W_N * 512, 0x00020000);
+  ws.voff = (unsigned)lane * 16u;
   DDuoHF::Out o[2];
   DDuoHF::env_step2<MODE, true>(cfg, lds, ws, io_of, valid, o, &p.hf);
 #pragma unroll

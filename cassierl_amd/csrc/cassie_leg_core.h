@@ -419,56 +419,86 @@ template <class B> struct Core {
       D qsb[3], qsl[5];
       Mass mm;
       lds.mark(0);
+      // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3).  Read FIRST: where the action row / the record's ctrl
+      // live in global memory (the 64-environments kernel) the loads' latency passes behind the kinematics instead of being waited for,
+      // one after the other, in front of the factorisation.
+      D cu[3];
+      if (from_rec) {
+        lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; cu[A_] = lds.cld(C_CTRL + A_); });
+      } else {
+        D act_[3];
+        lfor<0, 3>([&](auto aa) { constexpr int A_ = decltype(aa)::value; act_[A_] = lds.cld(C_ACT + A_); });
+        lfor<0, 3>([&](auto aa) {
+          constexpr int A_ = decltype(aa)::value;
+          constexpr int Dd = A_ == 2 ? 3 : A_;
+          if constexpr (MODE == 0) cu[A_] = 10.0 * (act_[A_] - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
+          else cu[A_] = act_[A_];
+        });
+      }
       {
         Kin k;
         fk<0>(st.qb, st.ql, st.vb, st.vl, leg, K, k);
         lds.mark(1);
         mass_bias<0>(k, leg, K, mm);
         lds.mark(2);
+        // The table constants of the active-set tests, in ONE batch ahead of the tests: every masked descriptor store below is a basic
+        // block of its own, and a constant loaded inside it is waited for there -- thirteen to sixteen load latencies in a row for a lone
+        // wavefront (r05 phase clocks: ~4800 cycles for these 490 instructions).
+        D c_rng[8], c_dofw[4], c_sphd[18], c_sphr[9], c_sphw[9], c_sphy[HF ? 9 : 1], c_anch[4];
+        lfor<0, 8>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_rng[Ii] = kc(K, LK_JNT_RANGE + Ii); });
+        lfor<0, 4>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_dofw[Ii] = kc(K, LK_DOF_INVWEIGHT + Ii); });
+        lfor<0, 18>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_sphd[Ii] = kc(K, LK_SPH_D + Ii); });
+        lfor<0, 9>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
+          c_sphr[Ii] = kc(K, LK_SPH_R + Ii); c_sphw[Ii] = kc(K, LK_SPH_INVWEIGHT + Ii);
+          if constexpr (HF) c_sphy[Ii] = kc(K, LK_SPH_Y + Ii);
+        });
+        c_anch[0] = kc(K, LK_EQ_D1); c_anch[1] = kc(K, LK_EQ_D1 + 1); c_anch[2] = kc(K, LK_EQ_D2); c_anch[3] = kc(K, LK_EQ_D2 + 1);
+        B::fence();
         lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; lds.cst(C_OX + J, k.ox[J], live | !live); lds.cst(C_OZ + J, k.oz[J], live | !live); });
         // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
         const D basez = st.qb[1] - cp_qpos0[1] + cp_link_off[0][0][1];
         lfor<0, 4>([&](auto jj) {
           constexpr int Jj = decltype(jj)::value;
           const D qd = st.ql[Jj];
-          const D lo = kc(K, LK_JNT_RANGE + 2 * Jj), hi = kc(K, LK_JNT_RANGE + 2 * Jj + 1);
+          const D lo = c_rng[2 * Jj], hi = c_rng[2 * Jj + 1];
           const D dlo = qd - lo, dhi = hi - qd;
           const M act = (dlo < 0.0) | (dhi < 0.0);
           const D pos = B::sel(dlo < 0.0, dlo, dhi);
           const D sgn = B::sel(dlo < 0.0, D(1.0), D(-1.0));
-          lds.st_lim(nlim, pos, sgn, kc(K, LK_DOF_INVWEIGHT + Jj), I(Jj), act & (nlim < 4));
+          lds.st_lim(nlim, pos, sgn, c_dofw[Jj], I(Jj), act & (nlim < 4));
           nlim = nlim + B::toI(act);
         });
         lfor<0, 9>([&](auto cc) {
           constexpr int Cc = decltype(cc)::value;
           constexpr int Lk = Cc == 0 ? 0 : (Cc + 1) / 2;   // Kin link of candidate Cc: pelvis, thigh x2, shin x2, tarsus x2, toe x2
           D cx, cz;
-          link_point<Lk>(k, kc(K, LK_SPH_D + 2 * Cc), kc(K, LK_SPH_D + 2 * Cc + 1), cx, cz);
+          link_point<Lk>(k, c_sphd[2 * Cc], c_sphd[2 * Cc + 1], cx, cz);
           if constexpr (HF) {
             // height field (terrain_sphere, cassie_kernels.hip): the sphere against the local plane of the cell under its centre;
             // contact frame = (normal (nx, nz), tangent (nz, -nx)), contact point half-way into the penetration along the normal
             const D basex = st.qb[0] - cp_qpos0[0] + cp_link_off[0][0][0];
-            const D rad = kc(K, LK_SPH_R + Cc);
+            const D rad = c_sphr[Cc];
             D dist, nx, nz;
-            B::hf_sphere(*hf, basex + cx, kc(K, LK_SPH_Y + Cc), basez + cz, rad, dist, nx, nz);
+            B::hf_sphere(*hf, basex + cx, c_sphy[Cc], basez + cz, rad, dist, nx, nz);
             M act = dist < 0.0;
             if constexpr (Cc == 0) act = act & (leg == 0);
             const D back = rad + 0.5 * dist;
-            lds.st_pair(ncon, cx - nx * back, cz - nz * back, dist, kc(K, LK_SPH_INVWEIGHT + Cc), I(Lk), act & (ncon < 3));
+            lds.st_pair(ncon, cx - nx * back, cz - nz * back, dist, c_sphw[Cc], I(Lk), act & (ncon < 3));
             lds.st_nrm(ncon, nx, act & (ncon < 3));
             ncon = ncon + B::toI(act);
           } else {
-          const D dist = basez + cz - kc(K, LK_SPH_R + Cc);
+          const D dist = basez + cz - c_sphr[Cc];
           M act = dist < 0.0;
           if constexpr (Cc == 0) act = act & (leg == 0);
           // contact point: half-way into the penetration, on the vertical through the sphere centre
-          lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, kc(K, LK_SPH_INVWEIGHT + Cc), I(Lk), act & (ncon < 3));
+          lds.st_pair(ncon, cx, 0.5 * dist - basez, dist, c_sphw[Cc], I(Lk), act & (ncon < 3));
           ncon = ncon + B::toI(act);
           }
         });
         // connect anchors: rod end (Kin link 5) against the heel-spring anchor on the tarsus (Kin link 3)
-        link_point<5>(k, kc(K, LK_EQ_D1), kc(K, LK_EQ_D1 + 1), p1x, p1z);
-        link_point<3>(k, kc(K, LK_EQ_D2), kc(K, LK_EQ_D2 + 1), p2x, p2z);
+        link_point<5>(k, c_anch[0], c_anch[1], p1x, p1z);
+        link_point<3>(k, c_anch[2], c_anch[3], p2x, p2z);
       }
       B::fence();
       lds.mark(3);
@@ -481,15 +511,6 @@ template <class B> struct Core {
       small = !B::any(go & ((nlim > 0) | (ncon > 2)));
       LEG_STAT_SMALL(small, go, nlim, ncon);
       {
-        // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3)
-        D cu[3];
-        lfor<0, 3>([&](auto aa) {
-          constexpr int A_ = decltype(aa)::value;
-          constexpr int Dd = A_ == 2 ? 3 : A_;
-          if (from_rec) cu[A_] = lds.cld(C_CTRL + A_);
-          else if constexpr (MODE == 0) cu[A_] = 10.0 * (lds.cld(C_ACT + A_) - st.ql[Dd]) + 5.0 * (0.0 - st.vl[Dd]);
-          else cu[A_] = lds.cld(C_ACT + A_);
-        });
         if (integrate) {
           // DynamicModel::setState of this substep (pre-step state), mj_data->ctrl, env clock -- for environments that carry it out
           lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; lds.cst(C_KQ + Bc, st.qb[Bc], go); lds.cst(C_KV + Bc, st.vb[Bc], go); });

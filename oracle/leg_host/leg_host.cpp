@@ -82,6 +82,8 @@ struct HostDuoB : HostB {
   struct W { double (*p)[NL]; };
   static VD wld(W ws, int slot) { VD r; LANES r.v[l] = ws.p[slot][l]; return r; }
   static void wst(W ws, int slot, VD v) { LANES ws.p[slot][l] = v.v[l]; }
+  static void wld2(W ws, int slot, VD& a, VD& b) { a = wld(ws, slot); b = wld(ws, slot + 1); }
+  static void wst2(W ws, int slot, VD a, VD b) { wst(ws, slot, a); wst(ws, slot + 1, b); }
   struct Lds {
     double cold[2][20][NL];
     double pr[2][2][4][NL], pr2[4][NL], lm[4][3][NL];
