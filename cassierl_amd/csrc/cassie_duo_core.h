@@ -368,6 +368,7 @@ template <class B> struct Duo : Core<B> {
       o[G].do_reset = none; o[G].bad = none;
     });
     B::fence();
+    lds.mark(16);   // (16..21: pieces of the glue, bucket 0 unless the build splits it) 16 = records in, state parked
     bool reset_pass = false;
     int sub = 0;
     while (true) {
@@ -497,16 +498,19 @@ template <class B> struct Duo : Core<B> {
         const Io io = io_of(G);
         lds.select(G, io);
         Lane st;
+        lds.mark(17);   // 17 = bookkeeping after the last substep
         get_lane(ws, G * W_GROUP, st);
         if (C::step_outputs(cfg, lds, io, st, live[G], o[G], reset_pass)) again = true;
         put_lane(ws, G * W_GROUP, st);
         B::fence();
+        lds.mark(reset_pass ? 19 : 18);   // 18 = outputs of the step, 19 = outputs of the reset pass
       });
       if (reset_pass || !again) break;
       reset_pass = true;
     }
     // ---- state write-back: q, v, warm start, clock, iteration count; the setState snapshot, the motor commands and qstate are in
     // the record already (written where they changed)
+    lds.mark(20);
     lfor<0, 2>([&](auto gg) {
       constexpr int G = decltype(gg)::value;
       const Io io = io_of(G);
@@ -527,6 +531,7 @@ template <class B> struct Duo : Core<B> {
       B::pst(io.rec, I(ES_NITER), B::toD(o[G].niter), valid[G] & left);
       B::pst(io.rec, I(ES_QPWSET), D(0.0), valid[G] & left & o[G].do_reset);
     });
+    lds.mark(21);   // 21 = write-back
   }
 };
 

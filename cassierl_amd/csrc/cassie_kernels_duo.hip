@@ -88,7 +88,11 @@ struct DevDuoB : DevB {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       const unsigned long long n = __builtin_readcyclecounter();
-      acc[k] += n - t_last; t_last = n;
+#ifdef DUO_GLUE_SPLIT   // experiment: the glue in pieces (marks 16..21 -> buckets 1..6), everything else in bucket 7
+      acc[k >= 16 ? k - 15 : k == 0 ? 0 : 7] += n - t_last; t_last = n;
+#else
+      acc[k < 16 ? k : 0] += n - t_last; t_last = n;
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #else

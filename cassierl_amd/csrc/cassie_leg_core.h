@@ -418,6 +418,8 @@ template <class B> struct Core {
     {
       D qsb[3], qsl[5];
       Mass mm;
+      D c_damp[5], c_actr[6], c_gear[3];        // table constants of the smooth force, read in the batch of the active-set tests
+      D c_eqsol[2], c_eqimp[3], c_eqw, sgl[5];  // ... of the rows, read ahead of the factorisation (sgl: signs of the leg's dofs)
       lds.mark(0);
       // motor commands of the own leg's actuators: hip (dof 0), knee (1), toe (3).  Read FIRST: where the action row / the record's ctrl
       // live in global memory (the 64-environments kernel) the loads' latency passes behind the kinematics instead of being waited for,
@@ -454,6 +456,9 @@ template <class B> struct Core {
           if constexpr (HF) c_sphy[Ii] = kc(K, LK_SPH_Y + Ii);
         });
         c_anch[0] = kc(K, LK_EQ_D1); c_anch[1] = kc(K, LK_EQ_D1 + 1); c_anch[2] = kc(K, LK_EQ_D2); c_anch[3] = kc(K, LK_EQ_D2 + 1);
+        lfor<0, 5>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_damp[Ii] = kc(K, LK_DOF_DAMPING + Ii); });   // (for the smooth force, below)
+        lfor<0, 6>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_actr[Ii] = kc(K, LK_ACT_RANGE + Ii); });
+        lfor<0, 3>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_gear[Ii] = kc(K, LK_ACT_GEAR + Ii); });
         B::fence();
         lfor<0, 6>([&](auto jj) { constexpr int J = decltype(jj)::value; lds.cst(C_OX + J, k.ox[J], live | !live); lds.cst(C_OZ + J, k.oz[J], live | !live); });
         // ---- active set.  Limits: leg dofs 0..3 (the rod is unlimited); contacts: pelvis sphere (left lane only) + 8 leg spheres.
@@ -510,6 +515,10 @@ template <class B> struct Core {
       out.go = go;
       small = !B::any(go & ((nlim > 0) | (ncon > 2)));
       LEG_STAT_SMALL(small, go, nlim, ncon);
+      c_eqsol[0] = kc(K, LK_EQ_SOLREF); c_eqsol[1] = kc(K, LK_EQ_SOLREF + 1);
+      lfor<0, 3>([&](auto ii) { constexpr int Ii = decltype(ii)::value; c_eqimp[Ii] = kc(K, LK_EQ_SOLIMP + Ii); });
+      c_eqw = kc(K, LK_EQ_INVWEIGHT);
+      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sgl[Dd] = kc(K, LK_DOF_SIGMA + Dd); });
       {
         if (integrate) {
           // DynamicModel::setState of this substep (pre-step state), mj_data->ctrl, env clock -- for environments that carry it out
@@ -523,12 +532,12 @@ template <class B> struct Core {
         lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; lds.cst(C_TAUB + Bc, taub[Bc], live | !live); });
         lfor<0, 5>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
-          D t = -kc(K, LK_DOF_DAMPING + Dd) * st.vl[Dd] - mm.biasl[Dd];
+          D t = -c_damp[Dd] * st.vl[Dd] - mm.biasl[Dd];
           if constexpr (Dd == 0 || Dd == 1 || Dd == 3) {
             constexpr int A_ = Dd == 3 ? 2 : Dd;
-            const D lo = kc(K, LK_ACT_RANGE + 2 * A_), hi = kc(K, LK_ACT_RANGE + 2 * A_ + 1);
+            const D lo = c_actr[2 * A_], hi = c_actr[2 * A_ + 1];
             const D u = B::sel(cu[A_] < lo, lo, B::sel(cu[A_] > hi, hi, cu[A_]));
-            t = t + kc(K, LK_ACT_GEAR + A_) * u;
+            t = t + c_gear[A_] * u;
           }
           taul[Dd] = t;
           lds.cst(C_TAUL + Dd, t, live | !live);
@@ -553,11 +562,9 @@ template <class B> struct Core {
         k_.d0 = d0; k_.d1 = d1; k_.w = w; k_.imp0 = impedance(d0, d1, w, D(0.0));
         return k_;
       };
-      const KindPar kp_eq = kind_par(kc(K, LK_EQ_SOLREF), kc(K, LK_EQ_SOLREF + 1), kc(K, LK_EQ_SOLIMP), kc(K, LK_EQ_SOLIMP + 1), kc(K, LK_EQ_SOLIMP + 2));
+      const KindPar kp_eq = kind_par(c_eqsol[0], c_eqsol[1], c_eqimp[0], c_eqimp[1], c_eqimp[2]);
       const KindPar kp_lim = kind_par(D(cp_limit_solref[0]), D(cp_limit_solref[1]), D(cp_limit_solimp[0]), D(cp_limit_solimp[1]), D(cp_limit_solimp[2]));
       const KindPar kp_con = kind_par(D(cp_contact_solref[0]), D(cp_contact_solref[1]), D(cp_contact_solimp[0]), D(cp_contact_solimp[1]), D(cp_contact_solimp[2]));
-      D sgl[5];   // signs of the leg's dofs
-      lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; sgl[Dd] = kc(K, LK_DOF_SIGMA + Dd); });
       D bvec[CAP], z[CAP][5];
       D jar_prev = 0.0, Rr_prev = 1.0;   // the normal row's values while its tangent row is built
       const D mu = CP_CONTACT_MU;
@@ -570,7 +577,7 @@ template <class B> struct Core {
         jb[0] = 0.0; jb[1] = 0.0; jb[2] = 0.0;
         if constexpr (S < 2) {
           kd = K_EQ;
-          invw = kc(K, LK_EQ_INVWEIGHT);
+          invw = c_eqw;
           pos = S == 0 ? p1x - p2x : p1z - p2z;
           // J = J(p1 on rod: pitch, hip, rod) - J(p2 on tarsus: pitch, hip, knee, ankle); the base slides cancel
           auto ent = [&](D px, D pz, auto jl_) { constexpr int Jl = decltype(jl_)::value; return S == 0 ? pz - lds.cld(C_OZ + Jl) : -(px - lds.cld(C_OX + Jl)); };  // y^ x (p - o), component S
@@ -635,9 +642,11 @@ template <class B> struct Core {
         D vel = jb[0] * st.vb[0] + jb[1] * st.vb[1] + jb[2] * st.vb[2];
         D bq = jb[0] * qsb[0] + jb[1] * qsb[1] + jb[2] * qsb[2];
         D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
+        // (a connect row has no entry on the toe dof, slot 3 of the leg's dofs; a contact / limit row none on the rod, slot 4: the terms
+        // that would add an exact zero are left out, here and in z, u, A below)
         lfor<0, 5>([&](auto dd) {
           constexpr int Dd = decltype(dd)::value;
-          vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd];
+          if constexpr (S < 2 ? Dd != 3 : Dd != 4) { vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd]; }
         });
         const D imp = impedance(simp0, simp1, simp2, pos);
         D R = (1.0 - imp) / imp * invw;
@@ -655,14 +664,14 @@ template <class B> struct Core {
         lfor<0, 5>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Li[symidx(5, Ii, Jj)] * jl[Jj]; });
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if constexpr (S < 2 ? Jj != 3 : Jj != 4) a += fc.Li[symidx(5, Ii, Jj)] * jl[Jj]; });
           z[S][Ii] = a;
         });
         D u[3];
         lfor<0, 3>([&](auto bb) {
           constexpr int Bc = decltype(bb)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += fc.Y[Jj][Bc] * jl[Jj]; });   // C' z = C' L^-1 jl = Y' jl
+          lfor<0, 5>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if constexpr (S < 2 ? Jj != 3 : Jj != 4) a += fc.Y[Jj][Bc] * jl[Jj]; });   // C' z = C' L^-1 jl = Y' jl
           u[Bc] = jb[Bc] - a;
         });
         Gmul(fc, u, ut[S]);
@@ -670,7 +679,7 @@ template <class B> struct Core {
         lfor<0, S + 1>([&](auto ii) {
           constexpr int Ii = decltype(ii)::value;
           D a = 0.0;
-          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; a += z[Ii][Dd] * jl[Dd]; });
+          lfor<0, 5>([&](auto dd) { constexpr int Dd = decltype(dd)::value; if constexpr (S < 2 ? Dd != 3 : Dd != 4) a += z[Ii][Dd] * jl[Dd]; });
           if constexpr (Ii == S) a += Rr;
           Al[symidx(CAP, Ii, S)] = a;
         });
