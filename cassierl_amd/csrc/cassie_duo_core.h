@@ -111,8 +111,9 @@ template <class B> struct Duo : Core<B> {
     lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & L.pair[P]); anyPair[1][P] = B::any(go & R.pair[P]); });
     D accL = 0.0, accR = 0.0;
     D rdenL[NP], rdenR[NP];
-    // FULL (compile time): every lane of the wavefront is sweeping and has both contact pairs on both legs (64 robots on their feet, none
-    // converged yet: the common case) -- the ownership / "still sweeping" selects are identities and are left out.  Same arithmetic.
+    // FULL (compile time): every lane of the wavefront is sweeping (64 robots, none converged yet: the common case) -- the "still
+    // sweeping" selects are identities and are left out; a lane without a pair runs the pair's step on its all-zero rows with the update
+    // masked off (the step adds exact zeros).  Same arithmetic.
     auto eq_step = [&](LegRows& g, D& acc, auto ss, auto full_) {
       LEG_FP_CONTRACT_OFF
       constexpr int S = decltype(ss)::value;
@@ -154,7 +155,8 @@ template <class B> struct Duo : Core<B> {
       D dn = fn - on, dt = ft - ot;
       D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rt)), dn * B::fma(0.5 * Ann, dn, rn));
       M keep = chg <= 1e-10;
-      if constexpr (!FULL) keep = keep & (sweeping & g.pair[P]);
+      if constexpr (FULL) keep = keep & g.pair[P];
+      else keep = keep & (sweeping & g.pair[P]);
       dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
       a0 = B::fma(g.ut[T][0], dt, B::fma(g.ut[N][0], dn, a0)); a1 = B::fma(g.ut[T][1], dt, B::fma(g.ut[N][1], dn, a1)); a2 = B::fma(g.ut[T][2], dt, B::fma(g.ut[N][2], dn, a2));
       acc = acc + chg;
@@ -175,8 +177,8 @@ template <class B> struct Duo : Core<B> {
     I niter = 0;
     int iter = 0;
     // two loops, not one loop with two bodies (one loop with both bodies: the allocator shuffles the row data between the register files,
-    // 228 moves per pass instead of 80): sweeps while every lane is a sweeping robot with two pairs per leg, then the general sweeps
-    if (!B::any(!(go & L.pair[0] & L.pair[1] & R.pair[0] & R.pair[1]))) {
+    // 228 moves per pass instead of 80): sweeps while every lane is a sweeping robot, then the general sweeps
+    if (!B::any(!go) && anyPair[0][0] && anyPair[0][1] && anyPair[1][0] && anyPair[1][1]) {   // (every pair slot is somebody's: no step is run for nobody)
       for (; iter < LEG_ITERS; iter++) {
         if (B::any(!sweeping)) break;
         accL = 0.0; accR = 0.0;
