@@ -581,9 +581,10 @@ def roofline_object(n_local, kernel_ms, dominant, pmc):
                     "traffic_bytes_per_launch": pmc.get("hbm_bytes_per_launch")},
             "flop_model": "useful: +,-,* = 1 (a*b+c = 2); /, sqrt, 1/x, exp = 1; sincos = 2; compare/select/move = 0; reset pass of a "
                           "terminated environment included.  issued = 64 x (ADD + MUL + TRANS + 2 FMA) FP64 wave-instructions",
-            "note": "FP64 vector unit: the joint Gauss-Seidel sweeps (a lane per environment, ~46 % of the launch) run at the 4-cycle issue rate of a lone "
-                    "wavefront, the lane-per-leg set-up / finish (~34 %) at ~9 cycles per instruction, the phase hand-over through the per-wavefront "
-                    "workspace ~16 %; `traffic` is L2-to-fabric bytes (97 % of it that workspace, Infinity-Cache resident), not HBM-bound (hbm.frac)"}
+            "note": "FP64 vector unit: the joint Gauss-Seidel sweeps (a lane per environment, ~48 % of the launch) run at the 4-cycle issue rate of a lone "
+                    "wavefront, the lane-per-leg set-up / finish (~30 %) at ~5 cycles per instruction, the phase hand-over through the per-wavefront "
+                    "workspace ~12 %, per-step glue ~8 %; `traffic` is L2-to-fabric bytes (97 % of it that workspace, Infinity-Cache resident), not "
+                    "HBM-bound (hbm.frac)"}
 
 
 # ------------------------------------------------------------------------------------------------ one rank

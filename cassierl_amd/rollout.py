@@ -79,6 +79,9 @@ def init_distributed(backend=None):
         if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            # c10d's store looks up the host name of every client it accepts (for a log line); where the container's resolver cannot reach a
+            # name server each of those lookups waits out the resolver's time-out (glibc default: 5 s x 2 attempts per server)
+            os.environ.setdefault("RES_OPTIONS", "timeout:1 attempts:1")
         if backend is None:
             backend = os.environ.get("CASSIE_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
