@@ -13,11 +13,27 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(args, env_extra=None, timeout=900):
+def _run(args, env_extra=None, timeout=900, attempts=2):
+    """bench.py in its own session: a run that outlives `timeout` is stopped together with the ranks it spawned (their process group --
+    r05: a two-rank run that hung on one box was killed by the launcher's pid alone, and its ranks went on sharing the GPU with the tests
+    behind it), and tried once more (a rendezvous that hangs does so at start-up; the second attempt gets a fresh port)."""
+    import signal
     env = dict(os.environ)
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
-    return p.returncode, p.stdout, p.stderr
+    for attempt in range(attempts):
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=timeout if attempt == attempts - 1 else min(timeout, 300))
+            return p.returncode, out, err
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)   # the session we started: launcher + its ranks, nothing else
+            except ProcessLookupError:
+                pass
+            out, err = p.communicate()
+            if attempt == attempts - 1:
+                return 124, out, err + "\n[test] bench.py timed out"
 
 
 def _line(out):
