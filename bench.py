@@ -415,6 +415,20 @@ def extra_workloads(traj, n):
     rows.append(run_env_workload("torque_random_no_reset_fallen", n, "stand", "Torque", 0, traj, 200, 20,
                                  lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
                                  "random torques, auto_reset off: robots on the ground (throughput floor of the PD/torque path)", auto_reset=False))
+    # counted useful FP64 of the two falling-robot rows (tests/count_flops.py: the first tier's own source through the op-counting CPU build, robots in the
+    # same regime) against the FP64 vector peak, over the WHOLE step (first tier in segments + the lower tiers beside it)
+    try:
+        uf_all = json.load(open(os.path.join(ROOT, "profiles", "useful_flops.json")))
+        for row in rows:
+            uf = (uf_all.get(row["workload"]) or {}).get("flop_per_env_step")
+            if uf:
+                ach = uf * row["env_steps_per_s"] / 1e12
+                row["roofline"] = dict(bound="fp64_valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_VALU_PEAK_TFLOPS,
+                                       useful_flop_per_env_step=uf,
+                                       note="useful flops counted on the two-lanes-per-environment kernel's source (what the first tier executes here, in "
+                                            "segments); an environment finished by a lower tier is priced at the same count")
+    except Exception:
+        pass
     # (b'') N4: the same random-PD rollout on a height field (terrain_random.py's <hfield>: here 3 cm rolling relief, 20 m x 20 m)
     xs = np.linspace(-10.0, 10.0, 2001)
     relief = np.tile(0.015 * (1.0 - np.cos(2.0 * np.pi * xs / 1.5)), (64, 1))

@@ -56,6 +56,41 @@ def count_cassie3d(n=16, warm=30, steps=30):
                 convention="as pd_bench; per env-step of 10 substeps CARRIED OUT by this kernel; robots fall during the counted steps")
 
 
+def count_fallen(n=16, warm=150, steps=12):
+    """The floor of the PD / torque path (bench row torque_random_no_reset_fallen): stand env, torque mode, U(+-ctrlrange) (stream 3), no reset -- after the
+    warm-up the robots lie on the ground.  An environment that needs more than eight rows on a leg leaves this kernel (on the GPU a lower tier finishes its
+    step); here it is put back on its feet and falls again: its substeps are not counted, their share is reported."""
+    import torch
+    import oracle_py as O
+    from conftest import state_vec
+    from leg_host import LegHostEnv, lib
+    from cassierl_amd import rollout as R
+    lo, hi = -np.array([12.2, 12.2, 0.9] * 2), np.array([12.2, 12.2, 0.9] * 2)
+    env = LegHostEnv(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False)
+    oe = O.OracleEnv("stand", "Torque")
+    oe.reset()
+    q, v = oe.oracle.state()
+    ctor = O.Oracle()
+    s0 = state_vec(q, v, oe.oracle.warmstart(), kq=ctor.state()[0], kv=ctor.state()[1], qstate=q)
+    env.set_full_state_host(np.tile(s0, (n, 1)))
+    ids = torch.arange(n)
+    done, left, sweeps, pairs, z = 0, 0, 0.0, 0, []
+    for t in range(warm + steps):
+        if t == warm:
+            lib().leg_host_ops()
+        env.step_host(R.random_actions(3, ids, t, lo, hi).numpy())
+        over = env.pending > 0
+        if t >= warm:
+            done += 10 * n - int(env.pending.sum()); left += int(env.pending.sum()); sweeps += env.state[~over, 85].sum(); pairs += int((~over).sum()); z.append(float(env.state[~over, 1].mean()))
+        env.state[over] = s0
+        env.pending[:] = 0
+    ops = lib().leg_host_ops()
+    return dict(flop_per_env_step=ops / max(1, done) * 10.0, pgs_sweeps_per_env_step=float(sweeps) / max(1, pairs), envs=n, env_steps=steps,
+                substeps_not_counted_frac=left / (10.0 * n * steps), mean_pelvis_height=float(np.mean(z)),
+                convention="as pd_bench; per env-step of 10 substeps CARRIED OUT by this kernel; robots on the ground (no reset); an environment that leaves the "
+                           "kernel's row capacity is put back on its feet")
+
+
 def main():
     import torch
     import oracle_py as O
@@ -88,6 +123,8 @@ def main():
                          convention="+,-,* = 1 (a*b+c = 2); /, sqrt, 1/x, exp = 1; sincos = 2; compare/select/move = 0; in a Gauss-Seidel step only "
                                     "the owner leg's lane counts; the reset pass of a terminated environment is included")
         print(name, json.dumps(out[name]))
+    out["torque_random_no_reset_fallen"] = count_fallen()
+    print("torque_random_no_reset_fallen", json.dumps(out["torque_random_no_reset_fallen"]))
     out["cassie3d_torque_random"] = count_cassie3d()
     print("cassie3d_torque_random", json.dumps(out["cassie3d_torque_random"]))
     with open(os.path.join(ROOT, "profiles", "useful_flops.json"), "w") as f:
