@@ -48,6 +48,12 @@ namespace leg {
 #ifndef LEG3_STAT   // instrumented CPU builds only (tests/leg3d_stats.py): counts executed sweeps / limit steps / contact steps / Newton iterations per wavefront
 #define LEG3_STAT(k)
 #endif
+#ifndef LEG3_MARK   // profiling builds of the device kernel only (cassie3d_leg.hip, -DCASSIE3D_PHASE_TIMING; tests/phase_profile_3d.py): shader cycles per phase of the substep
+#define LEG3_PHASE_BEGIN
+#define LEG3_MARK(k)
+#define LEG3_SW_MARK(k)
+#define LEG3_SW_FLUSH
+#endif
 #ifndef LEG3_ITERS
 #define LEG3_ITERS ITERATIONS   // (timing experiments only: -DLEG3_ITERS=n)
 #endif
@@ -412,11 +418,13 @@ template <class B> struct Core3 {
   static LEG3_SUBSTEP_FN void substep(typename B::Lds& lds, Lane& st, const D (&cu)[5], M live, bool integrate, SubOut& out) {
     const I leg = B::opq(B::leg());
     const KP_ K = B::kbase(leg);
+    LEG3_PHASE_BEGIN
     Fact fc;
     D qsb[6], qsl[7], sn[7], cs[7];
     {
       Mass mm;
       mass_bias(lds, st, K, mm, sn, cs);
+      LEG3_MARK(0)   // 0 = kinematics, mass matrix, bias
       B::fence();
       D taub[6], taul[7];
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; taub[Bc] = -mm.biasb[Bc]; });
@@ -436,6 +444,7 @@ template <class B> struct Core3 {
       minv_apply(fc, taub, taul, qsb, qsl);
     }
     B::fence();
+    LEG3_MARK(1)   // 1 = smooth force, factorisation, M^-1 tau
     // ---- raw rows (Jacobians, position, inverse weight).  Joint limits first (they only need q) and straight into their LDS
     // records: the contacts' records start behind them.  The connect rows stay in registers.
     I nlim = 0, ncon = 0;
@@ -561,6 +570,7 @@ template <class B> struct Core3 {
     out.nrows = nlim + ncon * 3 + 3;
     out.nrows = out.nrows + B::swapi(out.nrows);
     B::fence();
+    LEG3_MARK(2)   // 2 = raw rows: joint limits, collision, connect
     // ---- finish the rows: impedance, R, reference acceleration, z, u~, diagonal, warm start; c and a~ of the warm start
     const D mu = MU;
     struct KindPar { D kk, bb, d0, d1, w; };
@@ -627,6 +637,7 @@ template <class B> struct Core3 {
       warm(w, f);
       B::fence();
     });
+    LEG3_MARK(5)   // 5 = connect rows finished
     for (int j = 0; j < 6; j++) {   // joint limits (compacted: limit j exists only if limit j - 1 does)
       const M valid = go & (nlim > j);
       if (!B::any(valid)) break;
@@ -645,6 +656,7 @@ template <class B> struct Core3 {
       lds.stv(base + R3_F, f, valid);
       warm(w, f);
     }
+    LEG3_MARK(6)   // 6 = limit rows finished
     for (int p = 0; p < 9; p++) {   // contacts: normal, tangent 1, tangent 2
       const M valid = go & (ncon > p);
       if (!B::any(valid)) break;
@@ -687,6 +699,7 @@ template <class B> struct Core3 {
       put(base, wn, fn); put(base + C3_ROW, w1, f1); put(base + 2 * C3_ROW, w2, f2);
     }
     lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
+    LEG3_MARK(7)   // 7 = contact rows finished (+ their 3 x 3 blocks and cone warm start)
     // (A f)_i + b_i pieces shared by the cost of the warm start and the sweeps: two accumulation chains instead of one
     auto dot_c = [&](const D (&jl)[7]) {
       D x = jl[0] * c[0], y = jl[1] * c[1];
@@ -750,6 +763,7 @@ template <class B> struct Core3 {
       lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; c[Dd] = B::sel(drop, D(0.0), c[Dd]); });
       lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::sel(drop, D(0.0), at[Bc]); });
     }
+    LEG3_MARK(3)   // 3 = cost of the warm start (kept only if negative)
     // ---- PGS sweeps (mj_solPGS, elliptic cones), MuJoCo's row order; a~ = `at` is shared by the two lanes of an environment.
     // A lane that does not own a step executes it all the same with its deltas masked to zero; what it reads from its own LDS slots
     // is whatever it last wrote there (finite: the kernel clears the slots once), so 0 x it cannot poison c or a~.
@@ -889,6 +903,7 @@ template <class B> struct Core3 {
           eq_step(LI<0>{}, side); eq_step(LI<1>{}, side); eq_step(LI<2>{}, side);
           sync(w);
         }
+        LEG3_SW_MARK(0)   // (inside the sweeps: 0 = connect steps, 1 = limit steps, 2 = contact steps + the stopping test)
         for (int w = 0; w < 2; w++) {
           const M side = (w == 0 ? isL : !isL) & sweeping;
           if (!B::any(side & (nlim > 0))) continue;
@@ -899,6 +914,7 @@ template <class B> struct Core3 {
           }
           sync(w);
         }
+        LEG3_SW_MARK(1)
         for (int w = 0; w < 2; w++) {
           const M side = (w == 0 ? isL : !isL) & sweeping;
           if (!B::any(side & (ncon > 0))) continue;
@@ -912,10 +928,12 @@ template <class B> struct Core3 {
         const D improvement = -(acc + B::swap(acc));
         niter = niter + B::toI(sweeping);
         sweeping = sweeping & !(improvement * scale < TOLERANCE);
+        LEG3_SW_MARK(2)
       }
     }
     out.niter = niter;
     B::fence();
+    LEG3_SW_FLUSH
     // ---- qacc = qacc_smooth + M^-1 J' f = qs + [G' a~ ; c - Y G' a~]; implicit joint damping of mj_Euler as in cassie_leg_core.h:
     // (M + h B) qacc' = M qacc  <=>  qacc' = (I + E)^-1 qacc, E = M^-1 h B a contraction (tests/test_implicit_damping_bound.py)
     D xb[6], xl[7];
@@ -976,6 +994,7 @@ template <class B> struct Core3 {
       st.qq[2] = B::sel(go, a0 * r2 - a1 * r3 + a2 * r0 + a3 * r1, st.qq[2]);
       st.qq[3] = B::sel(go, a0 * r3 + a1 * r2 - a2 * r1 + a3 * r0, st.qq[3]);
     }
+    LEG3_MARK(4)   // 4 = qacc, implicit damping, integration
   }
 
   // ------------------------------------------------------------------------------------------------ HBM <-> lane, n_sub substeps

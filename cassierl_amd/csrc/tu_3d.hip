@@ -26,3 +26,13 @@ void init3d(int n_envs, hipStream_t s, double* state, const double* qpos, const 
 
 }  // namespace launch
 }  // namespace cassie3d
+
+#ifdef CASSIE3D_PHASE_TIMING
+// profiling builds only; not part of the public ABI: the phase clocks of env_step3d_leg_kernel since the last call
+extern "C" int Cassie3dDebugPhaseCycles(unsigned long long* out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cassie3d::leg::k5c_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(cassie3d::leg::k5c_phase), z, sizeof z) == hipSuccess ? 0 : -3;
+}
+#endif
