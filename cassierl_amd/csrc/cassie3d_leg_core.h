@@ -793,13 +793,24 @@ template <class B> struct Core3 {
         acc = acc + chg;
         eq[S].f = eq[S].f + d;
       };
-      auto lim_step = [&](I base_, M mine) {   // a joint limit: f >= 0
+      // A limit row's LDS record (LRaw) is read one step AHEAD (r05): the step of row j starts from registers while the record of row j + 1 is on
+      // its way (another record: the store of f_j does not touch it), instead of every step opening with ~100 cycles of LDS latency.
+      struct LRaw { D z[7], ut[6], R, b, f, ks, ad; };
+      auto lraw = [&](I base, LRaw& r) {
+        lfor<0, 7>([&](auto dd) { constexpr int Dd = decltype(dd)::value; r.z[Dd] = lds.ldv(base + (R3_Z + Dd)); });
+        lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; r.ut[Bc] = lds.ldv(base + (R3_UT + Bc)); });
+        r.R = lds.ldv(base + R3_R); r.b = lds.ldv(base + R3_B); r.f = lds.ldv(base + R3_F); r.ks = lds.ldv(base + R3_KS); r.ad = lds.ldv(base + R3_AD);
+      };
+      auto lim_step = [&](I base_, M mine, const LRaw& r) {   // a joint limit: f >= 0; r = the record of `base_` (of slot DYN0 on a bystander lane)
         typename B::OwnerScope scope_(mine);
         LEG3_STAT(1);
         const I base = B::seli(mine, base_, I(DYN0));   // (a bystander stays inside its slots)
-        LRow r; lload(base, r);
-        const D ad = lds.ldv(base + R3_AD), ai = B::rcp(ad);
-        const D res = (B::fma(r.R, r.f, r.b) + r.jc) + dot_a(r.ut);
+        const D ak = B::fabs(r.ks);
+        D ck = c[0];
+        lfor<1, 6>([&](auto dd) { constexpr int Dd = decltype(dd)::value; ck = B::sel(ak == D(Dd + 1.0), c[Dd], ck); });   // (a select tree instead of this chain: 5.60 -> 5.67 ms per step, not kept)
+        const D jc = B::sel(r.ks > 0.0, ck, -ck);
+        const D ad = r.ad, ai = B::rcp(ad);
+        const D res = (B::fma(r.R, r.f, r.b) + jc) + dot_a(r.ut);
         const D nf = B::fmax(B::fma(-res, ai, r.f), D(0.0));
         D d = nf - r.f;
         D chg = d * B::fma(0.5 * ad, d, res);
@@ -907,10 +918,15 @@ template <class B> struct Core3 {
         for (int w = 0; w < 2; w++) {
           const M side = (w == 0 ? isL : !isL) & sweeping;
           if (!B::any(side & (nlim > 0))) continue;
+          LRaw cur;
+          lraw(I(DYN0), cur);   // row 0 (a lane without limits reads its slot DYN0 too: masked below)
           for (int j = 0; j < 6; j++) {
             const M mine = side & (nlim > j);
             if (!B::any(mine)) break;
-            lim_step(I(DYN0 + j * R3_N), mine);
+            LRaw nxt = cur;
+            if (j < 5) lraw(B::seli(side & (nlim > j + 1), I(DYN0 + (j + 1) * R3_N), I(DYN0)), nxt);
+            lim_step(I(DYN0 + j * R3_N), mine, cur);
+            cur = nxt;
           }
           sync(w);
         }
