@@ -117,6 +117,29 @@ def test_two_ranks_sharing_one_gpu_exercise_the_n_rank_path():
     assert abs(_line(out1)["returns_checksum"] - line["returns_checksum"]) < 1e-6 * abs(line["returns_checksum"])
 
 
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """The driver's own command for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W` -- with the two ranks mapped onto the one GPU of this box and gloo carrying the collectives (RCCL refuses
+    two ranks on one device): ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, rank 0 prints the JSON line last."""
+    import signal
+    env = dict(os.environ, CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2"]
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("torchrun bench timed out: " + err[-1500:])
+    assert p.returncode == 0, err[-2000:]
+    line = _line(out)
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak" and line["finite"]
+    assert line["config"]["ranks_joined"] == 2 and line["config"]["envs_total"] == 4096 and line["config"]["backend"] == "gloo"
+    assert abs(line["value"] - 4096 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1   # ONE JSON line (rank 0's)
+
+
 def test_mismatched_world_size_is_refused():
     env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     rc, out, err = _run(["--gpus", "4", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline", "--no-extra"], env)
