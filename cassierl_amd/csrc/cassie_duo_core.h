@@ -120,7 +120,7 @@ template <class B> struct Duo : Core<B> {
       constexpr bool FULL = decltype(full_)::value != 0;
       const D res = B::fma(g.ut[S][2], a2, B::fma(g.ut[S][1], a1, B::fma(g.ut[S][0], a0, g.r[S])));
       D d = -(res * g.Ainv[S]);
-      D chg = d * B::fma(0.5 * g.Adiag[S], d, res);
+      D chg = d * B::fma(g.Adiag[S], d, res);   // (Adiag of a connect row holds A_ii / 2: sub_setup)
       if constexpr (!FULL) {
         const M mine = sweeping;   // slots 0, 1 are K_EQ in every environment that goes
         d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
@@ -289,7 +289,7 @@ template <class B> struct Duo : Core<B> {
     s.a0 = 0.0; s.a1 = 0.0; s.a2 = 0.0;
     lfor<0, NR>([&](auto ii) {
       constexpr int Ii = decltype(ii)::value;
-      s.r[Ii] = 0.0; s.f[Ii] = 0.0; s.Adiag[Ii] = 1.0; s.Ainv[Ii] = 1.0;
+      s.r[Ii] = 0.0; s.f[Ii] = 0.0; s.Adiag[Ii] = Ii < 2 ? 0.5 : 1.0; s.Ainv[Ii] = 1.0;
       lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; s.ut[Ii][Bc] = 0.0; });
       lfor<Ii, NR>([&](auto jj) { constexpr int Jj = decltype(jj)::value; s.Al[symidx(CAP, Ii, Jj)] = 0.0; });
     });

@@ -351,9 +351,10 @@ template <class B> struct Core {
     });
   }
 
-  static LEG_FN D impedance(D d0, D d1, D width, D x) {
+  // (iw = 1 / width, formed once per row kind and substep: the rows multiply where mj_makeImpedance divides)
+  static LEG_FN D impedance(D d0, D d1, D width, D iw, D x) {
     const M flat = (d0 == d1) | (width <= LMINVAL);
-    D xx = B::fabs(x / width);
+    D xx = B::fabs(x * iw);
     D y = B::sel(xx <= 0.5, 2.0 * xx * xx, 1.0 - 2.0 * (1.0 - xx) * (1.0 - xx));
     D r = d0 + y * (d1 - d0);
     r = B::sel(xx >= 1.0, d1, r);
@@ -554,12 +555,12 @@ template <class B> struct Core {
       // row (for a contact pair: the tangent row) is complete, so nothing but z, u~, b and the packed A survives a slot.
       // soft-constraint constants of the three row kinds: k = 1 / (dmax^2 tc^2 dampratio^2), b = 2 / (dmax tc), tc >= 2 h; the
       // impedance at position 0 (what a friction row uses for its own reference acceleration)
-      struct KindPar { D kk, bb, d0, d1, w, imp0; };
+      struct KindPar { D kk, bb, d0, d1, w, iw, imp0; };
       auto kind_par = [&](D solref0, D solref1, D d0, D d1, D w) {
         KindPar k_;
         const D tc = B::sel(solref0 < 2.0 * LH, D(2.0 * LH), solref0);
         k_.kk = 1.0 / (d1 * d1 * tc * tc * solref1 * solref1); k_.bb = 2.0 / (d1 * tc);
-        k_.d0 = d0; k_.d1 = d1; k_.w = w; k_.imp0 = impedance(d0, d1, w, D(0.0));
+        k_.d0 = d0; k_.d1 = d1; k_.w = w; k_.iw = 1.0 / w; k_.imp0 = impedance(d0, d1, w, k_.iw, D(0.0));
         return k_;
       };
       const KindPar kp_eq = kind_par(c_eqsol[0], c_eqsol[1], c_eqimp[0], c_eqimp[1], c_eqimp[2]);
@@ -639,6 +640,7 @@ template <class B> struct Core {
         const D kk_ = S < 2 ? kp_eq.kk : B::sel(islim, kp_lim.kk, kp_con.kk), bb_ = S < 2 ? kp_eq.bb : B::sel(islim, kp_lim.bb, kp_con.bb);
         const D simp0 = S < 2 ? kp_eq.d0 : B::sel(islim, kp_lim.d0, kp_con.d0), simp1 = S < 2 ? kp_eq.d1 : B::sel(islim, kp_lim.d1, kp_con.d1);
         const D simp2 = S < 2 ? kp_eq.w : B::sel(islim, kp_lim.w, kp_con.w), imp_at0 = S < 2 ? kp_eq.imp0 : B::sel(islim, kp_lim.imp0, kp_con.imp0);
+        const D simp2i = S < 2 ? kp_eq.iw : B::sel(islim, kp_lim.iw, kp_con.iw);
         D vel = jb[0] * st.vb[0] + jb[1] * st.vb[1] + jb[2] * st.vb[2];
         D bq = jb[0] * qsb[0] + jb[1] * qsb[1] + jb[2] * qsb[2];
         D jw = jb[0] * st.wb[0] + jb[1] * st.wb[1] + jb[2] * st.wb[2];
@@ -648,7 +650,7 @@ template <class B> struct Core {
           constexpr int Dd = decltype(dd)::value;
           if constexpr (S < 2 ? Dd != 3 : Dd != 4) { vel += jl[Dd] * st.vl[Dd]; bq += jl[Dd] * qsl[Dd]; jw += jl[Dd] * st.wl[Dd]; }
         });
-        const D imp = impedance(simp0, simp1, simp2, pos);
+        const D imp = impedance(simp0, simp1, simp2, simp2i, pos);
         D R = (1.0 - imp) / imp * invw;
         R = B::sel(R > LMINVAL, R, D(LMINVAL));
         const M ist = kd == K_CT;
@@ -685,6 +687,7 @@ template <class B> struct Core {
         });
         Adiag[S] = Al[symidx(CAP, S, S)] + (ut[S][0] * ut[S][0] + ut[S][1] * ut[S][1] + ut[S][2] * ut[S][2]);
         Ainv[S] = B::rcp(Adiag[S]);
+        if constexpr (S < 2) Adiag[S] = 0.5 * Adiag[S];   // a connect row's step only ever uses A_ii / 2 (the change of cost): halved here, once, exactly
         // warm start (mj_constraintUpdate from qacc_warmstart) of a single row; of a contact pair when its tangent row is complete
         const D Dd_ = B::rcp(Rr);
         D fv = 0.0;
@@ -700,8 +703,9 @@ template <class B> struct Core {
           const M bot = (mu * Nn + Tt <= 0.0) | ((Tt <= 0.0) & (Nn < 0.0));
           // middle zone: each row with its own D, as mj_constraintUpdate does (the two are equal: the pair shares its regulariser)
           const D NmT = Nn - mu * Tt;
-          const D fnm_n = -(Dn_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
-          const D fnm_t = -(Dd_ / (mu * mu * (1.0 + mu * mu))) * NmT * mu;
+          const D inv_cone = 1.0 / (mu * mu * (1.0 + mu * mu));   // (a constant of the model: the two divisions of mj_constraintUpdate's middle zone as multiplications)
+          const D fnm_n = -(Dn_ * inv_cone) * NmT * mu;
+          const D fnm_t = -(Dd_ * inv_cone) * NmT * mu;
           const D ftm = -fnm_t / Tt * U1 * mu;
           const D fn = B::sel(top, D(0.0), B::sel(bot, -Dn_ * jn, fnm_n));
           const D ft = B::sel(top, D(0.0), B::sel(bot, -Dd_ * jt, ftm));
@@ -784,7 +788,7 @@ template <class B> struct Core {
         const M mine = owner & sweeping & (kind[S] == K_EQ);
         const D res = B::fma(ut[S][2], a2, B::fma(ut[S][1], a1, B::fma(ut[S][0], a0, r[S])));
         D d = -(res * Ainv[S]);
-        D chg = d * B::fma(0.5 * Adiag[S], d, res);
+        D chg = d * B::fma(Adiag[S], d, res);   // (Adiag of a connect row holds A_ii / 2)
         d = B::sel(mine, d, D(0.0)); chg = B::sel(mine, chg, D(0.0));
         a0 = B::fma(ut[S][0], d, a0); a1 = B::fma(ut[S][1], d, a1); a2 = B::fma(ut[S][2], d, a2);
         acc = acc + chg;
