@@ -399,10 +399,9 @@ template <class B> struct Duo : Core<B> {
           lds.mark(15);   // 15 = state in, before the set-up (sub_setup's own marks: 1 kinematics .. 5 rows)
           Sub S;
           SubOut so;
-          C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf);
+          C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf, []() {}, []() {});   // (this backend: no split tail, nothing to do inside)
           ovf_ = so.overflow;
           B::fence();
-          lds.mark(6);    // 6 = warm start
           if (S.small) {
             join_ = true;
             put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);

@@ -50,6 +50,7 @@ struct DuoShared {
 static_assert(sizeof(DuoShared) == 39168, "LDS budget of four wavefronts per CU");
 
 struct DevDuoB : DevB {
+  static constexpr bool SPLIT_TAIL = false;
   // per-wavefront workspace in global memory (Duo::W_*): [slot][lane], the lane's pointer is the base of its column
   // Buffer addressing: one resource descriptor per wavefront (SGPRs), the lane's byte offset in ONE VGPR, the slot as the scalar offset
   // of the instruction -- so a slot costs an s_mov, not a 64-bit per-lane pointer (with plain pointers the compiler materialises one

@@ -23,6 +23,7 @@ namespace cassie {
 namespace leg {
 
 struct DevB {
+  static constexpr bool SPLIT_TAIL = true;   // sub_setup: a wavefront on its feet does not build its two empty row slots (cassie_leg_core.h)
   typedef double D;
   typedef int I;
   typedef bool M;

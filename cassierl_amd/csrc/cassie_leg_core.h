@@ -392,8 +392,10 @@ template <class B> struct Core {
     I niter;
   };
 
-  template <int MODE, bool HF = false>
-  static LEG_FN void sub_setup(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, Sub& s, const Terrain* hf = nullptr) {
+  // on_small() / on_general(): what the caller does with the rows, called at the END of the set-up inside the branch that built them (six slots /
+  // eight): the two cases never meet again before their rows are consumed, so nothing of a row has to survive a merge of the two paths.
+  template <int MODE, bool HF = false, class FS, class FG>
+  static LEG_FN void sub_setup(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, Sub& s, const Terrain* hf, FS&& on_small, FG&& on_general) {
     // Model constants are re-read from the constant tables in every substep through indices the optimiser cannot see through
     // (B::opq / B::zs): otherwise it hoists ~200 loop-invariant table values out of the substep loop and then spills them
     // (the same trap as in cassie_kernels.hip, r01 PMC: scratch traffic at every kernel boundary).
@@ -569,7 +571,7 @@ template <class B> struct Core {
       D bvec[CAP], z[CAP][5];
       D jar_prev = 0.0, Rr_prev = 1.0;   // the normal row's values while its tangent row is built
       const D mu = CP_CONTACT_MU;
-      lfor<0, CAP>([&](auto ss) {
+      auto build_slot = [&](auto ss) {
         constexpr int S = decltype(ss)::value;
         D pos = 0.0, invw = 0.0;
         D jb[3], jl[5];
@@ -715,29 +717,63 @@ template <class B> struct Core {
         }
         jar_prev = jar; Rr_prev = Rr;
         B::fence();   // keep the scheduler from interleaving the slots (longer live ranges -> spills)
-      });
-      B::fence();
-      lds.mark(5);
-      D at[3] = {D(0.0), D(0.0), D(0.0)};
-      lfor<0, CAP>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
-      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
-      D cost = 0.0;
-      lfor<0, CAP>([&](auto ii) {
-        constexpr int Ii = decltype(ii)::value;
-        D a = 0.0;
-        lfor<0, CAP>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += Al[symidx(CAP, Ii, Jj)] * f[Jj]; });
-        r[Ii] = a;   // own-leg part of (A f)_i, R included
-        const D full = a + (ut[Ii][0] * at[0] + ut[Ii][1] * at[1] + ut[Ii][2] * at[2]);
-        cost += f[Ii] * (0.5 * full + bvec[Ii]);
-      });
-      cost = cost + B::swap(cost);
-      const M drop = cost > 0.0;
-      lfor<0, CAP>([&](auto ss) {
-        constexpr int S = decltype(ss)::value;
-        f[S] = B::sel(drop, D(0.0), f[S]);
-        r[S] = B::sel(drop, D(0.0), r[S]) + bvec[S];
-      });
-      a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
+      };
+      lfor<0, 6>([&](auto ss) { build_slot(ss); });
+      // warm start of NS slots: a~, the own-leg part of A f, the cost of the warm start (kept only if negative)
+      auto warm_start = [&](auto ns_) {
+        constexpr int NS = decltype(ns_)::value;
+        D at[3] = {D(0.0), D(0.0), D(0.0)};
+        lfor<0, NS>([&](auto ss) { constexpr int S = decltype(ss)::value; lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] += ut[S][Bc] * f[S]; }); });
+        lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = at[Bc] + B::swap(at[Bc]); });
+        D cost = 0.0;
+        lfor<0, NS>([&](auto ii) {
+          constexpr int Ii = decltype(ii)::value;
+          D a = 0.0;
+          lfor<0, NS>([&](auto jj) { constexpr int Jj = decltype(jj)::value; a += Al[symidx(CAP, Ii, Jj)] * f[Jj]; });
+          r[Ii] = a;   // own-leg part of (A f)_i, R included
+          const D full = a + (ut[Ii][0] * at[0] + ut[Ii][1] * at[1] + ut[Ii][2] * at[2]);
+          cost += f[Ii] * (0.5 * full + bvec[Ii]);
+        });
+        cost = cost + B::swap(cost);
+        const M drop = cost > 0.0;
+        lfor<0, NS>([&](auto ss) {
+          constexpr int S = decltype(ss)::value;
+          f[S] = B::sel(drop, D(0.0), f[S]);
+          r[S] = B::sel(drop, D(0.0), r[S]) + bvec[S];
+        });
+        a0 = B::sel(drop, D(0.0), at[0]); a1 = B::sel(drop, D(0.0), at[1]); a2 = B::sel(drop, D(0.0), at[2]);
+      };
+      // Slots 6 and 7 of a wavefront on its feet (`small`: no joint limit, at most two pairs per leg, in EVERY environment) are empty in
+      // every lane: they are not built (r05: ~760 of the ~3000 instructions of this phase built exactly zeros and a unit diagonal), and the
+      // warm start runs over six slots -- the two left-out slots would add exact zeros to every sum.  Nothing reads their rows in that
+      // case (six-row sweeps); the finish reads their kind and force.
+      if constexpr (!B::SPLIT_TAIL) {
+        // (the 64-environments kernel: its set-up sits in a loop over the two groups with the eight-row solve inline behind it, and the branch
+        // here cost it 75 more spills -- 1.01 -> 1.08 ms per step -- where the two-lanes kernel gained 7 %: it builds the two empty slots)
+        build_slot(LI<6>{}); build_slot(LI<7>{});
+        B::fence();
+        lds.mark(5);
+        warm_start(LI<CAP>{});
+        B::fence();
+        lds.mark(6);
+        if (small) on_small(); else on_general();
+      } else if (small) {
+        B::fence();
+        lds.mark(5);
+        warm_start(LI<6>{});
+        kind[6] = K_NONE; kind[7] = K_NONE; f[6] = 0.0; f[7] = 0.0; r[6] = 0.0; r[7] = 0.0;
+        B::fence();
+        lds.mark(6);
+        on_small();
+      } else {
+        build_slot(LI<6>{}); build_slot(LI<7>{});
+        B::fence();
+        lds.mark(5);
+        warm_start(LI<CAP>{});
+        B::fence();
+        lds.mark(6);
+        on_general();
+      }
     }
   }
 
@@ -1017,10 +1053,8 @@ template <class B> struct Core {
   template <int MODE, bool HF = false>
   static LEG_FN void substep(typename B::Lds& lds, Lane& st, bool from_rec, M live, bool integrate, SubOut& out, const Terrain* hf = nullptr) {
     Sub s;
-    sub_setup<MODE, HF>(lds, st, from_rec, live, integrate, out, s, hf);
-    B::fence();
-    lds.mark(6);
-    sub_sweeps(s);
+    auto solve = [&]() { sub_sweeps(s); };   // (inside the branch of the set-up that knows `small`: the six- or the eight-row sweeps)
+    sub_setup<MODE, HF>(lds, st, from_rec, live, integrate, out, s, hf, solve, solve);
     out.niter = s.niter;
     B::fence();
     lds.mark(7);

@@ -71,6 +71,7 @@ inline vin lane_swap_idx() { vin r; LANES r[l] = l ^ 1; return r; }
 template <int W> inline vin lane_bcast_idx() { vin r; LANES r[l] = (l & ~1) | W; return r; }
 
 struct HostOps {
+  static constexpr bool SPLIT_TAIL = true;   // (cassie_leg_core.h: sub_setup; the duo emulation says false, as the device backends do)
   typedef VD D;
   typedef VI I;
   typedef VM M;

@@ -79,6 +79,7 @@ typedef cassie::leg::Core<HostBHF> HCoreHF;
 // environments of group A and NL / 2 of group B; in the joint sweep every lane holds one environment.  The cold slots are routed as on the
 // device: setState snapshot / qstate / motor commands to the record, the action from its row, the rest to per-group arrays.
 struct HostDuoB : HostB {
+  static constexpr bool SPLIT_TAIL = false;
   struct W { double (*p)[NL]; };
   static VD wld(W ws, int slot) { VD r; LANES r.v[l] = ws.p[slot][l]; return r; }
   static void wst(W ws, int slot, VD v) { LANES ws.p[slot][l] = v.v[l]; }
