@@ -46,6 +46,7 @@ BENCH_SCHEMA = "r05 (roofline: fp64_valu useful flops, hbm sub-object; cpu_basel
 PREROLL_STEPS_AT_64K = int(os.environ.get("CASSIE_BENCH_PREROLL_STEPS", "300"))     # untimed Env.steps before the timed region at 65 536 envs, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+USEFUL_FLOP_R04 = 300434.4270833333   # profiles/r04_n: counted useful FP64 per env-step of the bench workload as the source stood in rounds 3-4
 FP64_VALU_PEAK_TFLOPS = 78.6         # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
@@ -588,6 +589,9 @@ def roofline_object(n_local, kernel_ms, dominant, pmc):
             "frac": None if ach is None else ach / FP64_VALU_PEAK_TFLOPS, "traffic": pmc.get("hbm_bytes_per_launch"),
             "kernel": dominant + " (+ its hand-over passes)", "kernel_ms": kernel_ms,
             "useful_flop_per_env_step": useful,
+            # the same launch time priced with the count of rounds 3-4 (0.3004 Mflop per env-step: before the structurally zero Jacobian terms, the
+            # halved connect diagonals and the two empty row slots left the counted source) -- the figure comparable with earlier rounds' `frac`
+            "frac_with_r04_count": USEFUL_FLOP_R04 * n_local / sec / 1e12 / FP64_VALU_PEAK_TFLOPS, "useful_flop_per_env_step_r04": USEFUL_FLOP_R04,
             "issued": None if not issued else {"achieved": issued * n_local / sec / 1e12, "frac": issued * n_local / sec / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                                "flop_per_env_step": issued, "source": pmc.get("source")},
             "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_gbps / HBM_PEAK_GBPS,
