@@ -132,7 +132,63 @@ def _build_locked(force, verbose, only):
     return LIB
 
 
+VARDIR = os.path.join(LIBDIR, "variants")
+
+
+def variant_path(name):
+    return os.path.join(VARDIR, "libcassie2d_%s.so" % name)
+
+
+def build_variant(name, units, extra_flags, verbose=False):
+    """A second build of the library in which the translation units `units` are compiled with `extra_flags` ON TOP of the regular flags
+    (FLAGS + UNIT_FLAGS: the contraction mode the bit-identity between kernels depends on stays what the shipped build uses) and every other
+    unit is the regular build's object: lib/variants/libcassie2d_<name>.so, loaded through CASSIE2D_LIB.  Used by the A/B scripts under
+    profiles/tools and by the auto-var-init guard builds (tests/test_gpu_build_guard.py).  Content-stamped like the main library."""
+    build()
+    os.makedirs(VARDIR, exist_ok=True)
+    out = variant_path(name)
+    stamp = out + ".stamp"
+    ident = _flags_id() + "\n" + _tree_hash() + "\n" + " ".join(units) + " | " + " ".join(extra_flags)
+    try:
+        if os.path.exists(out) and open(stamp).read() == ident:
+            return out
+    except OSError:
+        pass
+
+    def compile_one(u):
+        obj = os.path.join(VARDIR, "%s_%s.o" % (u, name))
+        cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(u, []) + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        mine = list(ex.map(compile_one, units))
+    objs = [os.path.join(OBJDIR, u + ".o") for u in _units() if u not in units] + mine
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    with open(stamp, "w") as f:
+        f.write(ident)
+    return out
+
+
+# Guard builds (VERDICT r5 item 1): the units of the 64-environments-per-wavefront kernel with every automatic variable pre-set to a byte pattern /
+# to zero.  A read of an undefined value in device code -- or a register-allocation accident of this 512-register kernel -- shows up as a
+# difference between these builds and the shipped one (tests/test_gpu_build_guard.py compares them bit for bit on the GPU).
+GUARD_UNITS = ["tu_duo", "tu_duo_hf"]
+GUARD_VARIANTS = {"avi_pattern": ["-ftrivial-auto-var-init=pattern"], "avi_zero": ["-ftrivial-auto-var-init=zero"]}
+
+
+def build_guards(verbose=False):
+    return [build_variant(n, GUARD_UNITS, f, verbose) for n, f in sorted(GUARD_VARIANTS.items())]
+
+
 if __name__ == "__main__":
     import sys
-    only = sys.argv[1:] or None
-    print(build(force=only is None, verbose=True, only=only))
+    if sys.argv[1:2] == ["--variant"]:   # python -m cassierl_amd.build --variant <name> "<unit> <unit>" <flags...>
+        print(build_variant(sys.argv[2], sys.argv[3].split(), sys.argv[4:], verbose=True))
+    elif sys.argv[1:2] == ["--guards"]:
+        print("\n".join(build_guards(verbose=True)))
+    else:
+        only = sys.argv[1:] or None
+        print(build(force=only is None, verbose=True, only=only))

@@ -44,6 +44,9 @@ struct CassieVec {
   int* pending_leg = nullptr;                // substeps left per env after the two-lanes-per-env kernel (input of the 4-envs-per-wave kernel)
   bool leg = true;                           // first tier = the two-lanes-per-environment kernel (CASSIE2D_LEG=0/1 overrides the size rule)
   double* duo_ws = nullptr;                  // workspace of the 64-environments-per-wavefront kernel (L2::duo_workspace_bytes)
+  int duo_table = 0;                         // claim-table slots of its workspace (L2::duo_table_slots; 0: one slot per task).  CASSIE2D_DUO_TABLE=<slots> forces a table (tests)
+  bool duo_flat_hint = false;                // CASSIE2D_DUO_FLAT_HINT=1 (tests): every wavefront's first probe is word 0
+  size_t duo_ws_bytes = 0;
   bool duo = false;                          // ... in its 64-environments-per-wavefront form (cassie_kernels_duo.hip; CASSIE2D_DUO=0/1 overrides the size rule)
   unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
   unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
@@ -226,7 +229,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (side_by_side) {
-    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
     L2::classify_pending(h->n, h->stream, p, h->pending_leg);
     const bool forked = hipEventRecord(h->ev_fork, h->stream) == hipSuccess && hipStreamWaitEvent(h->side, h->ev_fork, 0) == hipSuccess;
     if (forked) {
@@ -250,7 +253,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (h->leg) {
-    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16(mode, h->n, h->stream, p2, h->pending);
@@ -261,7 +264,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
 void launch_physics_tiers_hf(CassieVec* h, int mode, const cassie::VecParams& p) {
   cassie::VecParams p2 = p, p3 = p;
   if (h->leg) {
-    if (h->duo) L2::step_duo_hf(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws); else L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
+    if (h->duo) L2::step_duo_hf(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16_hf(mode, h->n, h->stream, p2, h->pending);
@@ -408,11 +411,11 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (h->cfg.flags & CASSIE_LEG_TIER_ON) h->leg = h->g16;
   // the joint-sweep form of that tier (64 environments per wavefront) where the batch fills the chip with it: one wavefront per SIMD is
   // 65 536 environments; below DUO_MIN_ENVS the 32-environment wavefronts of the pair form finish earlier (twice as many SIMDs busy)
+  int simds = 1024;
   {
     // both forms run one wavefront per SIMD, so a launch takes whole ROUNDS of the chip's SIMDs: per round the pair form's wavefront
     // (32 environments) lives ~0.65 ms, the joint form's (64 environments) ~1.05 ms (r05, MI355X).  65 536 envs: 2 x 0.65 against 1 x 1.05;
     // 32 768: one round either way, the pair form's is shorter; 98 304: 3 x 0.65 against 2 x 1.05.
-    int simds = 1024;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
     const int rounds_pair = ((n_envs + 31) / 32 + simds - 1) / simds, rounds_joint = ((n_envs + 63) / 64 + simds - 1) / simds;
@@ -421,7 +424,14 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   { const char* e = getenv("CASSIE2D_DUO"); if (e && (e[0] == '0' || e[0] == '1')) h->duo = h->leg && e[0] == '1'; }
   if (h->cfg.flags & CASSIE_DUO_TIER_OFF) h->duo = false;
   if (h->cfg.flags & CASSIE_DUO_TIER_ON) h->duo = h->leg;
-  if (h->duo && hipMalloc(&h->duo_ws, L2::duo_workspace_bytes(n_envs)) != hipSuccess) return bail(CASSIE_EHIP);
+  if (h->duo) {
+    h->duo_table = L2::duo_table_slots(n_envs, simds);
+    { const char* e = getenv("CASSIE2D_DUO_TABLE"); if (e && atoi(e) >= 2) { int t = 2; while (t < atoi(e)) t *= 2; h->duo_table = t; } }   // tests: a small batch through the claim path
+    { const char* e = getenv("CASSIE2D_DUO_FLAT_HINT"); h->duo_flat_hint = e && e[0] == '1'; }
+    h->duo_ws_bytes = L2::duo_workspace_bytes(n_envs, h->duo_table);
+    if (hipMalloc(&h->duo_ws, h->duo_ws_bytes) != hipSuccess) return bail(CASSIE_EHIP);
+    if (hipMemset(h->duo_ws, 0, h->duo_ws_bytes) != hipSuccess) return bail(CASSIE_EHIP);
+  }
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_SIDE_BY_SIDE"); if (e && (e[0] == '0' || e[0] == '1')) h->side_mode = e[0] - '0'; }
@@ -488,6 +498,21 @@ int CassieVecGetCounters(CassieVec* h, uint64_t* out4) {
   out4[1] = host[cassie::STAT_CLEANUP_SUBSTEPS];
   out4[2] = host[cassie::STAT_K1_SUBSTEPS];
   out4[3] = host[cassie::STAT_NONFINITE];
+  return CASSIE_OK;
+}
+
+int CassieVecTierInfo(CassieVec* h, uint64_t* out8) {
+  if (!h || !out8) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  unsigned long long host[cassie::STAT_N];
+  HIPCHK(h, hipMemcpyAsync(host, h->stats, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out8[0] = !h->g16 ? 0 : !h->leg ? 1 : !h->duo ? 2 : 3;
+  out8[1] = (uint64_t)h->duo_table;
+  out8[2] = (uint64_t)h->duo_ws_bytes;
+  out8[3] = host[cassie::STAT_WS_PROBES];
+  out8[4] = h->pend_rate;
+  out8[5] = out8[6] = out8[7] = 0;
   return CASSIE_OK;
 }
 

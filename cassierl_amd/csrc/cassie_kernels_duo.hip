@@ -155,11 +155,63 @@ typedef Duo<DevDuoB> DDuo;
 static_assert(DDuo::C::C_TIME == 24 && DDuo::C::C_A2 == 28 && DDuo::C::C_TAUB == 29 && DDuo::C::C_OX == 37 && DDuo::C::C_OZ == 43 && DDuo::C::C_N == 49 &&
               DDuo::C::C_KQ == 0 && DDuo::C::C_KV == 8 && DDuo::C::C_QST == 16 && DDuo::C::C_CTRL == 21 && DDuo::C::C_ACT == 25, "DuoLds routes these slot numbers");
 
-// MODE: 0 PD, 1 torque, 2 motor commands from the state record.  pending[env] as env_step_leg_kernel.  workspace: duo_workspace_doubles(n)
-// doubles (W_N slots x 64 lanes per wavefront; contents only live inside one launch).
+// MODE: 0 PD, 1 torque, 2 motor commands from the state record.  pending[env] as env_step_leg_kernel.  workspace: W_N slots x 64 lanes per
+// wavefront SLOT (launch::duo_workspace_bytes; contents only live inside one task of one launch).
 constexpr size_t duo_workspace_doubles_per_wave = (size_t)(DDuo::W_N + DUO_WS_PAD) * 64;
+// THE WORKSPACE IS A PROPERTY OF THE CHIP, NOT OF THE BATCH (r06).  One wavefront of this kernel owns a SIMD (512 registers), so at most
+// 4 x CUs wavefronts exist at any time, however many the launch has.  A batch of up to DuoSlots::DIRECT_MAX tasks (one round of an MI355X,
+// the headline's 65 536 envs) indexes the workspace by its task number, as r05 did.  A larger batch CLAIMS a slot per wavefront from a table
+// of `mask + 1` busy words (a power of two >= 2 x the chip's SIMDs, one eighth of it per XCD): the first probe is a hash of the wavefront's physical place
+// (XCC, SE, CU, SIMD from HW_REG_XCC_ID / HW_REG_HW_ID) -- two resident wavefronts of this kernel cannot share a SIMD, so the probe finds its
+// word free and the same SIMD comes back to the same 139 KB, launch after launch: 143 MB touched on an MI355X for any batch, Infinity-Cache
+// resident (r05 indexed by the task: 1.14 GB at 524 288 envs).  The place is only a HINT: the claim is an atomic compare-and-swap with linear
+// probing, so a collision (another hash layout, a future part, the test mode that zeroes the hint) costs probes (STAT_WS_PROBES), never a
+// result.  The hardware's dispatcher stays the task queue: a wavefront that lost the arbitration for the fabric (-7..+10 % lifetime spread,
+// profiles/r05_phase_duo.txt) simply frees its SIMD later, and the next workgroup goes where a SIMD is free.
+// (Built and measured first as a persistent grid pulling tasks from a counter: the task loop around the body cost 68 B more scratch per lane
+// and +1.5 % at every batch size, profiles/r06_size_sweep.jsonl.)
+struct DuoSlots {
+  static constexpr int DIRECT_MAX = 1024;   // tasks up to which the workspace is indexed by the task (host: cassie_cabi.hip sizes it)
+  unsigned* busy;      // null: slot = task
+  unsigned mask;       // table size - 1
+  unsigned flat_hint;  // tests: every wavefront starts probing at word 0
+  __device__ __forceinline__ int claim(int lane, int task, unsigned long long* stats) const {
+    if (!busy) return task;
+    unsigned h = 0;
+    if (lane == 0) {
+      // HW_REG_HW_ID (4): WAVE_ID [3:0], SIMD_ID [5:4], PIPE_ID [7:6], CU_ID [11:8], SH_ID [12], SE_ID [15:13]; HW_REG_XCC_ID (20): XCC_ID [3:0]
+      // (s_getreg operand: size - 1 << 11 | offset << 6 | register).  MI355X census (profiles/tools/hwid_census.hip, profiles/r06_hwid_census.txt):
+      // XCC 0..7, SE 0..3, SH 0, CU 0..8, SIMD 0..3 -- 1152 places, 1024 of them active; key = xcc:3 | se:2 | cu:4 | simd:2 is injective there
+      // (2048 words).  Bits a larger part might use (SE bit 2, SH, XCC bit 3) are folded in: they can only cost probes.
+      const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+      const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+      const unsigned simd = (hw >> 4) & 3u, cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+      // The table is PARTITIONED BY XCD (xcc in the top three bits of the word index, probing wraps inside the partition): a slot is only ever
+      // re-used by wavefronts of one XCD, i.e. through one L2 -- the per-XCD L2s are not coherent with each other inside a launch, and a slot
+      // that moved between XCDs would need its old owner's dirty lines written back first (an agent-scope release = buffer_wbl2 of the whole
+      // L2: measured, 5 % of the launch at 131 072 envs).
+      const unsigned part = (mask + 1u) >> 3, pm = part - 1u;
+      const unsigned base = (xcc & 7u) * part;
+      unsigned k = flat_hint ? 0u : ((se & 3u) << 6 | cu << 2 | simd) + 37u * (sh + 2u * (se >> 2) + 4u * (xcc >> 3));
+      unsigned probes = 0;
+      while (atomicCAS(busy + base + (k & pm), 0u, 1u) != 0u) { k++; probes++; }
+      h = base + (k & pm);
+      if (probes && stats) atomicAdd(stats + STAT_WS_PROBES, (unsigned long long)probes);
+    }
+    return __builtin_amdgcn_readfirstlane((int)h);
+  }
+  __device__ __forceinline__ void release(int lane, int slot) const {
+    // every store of this task to the workspace has reached the L2 (vmcnt counts stores until they are acknowledged) before the word is freed;
+    // the next owner is a wavefront of the same XCD (see claim), so no write-back of the L2 is needed: a relaxed store
+    if (busy) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+      if (lane == 0) __hip_atomic_store(busy + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+};
+
 template <int MODE>
-__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace) {
+__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecParams p, int* pending, double* workspace, DuoSlots sl) {
 #if DUO_WAVES == 1
   __shared__ DuoShared sh;
   const int lane = threadIdx.x;
@@ -215,13 +267,15 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_kernel(VecPara
 #endif
   DDuo::Out o[2];
   DevDuoB::W ws;   // raw buffer over this wavefront's W_N x 512 bytes (word 3: 32-bit data format, gfx9 encoding)
-  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * duo_workspace_doubles_per_wave, 0, DDuo::W_N * 512, 0x00020000);
+  const int slot = sl.claim(lane, wave_id, p.stats);
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)slot * duo_workspace_doubles_per_wave, 0, DDuo::W_N * 512, 0x00020000);
   ws.voff = (unsigned)lane * 16u;
 #ifdef CASSIE_PHASE_TIMING
   for (int i = 0; i < 16; i++) lds.acc[i] = 0;
   lds.t_last = __builtin_readcyclecounter();
 #endif
   DDuo::env_step2<MODE>(cfg, lds, ws, io_of, valid, o);
+  sl.release(lane, slot);   // (the write-back at the end of env_step2 has consumed its loads from the workspace: they fed its stores to the records)
 #ifdef CASSIE_PHASE_TIMING
   lds.mark(0);
   if (lane == 0 && p.phase) for (int i = 0; i < 16; i++) atomicAdd(p.phase + i, lds.acc[i]);
@@ -272,7 +326,7 @@ typedef Duo<DevDuoBHF> DDuoHF;
 static_assert(DDuoHF::W_N == DDuo::W_N, "one workspace size for both instantiations");
 
 template <int MODE>
-__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_hf_kernel(VecParams p, int* pending, double* workspace) {
+__global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_hf_kernel(VecParams p, int* pending, double* workspace, DuoSlots sl) {
 #if DUO_WAVES == 1
   __shared__ DuoSharedHF sh;
   const int lane = threadIdx.x;
@@ -314,10 +368,12 @@ __global__ void __launch_bounds__(64 * DUO_WAVES, 1) env_step_duo_hf_kernel(VecP
   lds.lo = (lane & 1) * 5 + 3; lds.ao = (lane & 1) * 3;
   lds.a2[0] = 0.0; lds.a2[1] = 0.0;
   DevDuoBHF::W ws;
-  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)wave_id * duo_workspace_doubles_per_wave, 0, DDuoHF::W_N * 512, 0x00020000);
+  const int slot = sl.claim(lane, wave_id, p.stats);   // (as env_step_duo_kernel)
+  ws.r = __builtin_amdgcn_make_buffer_rsrc(workspace + (size_t)slot * duo_workspace_doubles_per_wave, 0, DDuoHF::W_N * 512, 0x00020000);
   ws.voff = (unsigned)lane * 16u;
   DDuoHF::Out o[2];
   DDuoHF::env_step2<MODE, true>(cfg, lds, ws, io_of, valid, o, &p.hf);
+  sl.release(lane, slot);
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     if (valid[g] && (lane & 1) == 0) {

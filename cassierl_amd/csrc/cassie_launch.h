@@ -35,9 +35,13 @@ void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tu_duo.hip: the same tier with 64 environments per wavefront (two groups set up lane-per-leg, one joint sweep with a lane per
 // environment; cassie_duo_core.h): bit-identical results, same hand-over through `pending`
-void step_duo(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace);
-void step_duo_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace);   // tu_duo_hf.hip: ... on the height field (p.hf)
-size_t duo_workspace_bytes(int n_envs);   // per handle: what group A of a wavefront hands from its set-up to the joint sweep and its finish, and group B's state
+// workspace: per wavefront SLOT.  table_slots == 0: slot = task (batches of up to one round of the chip); else every wavefront claims a slot from a
+// table of table_slots busy words behind the workspaces, first probe = hash of its physical place (DuoSlots, cassie_kernels_duo.hip): the
+// workspace is sized by the chip, not by the batch.  flat_hint (tests): every wavefront starts probing at word 0.
+void step_duo(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace, int table_slots, bool flat_hint);
+void step_duo_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace, int table_slots, bool flat_hint);   // tu_duo_hf.hip: ... on the height field (p.hf)
+int duo_table_slots(int n_envs, int simds);                  // 0 up to 1024 tasks, else a power of two >= 2 x simds
+size_t duo_workspace_bytes(int n_envs, int table_slots);     // workspaces + claim table; to be zeroed once by the owner
 // ... for a SEGMENT of the Env.step's substeps (p.n_sub = its length; `later` = substeps of the segments behind it; gone[env]: the
 // environment left this tier in an earlier segment; see env_step_leg_seg_kernel)
 void step_leg_segment(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, int* gone, bool first, int later);

@@ -43,7 +43,8 @@ inline int pending_count(int v, int pick) {
 //   STAT_CLEANUP_SUBSTEPS  env-substeps the packed fast-path kernels handed to a slower general kernel (any tier)
 //   STAT_K1_SUBSTEPS       ... of those, env-substeps that went all the way to the wave-per-environment kernel
 //   STAT_NONFINITE         environments whose state left the finite range (|q|,|v| <= 1e10, NaN) and were force-terminated
-enum { STAT_CLEANUP_SUBSTEPS = 0, STAT_K1_SUBSTEPS = 1, STAT_NONFINITE = 2, STAT_N = 4 };
+//   STAT_WS_PROBES         extra probes of the 64-environments kernel's workspace claims (DuoSlots::claim): 0 while the physical-place hash is collision-free
+enum { STAT_CLEANUP_SUBSTEPS = 0, STAT_K1_SUBSTEPS = 1, STAT_NONFINITE = 2, STAT_WS_PROBES = 3, STAT_N = 4 };
 constexpr double FINITE_BOUND = 1e10;  // mjMAXVAL of MuJoCo's mj_checkPos / mj_checkVel
 
 // Height-field terrain (rllab/envs/terrain_random.py): heights in metres, [nrow][ncol] row-major in HBM

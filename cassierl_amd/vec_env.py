@@ -16,7 +16,7 @@ CONTROL_MODES = {"PD": 0, "Torque": 1, "OSC": 2, "Jacobian": 3}
 ENV_KINDS = {"walk": 0, "stand": 1}
 FIX_STALE_KIN, FIX_STALE_QSTATE, WAVE_PER_ENV, NO_PINV_SHORTCUT = 1, 2, 4, 8  # 8: tests only (literal SVD route)
 LEG_TIER_OFF, LEG_TIER_ON = 16, 32  # first kernel tier: never / always the two-lanes-per-environment kernel (default: by batch size)
-DUO_TIER_OFF, DUO_TIER_ON = 64, 128  # ... never / always in its 64-environments-per-wavefront form (default: from 49 152 envs)
+DUO_TIER_OFF, DUO_TIER_ON = 64, 128  # ... never / always in its 64-environments-per-wavefront form (default: above 32 768 envs where it saves whole rounds of the chip's SIMDs: CassieVecCreate; `tier_info()` says what was chosen)
 STATE_STRIDE = 88
 
 
@@ -111,6 +111,16 @@ class CassieVecEnv:
         req, cleanup, k1, bad = (int(x) for x in out)
         return dict(substeps=req, cleanup_substeps=cleanup, k1_substeps=k1, nonfinite_resets=bad,
                     cleanup_frac=(cleanup / req if req else 0.0), k1_frac=(k1 / req if req else 0.0))
+
+    TIERS = ("wave_per_env", "g16", "leg", "duo")
+
+    def tier_info(self):
+        """First physics tier the library chose for this handle (by batch size, flags, environment overrides) and the state of the
+        64-environments kernel's hand-over workspace: claim-table slots (0 = one slot per task), bytes, extra claim probes so far."""
+        out = (ct.c_uint64 * 8)()
+        self._chk(self.L.CassieVecTierInfo(self.h, out))
+        return dict(first_tier=self.TIERS[int(out[0])], duo_table_slots=int(out[1]), duo_workspace_bytes=int(out[2]), ws_probes=int(out[3]),
+                    handovers_per_launch=int(out[4]))
 
     def reset_counters(self):
         self._chk(self.L.CassieVecResetCounters(self.h))

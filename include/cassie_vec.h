@@ -81,6 +81,15 @@ int CassieVecSynchronize(CassieVec* h);
 int CassieVecGetCounters(CassieVec* h, uint64_t* out4);
 int CassieVecResetCounters(CassieVec* h);
 
+/* Which kernel tier this handle runs first, and the state of its hand-over workspace (diagnostics; bench.py labels its roofline with it):
+ *   out8[0] first physics tier: 0 one wavefront per environment, 1 four environments per wavefront, 2 two lanes per environment
+ *           (env_step_leg_kernel), 3 64 environments per wavefront (env_step_duo_kernel) -- chosen at create by batch size / flags / environment
+ *   out8[1] claim-table slots of the 64-environments kernel's workspace (0: one slot per 64-environment task, batches of up to one round of the chip)
+ *   out8[2] bytes of that workspace
+ *   out8[3] extra probes of its workspace claims since create / CassieVecResetCounters (0 while the physical-place hash is collision-free)
+ *   out8[4] hand-overs per launch, as the segment scheduler currently estimates them;  out8[5..7] reserved (0) */
+int CassieVecTierInfo(CassieVec* h, uint64_t* out8);
+
 /* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */
 int CassieVecSetTrajectory(CassieVec* h, const double* time_host, const double* qpos_host, int n);
 

@@ -26,7 +26,7 @@ def vec_tier(request):
     size rule), "leg" = the two-lanes-per-environment kernel (`env_step_leg_kernel`, the kernel behind the bench headline, which
     the size rule only selects from 6144 environments up).  The oracle / golden-stream tests take this fixture so that the
     driver's plain `pytest -m gpu` run pins BOTH against the oracle, whatever the batch size of the test.  "duo" (r05) = that tier in its
-    64-environments-per-wavefront form (`env_step_duo_kernel`: the kernel behind the headline from 49 152 environments up)."""
+    64-environments-per-wavefront form (`env_step_duo_kernel`: the kernel behind the headline: above 32 768 environments where it saves whole rounds of the chip, `CassieVecEnv.tier_info()`)."""
     from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_OFF, LEG_TIER_ON, DUO_TIER_ON, DUO_TIER_OFF
     add = {"leg": LEG_TIER_ON | DUO_TIER_OFF, "duo": LEG_TIER_ON | DUO_TIER_ON, "g16": LEG_TIER_OFF}[request.param]
 

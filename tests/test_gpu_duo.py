@@ -139,3 +139,68 @@ def test_height_field_rollout_is_bit_identical(mode):
     _same(outs[0][1], outs[1][1], "state records")
     assert outs[0][2]["nonfinite_resets"] == outs[1][2]["nonfinite_resets"] == 0
     pair.close(); duo.close()
+
+
+@pytest.mark.parametrize("table,flat", [(2048, False), (128, True), (64, False)])
+def test_workspace_claim_table_is_bit_identical(table, flat, traj, monkeypatch):
+    """r06: batches of more than one round of the chip claim their hand-over workspace per wavefront from a table (DuoSlots, cassie_kernels_duo.hip;
+    first probe = hash of the wavefront's physical place, compare-and-swap + linear probing).  CASSIE2D_DUO_TABLE forces the claim path for a small
+    batch: the chip's own table size (the hash must be collision-free: zero extra probes), a small table with every first probe on word 0 (heavy
+    probing), a table with fewer words than wavefronts (a wavefront waits for a release) -- launch after launch, against the two-lanes kernel."""
+    import torch
+    from cassierl_amd import rollout as R
+    n = 4096 + 45
+    monkeypatch.setenv("CASSIE2D_DUO_TABLE", str(table))
+    if flat:
+        monkeypatch.setenv("CASSIE2D_DUO_FLAT_HINT", "1")
+    pair, duo = _envs(n, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True)
+    info = duo.tier_info()
+    assert info["first_tier"] == "duo" and info["duo_table_slots"] == table and pair.tier_info()["first_tier"] == "leg"
+    ids = torch.arange(n, device="cuda:0")
+    outs = []
+    for env in (pair, duo):
+        env.set_trajectory(traj["time"], traj["qpos"])
+        bufs = env.alloc()
+        env.reset(bufs)
+        rows = []
+        for t in range(12):
+            o, r, d = env.step(R.random_actions(1, ids, t, PD_LO, PD_HI), bufs)
+            rows.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+        outs.append((rows, env.get_full_state_host(), env.counters()))
+    for t, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        _close(a[0], b[0], (t, "obs")); _close(a[1], b[1], (t, "reward")); _same(a[2], b[2], (t, "done"))
+    _same(outs[0][1], outs[1][1], "state records")
+    probes = duo.tier_info()["ws_probes"]
+    if table == 2048:
+        assert probes == 0, "two resident wavefronts hashed to one workspace slot: the physical-place hash is not collision-free on this part"
+    if flat:
+        assert probes > 0
+    pair.close(); duo.close()
+
+
+def test_workspace_claim_table_falling_robots_and_terrain(monkeypatch):
+    """... with robots that fall (eight-row groups, hand-overs to the lower tiers) and on the height field (env_step_duo_hf_kernel)."""
+    import torch
+    from cassierl_amd import rollout as R
+    monkeypatch.setenv("CASSIE2D_DUO_TABLE", "64")
+    monkeypatch.setenv("CASSIE2D_DUO_FLAT_HINT", "1")
+    n = 2048 + 19
+    xs = np.linspace(-10.0, 10.0, 2001)
+    relief = np.tile(0.015 * (1.0 - np.cos(2.0 * np.pi * xs / 1.5)), (64, 1))
+    for hf in (False, True):
+        pair, duo = _envs(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=hf)
+        ids = torch.arange(n, device="cuda:0")
+        outs = []
+        for env in (pair, duo):
+            if hf:
+                env.set_heightfield(relief, 10.0, 10.0)
+            bufs = env.alloc()
+            env.reset(bufs)
+            for t in range(60):
+                o, r, d = env.step(R.random_actions(3, ids, t, -TQ, TQ), bufs)
+            outs.append((o.cpu().numpy().copy(), d.cpu().numpy().copy(), env.get_full_state_host(), env.counters()))
+        _close(outs[0][0], outs[1][0], "obs"); _same(outs[0][1], outs[1][1], "done"); _same(outs[0][2], outs[1][2], "state records")
+        assert outs[0][3]["cleanup_substeps"] == outs[1][3]["cleanup_substeps"]
+        if not hf:
+            assert outs[0][3]["cleanup_substeps"] > 0
+        pair.close(); duo.close()

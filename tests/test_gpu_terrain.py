@@ -27,6 +27,13 @@ def png_field():
     return hm - max(T.height_at(hm, 10, 10, x, y) for x in np.linspace(-0.2, 0.3, 26) for y in (-0.1305, 0.1305)) - 1e-4
 
 
+def _tier_flags(t):
+    """first physics tier of a test id: False = four envs per wavefront, True = wave per env, "leg" = two lanes per env (env_step_leg_hf_kernel),
+    "duo" = 64 envs per wavefront (env_step_duo_hf_kernel: its DIRECT oracle ids, r06)"""
+    from cassierl_amd.vec_env import WAVE_PER_ENV, LEG_TIER_ON, DUO_TIER_ON, DUO_TIER_OFF
+    return {False: 0, True: WAVE_PER_ENV, "leg": LEG_TIER_ON | DUO_TIER_OFF, "duo": LEG_TIER_ON | DUO_TIER_ON}[t]
+
+
 def rel_err(sg, q1, v1):
     return max(np.abs(sg[:13] - q1).max() / np.abs(q1).max(), np.abs(sg[13:26] - v1).max() / (1e-3 + np.abs(v1).max()))
 
@@ -43,7 +50,7 @@ def _oracles(oracle_mod, hm, shifts):
     return os_
 
 
-@pytest.mark.parametrize("wave_per_env", [False, True, "leg"])
+@pytest.mark.parametrize("wave_per_env", [False, True, "leg", "duo"])
 @pytest.mark.parametrize("mode", ["Torque", "PD"])
 def test_ramp_teacher_forced_substeps(vec, oracle_mod, mode, wave_per_env):
     """300 substeps, teacher-forced each step, robots on the flat part, across the kink and on the slope (0.1) of the ramp; each
@@ -53,7 +60,7 @@ def test_ramp_teacher_forced_substeps(vec, oracle_mod, mode, wave_per_env):
     shifts = [(-1.0, 0.0), (0.4, 0.0), (0.45, 0.002), (1.0, 0.05), (2.0, 0.15), (3.3, 0.28)]
     os_ = _oracles(oracle_mod, hm, shifts)
     n = len(os_)
-    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=LEG_TIER_ON if wave_per_env == "leg" else (WAVE_PER_ENV if wave_per_env else 0))
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=_tier_flags(wave_per_env))
     env.set_heightfield(hm, 10.0, 10.0)
     rng = np.random.default_rng(12)
     worst, sloped = 0.0, 0
@@ -74,7 +81,7 @@ def test_ramp_teacher_forced_substeps(vec, oracle_mod, mode, wave_per_env):
     env.close()
 
 
-@pytest.mark.parametrize("leg_tier", [False, True])
+@pytest.mark.parametrize("leg_tier", [False, "leg", "duo"])
 def test_png_terrain_free_running_1000_substeps(vec, oracle_mod, png_field, leg_tier):
     """North-star bar on terrain: 1000 free-running torque-mode substeps on one of the reference's terrain images, 8 robots
     dropped at different x; (qpos, qvel) within 1e-5 relative of the oracle throughout (robots land, tumble, lie on the relief)."""
@@ -83,7 +90,7 @@ def test_png_terrain_free_running_1000_substeps(vec, oracle_mod, png_field, leg_
     os_ = _oracles(oracle_mod, hm, shifts)
     n = len(os_)
     from cassierl_amd.vec_env import LEG_TIER_ON
-    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False, flags=LEG_TIER_ON if leg_tier else 0)
+    env = vec(n, kind="stand", control_mode="Torque", n_substeps=1, auto_reset=False, flags=_tier_flags(leg_tier))
     env.set_heightfield(hm, 10.0, 10.0)
     env.set_full_state_host(np.array([state_vec(*o.state(), o.warmstart()) for o in os_]))
     rng = np.random.default_rng(5)
@@ -106,7 +113,7 @@ def test_png_terrain_free_running_1000_substeps(vec, oracle_mod, png_field, leg_
     env.close()
 
 
-@pytest.mark.parametrize("leg_tier", [False, True])
+@pytest.mark.parametrize("leg_tier", [False, "leg", "duo"])
 def test_env_step_on_terrain_packed_vs_wave_per_env(vec, traj, png_field, leg_tier):
     """Cassie2dEnv.step (stand env, PD and torque) on the terrain: 257 robots spread over 12 m of relief, the packed kernel with
     its hand-over pass against the wave-per-environment kernel, teacher-forced per Env.step; resets land on the terrain too."""
@@ -114,7 +121,7 @@ def test_env_step_on_terrain_packed_vs_wave_per_env(vec, traj, png_field, leg_ti
     hm = png_field
     n = 257
     for mode in ("Torque", "PD"):
-        a = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True, flags=LEG_TIER_ON if leg_tier else 0)
+        a = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True, flags=_tier_flags(leg_tier))
         b = vec(n, kind="stand", control_mode=mode, n_substeps=10, auto_reset=True, flags=WAVE_PER_ENV)
         for e in (a, b):
             e.set_heightfield(hm, 10.0, 10.0)
@@ -183,7 +190,7 @@ def _py_standing_jac(o, zpos, zvel):
     return np.array([fx, fz, my, fx, fz, my])
 
 
-@pytest.mark.parametrize("wave_per_env", [False, True, "leg"])
+@pytest.mark.parametrize("wave_per_env", [False, True, "leg", "duo"])
 @pytest.mark.parametrize("mode", ["OSC", "Jacobian"])
 def test_controllers_step_on_the_ramp_teacher_forced(vec, oracle_mod, mode, wave_per_env):
     """StepOsc / StepJacobian on terrain (rllab/envs/terrain_random.py:51-76 rewrites the MJCF every Step* variant loads,
@@ -195,7 +202,7 @@ def test_controllers_step_on_the_ramp_teacher_forced(vec, oracle_mod, mode, wave
     shifts = [(-1.0, 0.0), (0.4, 0.0), (0.45, 0.002), (1.0, 0.05), (2.0, 0.15), (3.3, 0.28)]
     os_ = _oracles(oracle_mod, hm, shifts)
     n = len(os_)
-    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=LEG_TIER_ON if wave_per_env == "leg" else (WAVE_PER_ENV if wave_per_env else 0))
+    env = vec(n, kind="stand", control_mode=mode, n_substeps=1, auto_reset=False, flags=_tier_flags(wave_per_env))
     env.set_heightfield(hm, 10.0, 10.0)
     worst, worst_u, sloped = 0.0, 0.0, 0
     for t in range(200):
