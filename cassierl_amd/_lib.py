@@ -22,7 +22,7 @@ EXPORTS = [
     "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecTierInfo", "CassieVecSetTrajectory", "CassieVecSetHeightField", "CassieVecReset", "CassieVecResetTo",
     "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
-    "CassieVecDebugSubstepHost", "CassieVecTimeSteps",
+    "CassieVecDebugSubstepHost", "CassieVecDebugWorkspaceHost", "CassieVecTimeSteps",
     # batched Cassie3d physics (include/cassie3d_vec.h)
     "Cassie3dVecCreate", "Cassie3dVecFree", "Cassie3dVecLastError", "Cassie3dVecSetStream", "Cassie3dVecSynchronize",
     "Cassie3dVecReset", "Cassie3dVecStep", "Cassie3dVecStatePtr", "Cassie3dVecGetCounters", "Cassie3dVecResetCounters", "Cassie3dVecStepHost", "Cassie3dVecGetStateHost",
@@ -85,6 +85,8 @@ def load():
     L.CassieVecSetStateHost.argtypes = [vp, dp]
     L.CassieVecGetFullStateHost.argtypes = [vp, dp]
     L.CassieVecDebugSubstepHost.argtypes = [vp, ct.c_int, dp, dp]
+    if hasattr(L, "CassieVecDebugWorkspaceHost"):
+        L.CassieVecDebugWorkspaceHost.argtypes = [vp, dp, ct.c_uint64, ct.POINTER(ct.c_uint64)]
     L.CassieVecTimeSteps.argtypes = [vp, dp, ct.c_int, dp, dp, u8p, ct.POINTER(ct.c_float)]
     L.Cassie3dVecCreate.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, ct.c_int]
     L.Cassie3dVecFree.argtypes = [vp]

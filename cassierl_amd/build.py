@@ -101,6 +101,36 @@ def build(force=False, verbose=False, only=None):
         return _build_locked(force, verbose, only)
 
 
+# ISA guard (cassierl_amd/isa_guard.py): the hipcc of this image (ROCm 7.2.0) can place a live-range split copy of a VECTOR register ahead of the
+# `s_or_b64 exec` of a control-flow join -- the copy then only reaches the lanes that were active inside the divergent region (r06: the
+# auto-var-init=pattern build of env_step_duo_kernel<1>, wrong on the GPU for every robot whose last contact candidate was out of contact).  Every
+# unit is scanned after it is compiled; a unit with a hit is recompiled with flags that move the allocator's split points (each of them gave a
+# clean AND correct build of the affected kernel, profiles/r06_exec_hole.txt) and the library is not linked while any unit has one.
+ISA_RETRY_FLAGS = [["-mllvm", "-amdgpu-opt-exec-mask-pre-ra=0"], ["-mllvm", "-disable-machine-sink"], ["-mllvm", "-disable-machine-licm"]]
+
+
+def _compile_guarded(cmd, obj, verbose, log=None):
+    """Run the compile command; scan the object; retry with ISA_RETRY_FLAGS while the scan finds an exec hole.  Returns the extra flags used."""
+    from . import isa_guard
+    tried = []
+    for extra in [[]] + ISA_RETRY_FLAGS:
+        c = cmd[:1] + extra + cmd[1:]
+        if verbose:
+            print(" ".join(c), flush=True)
+        subprocess.check_call(c, cwd=CSRC)
+        hits = isa_guard.check_object(obj)
+        if not hits:
+            if extra:
+                msg = "isa_guard: %s compiled clean with %s after: %s" % (os.path.basename(obj), " ".join(extra), "; ".join(tried))
+                print(msg, flush=True)
+                if log is not None:
+                    log.append(msg)
+            return extra
+        tried.append("%s -> %d exec hole(s): %s" % (" ".join(extra) or "(regular flags)", len(hits), hits[0][2]))
+    raise RuntimeError("isa_guard: %s still has a vector instruction ahead of an exec restore with every retry flag set:\n%s" %
+                       (obj, "\n".join(tried)))
+
+
 def _build_locked(force, verbose, only):
     if not _stamp_matches():
         force = True   # objects of another flag set: recompile every unit
@@ -114,9 +144,7 @@ def _build_locked(force, verbose, only):
             stale = u in only or not os.path.exists(obj)
         if stale:
             cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(u, []) + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd, cwd=CSRC)
+            _compile_guarded(cmd, obj, verbose)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
@@ -139,16 +167,19 @@ def variant_path(name):
     return os.path.join(VARDIR, "libcassie2d_%s.so" % name)
 
 
-def build_variant(name, units, extra_flags, verbose=False):
+def build_variant(name, units, extra_flags, verbose=False, guarded=True):
     """A second build of the library in which the translation units `units` are compiled with `extra_flags` ON TOP of the regular flags
     (FLAGS + UNIT_FLAGS: the contraction mode the bit-identity between kernels depends on stays what the shipped build uses) and every other
     unit is the regular build's object: lib/variants/libcassie2d_<name>.so, loaded through CASSIE2D_LIB.  Used by the A/B scripts under
-    profiles/tools and by the auto-var-init guard builds (tests/test_gpu_build_guard.py).  Content-stamped like the main library."""
+    profiles/tools and by the auto-var-init guard builds (tests/test_gpu_build_guard.py).  Content-stamped like the main library.
+    guarded: the units go through the ISA guard like the shipped build's (scan, retry flags); False keeps whatever the compiler produced
+    (diagnosis: the known-wrong builds of profiles/r06_exec_hole.txt)."""
     build()
     os.makedirs(VARDIR, exist_ok=True)
     out = variant_path(name)
     stamp = out + ".stamp"
-    ident = _flags_id() + "\n" + _tree_hash() + "\n" + " ".join(units) + " | " + " ".join(extra_flags)
+    ident = _flags_id() + "\n" + _tree_hash() + "\n" + " ".join(units) + " | " + " ".join(extra_flags) + (" | guarded" if guarded else " | unguarded")
+    notes = []
     try:
         if os.path.exists(out) and open(stamp).read() == ident:
             return out
@@ -158,9 +189,12 @@ def build_variant(name, units, extra_flags, verbose=False):
     def compile_one(u):
         obj = os.path.join(VARDIR, "%s_%s.o" % (u, name))
         cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(u, []) + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, u + ".hip")]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=CSRC)
+        if guarded:
+            _compile_guarded(cmd, obj, verbose, notes)
+        else:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
@@ -169,18 +203,29 @@ def build_variant(name, units, extra_flags, verbose=False):
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     with open(stamp, "w") as f:
         f.write(ident)
+    with open(out + ".notes", "w") as f:   # which units needed a retry flag set (tests print it)
+        f.write("\n".join(notes))
     return out
 
 
 # Guard builds: the units of the 64-environments-per-wavefront kernel with every automatic variable pre-set to a byte pattern /
 # to zero.  A read of an undefined value in device code -- or a register-allocation accident of this 512-register kernel -- shows up as a
 # difference between these builds and the shipped one (tests/test_gpu_build_guard.py compares them bit for bit on the GPU).
-GUARD_UNITS = ["tu_duo", "tu_duo_hf"]
-GUARD_VARIANTS = {"avi_pattern": ["-ftrivial-auto-var-init=pattern"], "avi_zero": ["-ftrivial-auto-var-init=zero"]}
+# "view": the r05 experiment whose device build depended on dead code, recreated (-DDUO_VIEW_EXPERIMENT, cassie_duo_core.h: joint_solve_view): a second
+# joint-solve path compiled into env_step_duo_kernel behind a flag no caller sets -- 1.2 KB of scratch instead of 264 B, another register allocation of
+# the whole kernel.  Must give the shipped build's results with the branch never taken AND with it taken (CASSIE_DUO_VIEW_FLAG).
+GUARD_VARIANTS = {"avi_pattern": (["tu_duo", "tu_duo_hf"], ["-ftrivial-auto-var-init=pattern"]),
+                  "avi_zero": (["tu_duo", "tu_duo_hf"], ["-ftrivial-auto-var-init=zero"]),
+                  "view": (["tu_duo"], ["-DDUO_VIEW_EXPERIMENT"])}
+DUO_VIEW_FLAG = 0x20000000   # CASSIE_DUO_VIEW_FLAG (cassie_duo_core.h), honoured by the "view" build only
 
 
 def build_guards(verbose=False):
-    return [build_variant(n, GUARD_UNITS, f, verbose) for n, f in sorted(GUARD_VARIANTS.items())]
+    libs = {n: build_variant(n, u, f, verbose) for n, (u, f) in sorted(GUARD_VARIANTS.items())}
+    # the pattern build of tu_duo exactly as the compiler emits it, NOT passed through the ISA guard: with hipcc 7.2.0 its env_step_duo_kernel<1> holds
+    # the exec-hole copy and is wrong on the GPU (the guard's known-bad reference: tests/test_isa_guard.py, tests/test_gpu_build_guard.py)
+    libs["avi_pattern_raw"] = build_variant("avi_pattern_raw", ["tu_duo"], ["-ftrivial-auto-var-init=pattern"], verbose, guarded=False)
+    return libs
 
 
 if __name__ == "__main__":
@@ -188,7 +233,7 @@ if __name__ == "__main__":
     if sys.argv[1:2] == ["--variant"]:   # python -m cassierl_amd.build --variant <name> "<unit> <unit>" <flags...>
         print(build_variant(sys.argv[2], sys.argv[3].split(), sys.argv[4:], verbose=True))
     elif sys.argv[1:2] == ["--guards"]:
-        print("\n".join(build_guards(verbose=True)))
+        print("\n".join(build_guards(verbose=True).values()))
     else:
         only = sys.argv[1:] or None
         print(build(force=only is None, verbose=True, only=only))

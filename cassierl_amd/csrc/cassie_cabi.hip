@@ -663,6 +663,17 @@ int CassieVecGetFullStateHost(CassieVec* h, double* s) {
   return CASSIE_OK;
 }
 
+int CassieVecDebugWorkspaceHost(CassieVec* h, double* out_host, uint64_t max_doubles, uint64_t* n_doubles) {
+  if (!h || !n_doubles) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  *n_doubles = h->duo_ws_bytes / sizeof(double);
+  if (!out_host || !h->duo_ws) return CASSIE_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint64_t m = *n_doubles < max_doubles ? *n_doubles : max_doubles;
+  HIPCHK(h, hipMemcpy(out_host, h->duo_ws, m * sizeof(double), hipMemcpyDeviceToHost));
+  return CASSIE_OK;
+}
+
 int CassieVecDebugSubstepHost(CassieVec* h, int control_mode, const double* a, double* dbg_host) {
   if (!h || !a || !dbg_host) return CASSIE_EINVAL;
   size_t n = h->n;

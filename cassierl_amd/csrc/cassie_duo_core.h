@@ -40,6 +40,9 @@
 
 #include "cassie_leg_core.h"
 
+#ifndef CASSIE_DUO_VIEW_FLAG
+#define CASSIE_DUO_VIEW_FLAG 0x20000000   // (DUO_VIEW_EXPERIMENT builds only; no caller sets it)
+#endif
 #ifndef LEG_NOUNROLL
 #define LEG_NOUNROLL _Pragma("clang loop unroll(disable)")
 #endif
@@ -324,6 +327,55 @@ template <class B> struct Duo : Core<B> {
     }
   }
 
+#ifdef DUO_VIEW_EXPERIMENT
+  // ---- r05 EXPERIMENT, kept as source for the build guard (tests/test_gpu_build_guard.py, DESIGN.md section 5 K1d "dead-code dependence"): the joint
+  // sweep's rows transposed by the ADDRESSES of the hand-over instead of lane exchanges.  Joint lane 2e + k (environment e of group k) reads its LEFT
+  // leg's rows from column 2e of group k's block and its RIGHT leg's from column 2e + 1 (B::wview), and writes the forces back the same way.  Slower
+  // (every load touches 2 KB of workspace and uses half of it), and in r05 the GPU build that merely CONTAINED this branch -- never taken -- gave wrong
+  // results.  -DDUO_VIEW_EXPERIMENT compiles the branch in behind a flag no caller sets (CASSIE_DUO_VIEW_FLAG).
+  template <int X> static LEG_FN void view_rows(W wv, LegRows& g, D& a0, D& a1, D& a2, M& go_) {
+    D t[W_NROWS];
+    get_block(wv, W_ROWS, t);
+    int k = 0;
+    lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; g.f[Ii] = t[k++]; });
+    lfor<0, NR>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      g.r[Ii] = t[k++]; g.Adiag[Ii] = t[k++]; g.Ainv[Ii] = t[k++];
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; g.ut[Ii][Bc] = t[k++]; });
+      lfor<Ii, NR>([&](auto jj) { constexpr int Jj = decltype(jj)::value; g.Al[symidx(NR, Ii, Jj)] = t[k++]; });
+    });
+    lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; g.Ant[P] = t[k++]; });
+    if constexpr (X == 0) { a0 = t[k]; a1 = t[k + 1]; a2 = t[k + 2]; }
+    M go; I ncon;
+    get_misc(wv, 0, go, ncon);
+    lfor<0, NP>([&](auto pp) { constexpr int P = decltype(pp)::value; g.pair[P] = go & (ncon > I(P)); });
+    if constexpr (X == 0) go_ = go;
+  }
+  static LEG_FN void joint_solve_view(W ws, const bool (&join)[2]) {
+    const M even = B::leg() == I(0);
+    const M none = even & !even;
+    const M mine = (even & (join[0] ? !none : none)) | ((!even) & (join[1] ? !none : none));   // this lane's group takes part
+    const W wl = B::wview(ws, W_GROUP, 0), wr = B::wview(ws, W_GROUP, 1);
+    LegRows L, R;
+    D a0, a1, a2, d0, d1, d2;
+    M goL, goR;
+    view_rows<0>(wl, L, a0, a1, a2, goL);
+    view_rows<1>(wr, R, d0, d1, d2, goR);
+    const M go = mine & goL;
+    I niter;
+    B::fence();
+    joint_sweeps(L, R, a0, a1, a2, go, niter);
+    B::fence();
+    D tl[NR], tr[NR];
+    lfor<0, NR>([&](auto ii) { constexpr int Ii = decltype(ii)::value; tl[Ii] = L.f[Ii]; tr[Ii] = R.f[Ii]; });
+    if (B::any(mine)) {
+      B::wput_if(wl, W_ROWS, tl, mine); B::wput_if(wr, W_ROWS, tr, mine);
+      B::wst_if(wl, W_MISC + 2, B::toD(niter), mine); B::wst_if(wr, W_MISC + 2, B::toD(niter), mine);
+      B::wst_if(wl, W_MISC + 3, D(1.0), mine);   // the group's spare slot: "this path ran" (the guard test reads it back; nothing else writes it)
+    }
+  }
+#endif
+
   // ------------------------------------------------------------------------------------------------ fused Env.step, two groups
   // io_of(g): the group's per-lane pointers (record, action row, observation row ...), g wave-uniform at run time; valid / o: per group.
   // The backend's Lds is switched to a group with lds.select(g, io) before any of that group's code runs; lds.snapshot(bool): stores to the
@@ -428,6 +480,11 @@ template <class B> struct Duo : Core<B> {
         });
         B::fence();
         lds.mark(11);   // 11 = rows of both groups in
+#ifdef DUO_VIEW_EXPERIMENT
+        if (cfg.flags & CASSIE_DUO_VIEW_FLAG) joint_solve_view(ws, join);
+        else
+#endif
+        {
         joint_solve(S, join);
         B::fence();
         lds.mark(7);    // 7 = transpose + joint sweeps + forces back
@@ -438,6 +495,7 @@ template <class B> struct Duo : Core<B> {
             B::wst(ws, G * W_GROUP + W_MISC + 2, B::toD(S[G].niter));
           }
         });
+        }
         B::fence();
         lds.mark(12);   // 12 = forces out
         // ---- phase 3, per group: finish

@@ -76,6 +76,19 @@ struct DevDuoB : DevB {
     u32x4 w; w.x = (unsigned)__double2loint(a); w.y = (unsigned)__double2hiint(a); w.z = (unsigned)__double2loint(b); w.w = (unsigned)__double2hiint(b);
     __builtin_amdgcn_raw_buffer_store_b128(w, ws.r, ws.voff, wofs(slot), DUO_WS_ST_AUX);
   }
+#ifdef DUO_VIEW_EXPERIMENT
+  // the view of joint lane 2e + k on column 2e + X of group k's block (group stride in slots; see joint_solve_view)
+  static LEG_FN W wview(W ws, int group_slots, int X) {
+    W v; v.r = ws.r;
+    const unsigned lane = ws.voff >> 4;
+    v.voff = ((lane & ~1u) + (unsigned)X) * 16u + (lane & 1u) * (unsigned)(group_slots / 2) * 1024u;
+    return v;
+  }
+  template <int N> static LEG_FN void wput_if(W ws, int first, double (&t)[N], bool m) {
+    if (m) { for (int i = 0; i < N; i++) wst(ws, first + i, t[i]); }
+  }
+  static LEG_FN void wst_if(W ws, int slot, double v, bool m) { if (m) wst(ws, slot, v); }
+#endif
   struct Lds {
     DuoShared* sh;
     int g;

@@ -122,6 +122,16 @@ class CassieVecEnv:
         return dict(first_tier=self.TIERS[int(out[0])], duo_table_slots=int(out[1]), duo_workspace_bytes=int(out[2]), ws_probes=int(out[3]),
                     handovers_per_launch=int(out[4]))
 
+    def debug_workspace_host(self):
+        """The 64-environments kernel's hand-over workspace as the last launch left it: array [wavefront slot][W_N slots][64 lanes] (diagnosis)."""
+        n = ct.c_uint64()
+        self._chk(self.L.CassieVecDebugWorkspaceHost(self.h, None, 0, ct.byref(n)))
+        buf = np.zeros(int(n.value))
+        self._chk(self.L.CassieVecDebugWorkspaceHost(self.h, buf.ctypes.data, n.value, ct.byref(n)))
+        per = 136 * 64 * 2
+        w = buf[:len(buf) // per * per].reshape(-1, 136, 64, 2)          # [wave][slot pair][lane][2]
+        return w.transpose(0, 1, 3, 2).reshape(w.shape[0], 272, 64)       # [wave][slot][lane]
+
     def reset_counters(self):
         self._chk(self.L.CassieVecResetCounters(self.h))
 

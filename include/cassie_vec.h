@@ -131,6 +131,9 @@ int CassieVecGetFullStateHost(CassieVec* h, double* state_host /*[n][88]*/);
 
 /* test hook: one substep for every env with a per-stage debug record ([n][512] doubles, host) */
 int CassieVecDebugSubstepHost(CassieVec* h, int control_mode, const double* actions_host, double* debug_host);
+/* test / diagnosis hook: the hand-over workspace of the 64-environments-per-wavefront kernel as the last launch left it ([slot pair][lane][2]
+ * doubles per wavefront slot, Duo::W_* in csrc/cassie_duo_core.h): *n_doubles = its size; out_host may be null (size query) */
+int CassieVecDebugWorkspaceHost(CassieVec* h, double* out_host, uint64_t max_doubles, uint64_t* n_doubles);
 /* kernel timing helper for bench.py: launches `steps` Env.steps back to back on the handle's stream and
  * returns the average kernel time in milliseconds measured with HIP events on that stream */
 int CassieVecTimeSteps(CassieVec* h, const double* actions_dev, int steps, double* obs_dev, double* reward_dev,

@@ -18,7 +18,7 @@ def main(out):
     from cassierl_amd import rollout as R
     from cassierl_amd.trajectory import default_gait
     from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_ON, DUO_TIER_ON
-    fl = LEG_TIER_ON | DUO_TIER_ON
+    fl = LEG_TIER_ON | DUO_TIER_ON | int(os.environ.get("GUARD_EXTRA_FLAGS", "0"), 0)
     g = default_gait()
     res = {}
 
@@ -54,6 +54,17 @@ def main(out):
     xs = np.linspace(-10.0, 10.0, 2001)
     relief = np.tile(0.015 * (1.0 - np.cos(2.0 * np.pi * xs / 1.5)), (64, 1))
     run("hf_pd", 2077, 20, 6, PD_LO, PD_HI, hf=relief, shift=True, kind="stand", control_mode="PD", n_substeps=10, auto_reset=True)
+    # kernel time of the headline workload with this build / these flags (tells a taken experiment branch from one that is not)
+    env = CassieVecEnv(65536, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True, flags=fl)
+    env.set_trajectory(g.time, g.qpos)
+    bufs = env.alloc(); env.reset(bufs)
+    ids = torch.arange(65536, device="cuda:0")
+    for t in range(5):
+        env.step(R.random_actions(1, ids, t, PD_LO, PD_HI), bufs)
+    res["ms_per_65536_env_step"] = np.array([env.time_steps(R.random_actions(1, ids, 5, PD_LO, PD_HI), 10, bufs)])
+    ws = env.debug_workspace_host()
+    res["ms_view_marks"] = np.array([float(ws[:, 135, :].sum() + ws[:, 136 + 135, :].sum())])   # Duo::W_MISC + 3 of both groups: written by joint_solve_view only
+    env.close()
     np.savez(out, **res)
 
 
