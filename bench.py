@@ -30,6 +30,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 65536
+FIRST_TIER_KERNEL = {"duo": "cassie::leg::env_step_duo_kernel<0>", "leg": "cassie::leg::env_step_leg_kernel<0>",
+                     "g16": "cassie::g16::env_step_g16_kernel<0, false>", "wave_per_env": "cassie::env_step_kernel<0, 1, 32, false>"}   # CassieVecEnv.tier_info()["first_tier"] -> kernel of one PD Env.step
+
+
 def dominant_kernel(n_envs, simds=1024):
     """The kernel one bench step launches (PD mode, flat floor), by the library's rule (cassie_cabi.hip, CassieVecCreate: whole rounds of one
     wavefront per SIMD -- 64 environments per wavefront at ~1.05 ms a round against 32 at ~0.65 ms; LEG_MIN_ENVS below that)."""
@@ -66,6 +70,7 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-trpo", action="store_true", help="N > 1: skip the TRPO outer loop (configs[3]'s caller) after the random-policy rollout")
     ap.add_argument("--trpo-iters", type=int, default=6)
+    ap.add_argument("--trpo-timeout", type=float, default=300.0, help="N > 1: seconds after which a TRPO stage that has not finished is taken for a lost rank (headline printed, exit 6)")
     ap.add_argument("--cpu-legs-only", action="store_true", help="internal: print the CPU legs of configs[0]/[2]/[4] as JSON (no GPU) and exit")
     return ap.parse_args()
 
@@ -416,7 +421,7 @@ def extra_workloads(traj, n):
     rows.append(run_env_workload("torque_random_no_reset_fallen", n, "stand", "Torque", 0, traj, 200, 20,
                                  lambda t: R.random_actions(3, ids, t, tq_box.low, tq_box.high),
                                  "random torques, auto_reset off: robots on the ground (throughput floor of the PD/torque path)", auto_reset=False))
-    # counted useful FP64 of the two falling-robot rows (tests/count_flops.py: the first tier's own source through the op-counting CPU build, robots in the
+    # counted useful FP64 of the two falling-robot rows (tools/count_flops.py: the first tier's own source through the op-counting CPU build, robots in the
     # same regime) against the FP64 vector peak, over the WHOLE step (first tier in segments + the lower tiers beside it)
     try:
         uf_all = json.load(open(os.path.join(ROOT, "profiles", "useful_flops.json")))
@@ -504,7 +509,7 @@ def extra_workloads(traj, n):
     dt = time.perf_counter() - t0
     row = dict(workload="configs[4]_cassie3d_torque_random", note="cassie3d_stiff.xml physics, random torques, robots fall during the run",
                envs=n3, warmup_steps=30, steps=30, env_steps_per_s=n3 * 30 / dt, ms_per_step=dt / 30 * 1e3)
-    try:   # roofline of configs[4]: counted useful FP64 flops of exactly this workload (tests/count_flops.py, op-counting CPU build of
+    try:   # roofline of configs[4]: counted useful FP64 flops of exactly this workload (tools/count_flops.py, op-counting CPU build of
         # the lane-per-leg kernel's source) / the measured step time, against the FP64 vector peak
         uf = json.load(open(os.path.join(ROOT, "profiles", "useful_flops.json")))["cassie3d_torque_random"]["flop_per_env_step"]
         ach = uf * n3 * 30 / dt / 1e12
@@ -529,29 +534,66 @@ def extra_workloads(traj, n):
     return rows
 
 
-def trpo_outer_loop(n, world, device, warm=4, iters=6):
+def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s=300.0):
     """configs[3]'s caller (rllab/envs/trpo_cassie.py:21-48): TRPO iterations on `n` envs per rank x 8 Env.steps -- rollout, baseline,
     gradient, ten Fisher-vector products, line search -- with the data-parallel collectives of the update (all_reduce of the
     ~1.3 k-parameter gradient / Fisher-vector products / line-search scalars / baseline normal equations, all_gather of the per-env
     returns) timed one by one with HIP events.  Every rank calls this; the timed region is barrier + synchronize on both sides and
-    the MAX over ranks.  Returns the row (meaningful on rank 0)."""
+    the MAX over ranks.  Returns the row (meaningful on rank 0).
+
+    The stage is made of collectives, so with more than one rank: (1) everything that can fail LOCALLY -- the env, its hand-over
+    workspace, the policy -- is constructed first, and the ranks agree on success with one all_reduce(MIN); if any rank failed, every rank
+    skips the stage and the row says so; (2) a failure AFTER that point leaves the ranks out of step for good: `on_desync(reason)` is called
+    (the caller prints the headline it has already measured) and the process exits non-zero -- also from a watchdog when the stage does
+    not finish within `timeout_s` because another rank died inside it; (3) T.COMM is reset and the env closed on every path."""
+    import threading
     import torch
     from cassierl_amd import rollout as R
     from cassierl_amd import trpo as T
     from cassierl_amd.trajectory import default_gait
-    algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", device=device, trajectory=default_gait(), batch_size=n * world * 8)
-    for _ in range(warm):
-        algo.train_iteration()
-    T.COMM = T.CommTimer() if world > 1 else None
-    torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        st = algo.train_iteration()
-    torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
-    dt = R.max_over_ranks(time.perf_counter() - t0, device="cuda:%d" % device)
-    comm = T.COMM.summary() if T.COMM is not None else {}
-    T.COMM = None
-    algo.env.close()
+    algo, err = None, None
+    try:
+        if os.environ.get("CASSIE_TEST_HOOKS") == "1" and os.environ.get("CASSIE_TEST_TRPO_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("test hook: this rank fails to construct the TRPO stage")
+        algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", device=device, trajectory=default_gait(), batch_size=n * world * 8)
+    except Exception as ex:
+        err = repr(ex)
+    if R.min_over_ranks(0.0 if err else 1.0, device="cuda:%d" % device) < 1.0:
+        if algo is not None:
+            algo.env.close()
+        return dict(workload="trpo_outer_loop_walk_pd", skipped=True, error=err or "another rank could not construct the stage; skipped on every rank")
+
+    def desync(reason):
+        try:
+            if on_desync is not None:
+                on_desync(reason)
+        finally:
+            os._exit(6)   # the ranks are out of step: nothing collective can follow, and a process that has touched the GPU is not re-executed
+
+    dog = threading.Timer(timeout_s, desync, args=("the TRPO stage did not finish within %.0f s (a rank died inside a collective?)" % timeout_s,)) if world > 1 else None
+    if dog is not None:
+        dog.daemon = True
+        dog.start()
+    try:
+        for _ in range(warm):
+            algo.train_iteration()
+        T.COMM = T.CommTimer() if world > 1 else None
+        torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            st = algo.train_iteration()
+        torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
+        dt = R.max_over_ranks(time.perf_counter() - t0, device="cuda:%d" % device)
+        comm = T.COMM.summary() if T.COMM is not None else {}
+    except Exception as ex:
+        if world > 1:
+            desync("the TRPO stage failed on this rank inside its collectives: %r" % (ex,))
+        raise
+    finally:
+        if dog is not None:
+            dog.cancel()
+        T.COMM = None
+        algo.env.close()
     per_iter = {k: dict(calls_per_iteration=v["calls"] / iters, ms_per_iteration=v["total_ms"] / iters, mean_ms=v["mean_ms"], max_ms=v["max_ms"]) for k, v in comm.items()}
     return dict(workload="trpo_outer_loop_walk_pd",
                 note="TRPO iterations (rollout of 8 Env.steps + update) on %d envs per rank x %d rank(s); env-steps of the rollouts per second of the whole loop" % (n, world),
@@ -572,7 +614,7 @@ def pmc_for_this_tree():
 
 def roofline_object(n_local, kernel_ms, dominant, pmc):
     """The ceiling that binds this path is the FP64 vector unit, not HBM: `achieved` = USEFUL FP64 flops of the
-    algorithm per launch (counted by an op-counting build of the kernel's own source for this workload's row mix, tests/count_flops.py
+    algorithm per launch (counted by an op-counting build of the kernel's own source for this workload's row mix, tools/count_flops.py
     -> profiles/useful_flops.json; inside a Gauss-Seidel step only the owner lane counts) / the dominant kernel's launch time measured
     here with HIP events; `peak` = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz.  `issued` (PMC: VALU instruction counters x 64 lanes,
     an upper bound of the useful work) and `traffic` (PMC: HBM bytes per launch) are only given when profiles/pmc_traffic.json
@@ -695,19 +737,12 @@ def worker(args):
     kernel_ms = kev0.elapsed_time(kev1) / args.steps
     q, v = env.get_state_host()
     finite = bool(np.isfinite(q).all() and np.isfinite(v).all())
+    tier = env.tier_info()   # what the library chose for this handle (batch size, flags, CASSIE2D_* overrides), not a re-derivation of its rule
     env.close()
     backend = R.dist.get_backend() if R.dist.is_initialized() else None
-    # configs[3] as written ("512k envs sharded 8 x MI355X, TRPO outer loop, RCCL return gather"): with more than one rank every rank
-    # also runs the TRPO loop on its shard (gradient / Fisher-vector-product all-reduces, return gather); the random-policy rollout
-    # above stays the headline metric.  Collective: every rank takes part, so a failure on one rank must not leave the others waiting.
-    trpo_row = None
-    if world > 1 and not args.no_trpo:
-        try:
-            trpo_row = trpo_outer_loop(n_local, world, dev, warm=3, iters=args.trpo_iters)
-        except Exception as ex:
-            trpo_row = dict(workload="trpo_outer_loop_walk_pd", error=repr(ex))
 
     rc = 0
+    line = None
     if rank == 0:
         n_total = n_local * world
         value = n_total * args.steps / elapsed
@@ -721,7 +756,7 @@ def worker(args):
             pmc = {}
         from cassierl_amd.build import source_hash
         pmc_ok = pmc.get("envs") == n_local and pmc.get("csrc_sha16") == source_hash()
-        dominant = (pmc.get("dominant_kernel") if pmc_ok else None) or dominant_kernel(n_local)
+        dominant = FIRST_TIER_KERNEL[tier["first_tier"]]
         line = {
             "metric": "env-steps/sec (whole node) for Cassie2d batched rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": ranks_joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -732,14 +767,41 @@ def worker(args):
                                       ("configs[1] as written" if n_local == 4096 else "configs[1] workload at a non-default size")),
                        "envs_per_gpu": n_local, "envs_total": n_total, "substeps_per_env_step": 10, "parallelism": "env-shards x%d" % world,
                        "collective": "one all_gather of per-env returns per rollout batch", "gather_ms": gather_ms,
-                       "backend": backend, "ranks_joined": ranks_joined, "preroll_steps": preroll_steps},
+                       "backend": backend, "ranks_joined": ranks_joined, "preroll_steps": preroll_steps,
+                       "first_tier": tier["first_tier"], "duo_workspace_MB": tier["duo_workspace_bytes"] / 1e6, "duo_claim_table_slots": tier["duo_table_slots"]},
             "roofline": roofline_object(n_local, kernel_ms, dominant, pmc if pmc_ok else {}),
             "physics_substeps_per_s": value * 10, "returns_checksum": float(all_returns.sum().item()), "finite": finite,
             "episodes_terminated_per_env_step": float(dones.item()) / (n_local * args.steps),
             "cleanup_frac": counters["cleanup_frac"], "k1_frac": counters["k1_frac"], "nonfinite_resets": counters["nonfinite_resets"],
             "workload_note": "reference quirk Q3 (stale qstate) makes reward < 0.6 on every step, so every env terminates and auto-resets "
                              "each step: the headline is the reference-faithful but degenerate regime; `extra` holds the regimes where robots move",
+            "cpu_baseline": None,
         }
+
+    def print_line():
+        # RCCL writes its banner ("Librccl path : ...") through C stdio, which is flushed at exit when stdout is a pipe: flush
+        # it now so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
+
+    # configs[3] as written ("512k envs sharded 8 x MI355X, TRPO outer loop, RCCL return gather"): with more than one rank every rank
+    # also runs the TRPO loop on its shard (gradient / Fisher-vector-product all-reduces, return gather); the random-policy rollout
+    # above stays the headline metric and is ALREADY in `line`: if the ranks fall out of step inside this stage, rank 0 prints the
+    # headline with the reason and every rank exits non-zero (trpo_outer_loop: on_desync).
+    trpo_row = None
+    if world > 1 and not args.no_trpo:
+        def on_desync(reason):
+            if rank == 0:
+                line["config"]["trpo_outer_loop"] = dict(workload="trpo_outer_loop_walk_pd", error=reason)
+                print_line()
+            sys.stderr.write("bench.py rank %d: %s\n" % (rank, reason))
+        trpo_row = trpo_outer_loop(n_local, world, dev, warm=3, iters=args.trpo_iters, on_desync=on_desync, timeout_s=args.trpo_timeout)
+
+    if rank == 0:
         if not finite or ranks_joined != max(1, args.gpus):
             rc = 4
         if trpo_row is not None:
@@ -772,20 +834,11 @@ def worker(args):
                     line["extra"] += cpu_legs_other_configs()
                 except Exception as ex:
                     line["extra"].append({"error": "cpu legs: " + repr(ex)})
-        else:
-            line["cpu_baseline"] = None
     if R.dist.is_initialized():
         R.dist.barrier()
         R.dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes its banner ("Librccl path : ...") through C stdio, which is flushed at exit when stdout is a pipe: flush
-        # it now so that the JSON line is the LAST line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(line), flush=True)
+        print_line()
     return rc
 
 

@@ -647,7 +647,7 @@ def main(xml=DEFAULT_XML):
     os.makedirs(os.path.join(REPO, "tests", "golden"), exist_ok=True)
     with open(os.path.join(REPO, "tests", "golden", "model_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)
-    # planar tables as JSON (consumed by tests/planar_proto.py, the executable spec of the kernel math)
+    # planar tables as JSON (consumed by tools/planar_proto.py, the executable spec of the kernel math)
     def _j(x):
         if isinstance(x, dict):
             return {k: _j(v) for k, v in x.items()}

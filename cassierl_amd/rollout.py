@@ -113,6 +113,15 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def min_over_ranks(value, device=None):
+    """all_reduce(MIN): e.g. an `ok` flag every rank must agree on before a stage made of collectives is entered."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -18,9 +18,9 @@ run() {  # name, counters, program args...
 }
 for wl in ${PMC_WORKLOADS:-pd osc c3}; do
   case $wl in
-    pd)  prog="$root/tests/prof_step.py 65536 4 PD" ;;
-    osc) prog="$root/tests/prof_step.py 65536 4 OSC" ;;
-    c3)  prog="$root/tests/bench_cassie3d.py --envs 16384 --steps 4" ;;
+    pd)  prog="$root/tools/prof_step.py 65536 4 PD" ;;
+    osc) prog="$root/tools/prof_step.py 65536 4 OSC" ;;
+    c3)  prog="$root/tools/bench_cassie3d.py --envs 16384 --steps 4" ;;
   esac
   for grp in ${PMC_GROUPS:-sq1 sq2 fetch write}; do
     case $grp in

@@ -12,7 +12,7 @@ for grp in a b; do
     a) ctrs="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" ;;
     b) ctrs="SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE SQ_INSTS_SALU" ;;
   esac
-  rocprofv3 --pmc $ctrs --output-format csv -d "$out/pmc_trpo_$grp" -o pmc -- python3 "$root/tests/prof_fvp.py" 8 > "$out/pmc_trpo_$grp.log" 2>&1
+  rocprofv3 --pmc $ctrs --output-format csv -d "$out/pmc_trpo_$grp" -o pmc -- python3 "$root/tools/prof_fvp.py" 8 > "$out/pmc_trpo_$grp.log" 2>&1
   echo "trpo_$grp rc=$? $(find "$out/pmc_trpo_$grp" -name '*counter_collection.csv' | head -1 | xargs -r wc -l)"
 done
 python3 - "$out" <<'PY'

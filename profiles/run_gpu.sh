@@ -24,13 +24,13 @@ for w in $what; do
     legforced)   # the whole -m gpu suite once more with the two-lanes-per-environment tier forced on for every batch size
       CASSIE2D_LEG=1 timeout 3000 python3 -m pytest tests -m gpu -q > "$out/pytest_gpu_leg_forced.log" 2>&1; echo "pytest(leg forced) rc=$?" >> "$out/pytest_gpu_leg_forced.log"
       tail -3 "$out/pytest_gpu_leg_forced.log" ;;
-    profosc)   # kernel statistics of configs[2]: controller kernel + physics kernel per substep (tests/prof_step.py, OSC in the loop)
+    profosc)   # kernel statistics of configs[2]: controller kernel + physics kernel per substep (tools/prof_step.py, OSC in the loop)
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_osc" -o osc -- \
-          python3 "$root/tests/prof_step.py" 65536 30 OSC > "$out/stats_osc.log" 2>&1 )
+          python3 "$root/tools/prof_step.py" 65536 30 OSC > "$out/stats_osc.log" 2>&1 )
       find "$out/stats_osc" -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-170 ;;
     proffallen)   # kernel trace of the all-fallen floor (lower tiers side by side on two streams)
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_fallen" -o fallen -- \
-          python3 "$root/tests/prof_fallen.py" > "$out/stats_fallen.log" 2>&1 )
+          python3 "$root/tools/prof_fallen.py" > "$out/stats_fallen.log" 2>&1 )
       find "$out/stats_fallen" -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | cut -c1-170 ;;
     trpo)
       timeout 900 python3 train_trpo.py --envs-per-gpu 65536 --horizon 8 --n-itr 5 --kind stand --control-mode Torque --timing > "$out/trpo_65536.jsonl" 2> "$out/trpo.err"
@@ -44,7 +44,7 @@ for w in $what; do
       find "$out/stats_trpo" -name "*kernel_stats.csv" | head -1 | xargs -r head -14 | cut -c1-170 ;;
     prof3d)   # kernel statistics of configs[4] (Cassie3d, 16 384 envs, reset every 40 steps)
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_3d" -o c3d -- \
-          python3 "$root/tests/bench_cassie3d.py" > "$out/stats_3d.log" 2>&1 )
+          python3 "$root/tools/bench_cassie3d.py" > "$out/stats_3d.log" 2>&1 )
       grep -a "^{" "$out/stats_3d.log" | tail -1 > "$out/cassie3d_bench.json"
       find "$out/stats_3d" -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-170 ;;
     pmc)

@@ -96,7 +96,7 @@ def main():
         sys.path.insert(0, ROOT)
         from cassierl_amd.build import source_hash
         useful = None
-        try:  # counted useful flops of the same workload (tests/count_flops.py writes it)
+        try:  # counted useful flops of the same workload (tools/count_flops.py writes it)
             useful = json.load(open(os.path.join(HERE, "useful_flops.json")))["pd_bench"]["flop_per_env_step"]
         except Exception:
             pass

@@ -1,13 +1,13 @@
 set -u
-root=$(pwd); out=$root/gpurun_out/${1:-r05_d}; mkdir -p $out
+root=$(cd "$(dirname "$0")/../.." && pwd); out=$root/gpurun_out/${1:-r05_d}; mkdir -p $out
 true
 cd /tmp && export TMPDIR=/tmp
 G1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
 G2="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT GRBM_GUI_ACTIVE"
 for d in 0 1; do
   export CASSIE2D_DUO=$d
-  rocprofv3 --pmc $G1 --output-format csv -d $out/pmc_duo${d}_g1 -o pmc -- python3 $root/tests/prof_step.py 65536 4 PD > $out/pmc_duo${d}_g1.log 2>&1
-  rocprofv3 --pmc $G2 --output-format csv -d $out/pmc_duo${d}_g2 -o pmc -- python3 $root/tests/prof_step.py 65536 4 PD > $out/pmc_duo${d}_g2.log 2>&1
+  rocprofv3 --pmc $G1 --output-format csv -d $out/pmc_duo${d}_g1 -o pmc -- python3 $root/tools/prof_step.py 65536 4 PD > $out/pmc_duo${d}_g1.log 2>&1
+  rocprofv3 --pmc $G2 --output-format csv -d $out/pmc_duo${d}_g2 -o pmc -- python3 $root/tools/prof_step.py 65536 4 PD > $out/pmc_duo${d}_g2.log 2>&1
 done
 python3 - "$out" <<'P'
 import csv,glob,collections,sys

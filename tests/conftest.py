@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):   # tools/: planar_proto.py, the executable spec of the kernel math
     if p not in sys.path:
         sys.path.insert(0, p)
 

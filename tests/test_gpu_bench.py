@@ -175,3 +175,17 @@ def test_launcher_stops_all_ranks_when_one_dies():
     rc, out, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "256", "--no-cpu-baseline"], env, timeout=600)
     assert rc != 0 and "rank 1 exited" in err and time.time() - t0 < 300
     assert not [l for l in out.strip().splitlines() if l.startswith("{")]
+
+
+def test_trpo_stage_is_skipped_on_every_rank_when_one_cannot_construct_it():
+    """the TRPO stage behind the headline is made of collectives; a rank that fails to build its env / workspace / policy must not leave
+    the others waiting in a broadcast.  Rank 1 is made to fail its construction: the ranks agree (all_reduce MIN) to skip, the run ends with rc 0,
+    ONE JSON line, the headline measured before the stage intact and the row saying why it was skipped."""
+    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_HOOKS="1", CASSIE_TEST_TRPO_FAIL_RANK="1")
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2"], env, timeout=600)
+    assert rc == 0, err[-2000:]
+    line = _line(out)
+    assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1
+    assert line["n_gpus"] == 2 and line["finite"] and line["value"] > 0 and line["config"]["first_tier"] == "g16"
+    row = line["config"]["trpo_outer_loop"]
+    assert row["skipped"] and "another rank" in row["error"] and line["config"]["trpo_outer_loop_env_steps_per_s"] is None

@@ -142,7 +142,7 @@ def test_free_running_1000_substeps_within_1e5(V3, kat, tier):
 
 
 def test_free_running_10000_substeps_drift_within_1e5(V3, kat, tier):
-    """The drift run of tests/parity_drift.py as a test: 10 000 FREE-RUNNING torque substeps = 1000 Env.steps of
+    """The drift run of tools/parity_drift.py as a test: 10 000 FREE-RUNNING torque substeps = 1000 Env.steps of
     cassie3d_stiff.xml, smooth random torques (a new draw every 200 substeps), HIP path against the oracle from the same state and
     the same torques, no teacher forcing; the north_star bar (1e-5 relative) at every 100th substep.  Measured: ~2e-9."""
     import oracle_py

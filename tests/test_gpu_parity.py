@@ -130,7 +130,7 @@ def test_free_running_torque_1000_substeps(vec_tier, oracle_mod):
 
 
 def test_free_running_torque_10000_substeps_drift(vec_tier, oracle_mod):
-    """The drift run of tests/parity_drift.py as a test: 10 000 FREE-RUNNING torque substeps = 1000 Env.steps, smooth
+    """The drift run of tools/parity_drift.py as a test: 10 000 FREE-RUNNING torque substeps = 1000 Env.steps, smooth
     random torques (a new draw every 200 substeps: the robot sways, falls and rolls on the ground), HIP path against the oracle from
     the same state, no teacher forcing; the north_star bar (1e-5 relative) at every 100th substep, each first tier.
     Measured: 3e-13 .. 7e-12 depending on the tier's roundings."""
@@ -228,7 +228,7 @@ def test_pd_1000_substeps_shadowing_bound(vec_tier, oracle_mod):
     env.close()
 
 
-TWIN_EPS = 3e-14     # measured per-substep deviation of the HIP path from the oracle (tests/teacher_forced_error.py: max 3.2e-14)
+TWIN_EPS = 3e-14     # measured per-substep deviation of the HIP path from the oracle (tools/teacher_forced_error.py: max 3.2e-14)
 TWIN_C = 20.0
 
 

@@ -1,4 +1,4 @@
-"""The planar formulation the HIP kernels implement (tests/planar_proto.py) against the 3-D oracle:
+"""The planar formulation the HIP kernels implement (tools/planar_proto.py) against the 3-D oracle:
 validates the sagittal-plane reduction, the 2-row contacts/connects, the fixed slot order and the
 incremental-residual PGS on CPU, step by step (teacher-forced so that chaos cannot mask a bug)."""
 import numpy as np

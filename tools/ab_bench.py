@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the extension on the bench workload (not a test): for each library given on the command line, the median
 kernel time of one 65 536-env Env.step (PD and torque) by HIP events, plus a spot check that the builds agree.
-usage: python tests/ab_bench.py libA.so libB.so      (AB_ENVS = batch size, default 65536; AB_FLAGS = CassieVecConfig flags, e.g. 16 = no leg tier)"""
+usage: python tools/ab_bench.py libA.so libB.so      (AB_ENVS = batch size, default 65536; AB_FLAGS = CassieVecConfig flags, e.g. 16 = no leg tier)"""
 import json
 import os
 import subprocess

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of builds of the extension on configs[2] (not a test): per library, wall time of the OSC Env.step with random targets and of
-the scripted standing controller at 65 536 envs.   usage: python tests/ab_osc.py libA.so [libB.so ...]"""
+the scripted standing controller at 65 536 envs.   usage: python tools/ab_osc.py libA.so [libB.so ...]"""
 import json
 import os
 import subprocess

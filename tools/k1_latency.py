@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of the wave-per-environment kernel on fallen robots (not a test): N envs (few: one wavefront per SIMD at most), ms per
-Env.step of ten substeps.   usage: python tests/k1_latency.py [n_envs]   (CASSIE2D_LIB selects the build)"""
+Env.step of ten substeps.   usage: python tools/k1_latency.py [n_envs]   (CASSIE2D_LIB selects the build)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

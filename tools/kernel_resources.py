@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compiler-reported resources of every kernel of a translation unit (not a test): registers, scratch, LDS, occupancy.
-usage: python tests/kernel_resources.py tu_g16 [tu_3d ...]   (extra hipcc flags through CASSIE_HIPCC_FLAGS)"""
+usage: python tools/kernel_resources.py tu_g16 [tu_3d ...]   (extra hipcc flags through CASSIE_HIPCC_FLAGS)"""
 import os
 import re
 import subprocess

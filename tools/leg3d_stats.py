@@ -2,7 +2,7 @@
 """What a wavefront of the lane-per-leg Cassie3d kernel executes per substep (not a test): the kernel source compiled for the CPU with 64
 lanes = the 32 environments of one wavefront and counters on its wave-uniform loops -- sweeps, joint-limit steps, contact steps and
 Newton iterations of the cone QCQP -- on the configs[4] workload (random torques from the standing pose).
-usage: python tests/leg3d_stats.py /path/to/libleg3d_stats.so   (g++ ... -DLEG_HOST_FAST -DLEG_HOST_LANES=64 -DLEG3_STATS leg3d_host.cpp)"""
+usage: python tools/leg3d_stats.py /path/to/libleg3d_stats.so   (g++ ... -DLEG_HOST_FAST -DLEG_HOST_LANES=64 -DLEG3_STATS leg3d_host.cpp)"""
 import ctypes as ct, sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PGS sweeps per substep actually needed per environment vs per wavefront of 32 (not a test).  usage: python tests/niter_stats.py [PD|Torque]"""
+"""PGS sweeps per substep actually needed per environment vs per wavefront of 32 (not a test).  usage: python tools/niter_stats.py [PD|Torque]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

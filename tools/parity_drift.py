@@ -2,7 +2,7 @@
 """Free-running parity drift (not a pytest file): HIP path vs CPU oracle from the same initial state and the same action
 stream, no teacher forcing, error recorded every 500 substeps.  Writes one JSON line per model.
 
-  python tests/parity_drift.py [substeps]     (GPU box; ~1 min for 10 000 substeps)
+  python tools/parity_drift.py [substeps]     (GPU box; ~1 min for 10 000 substeps)
 """
 import json
 import os

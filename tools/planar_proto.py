@@ -21,7 +21,7 @@ LIMIT_DOFS = [3, 4, 5, 6, 8, 9, 10, 11]
 
 
 def load_tables():
-    with open(os.path.join(HERE, "golden", "planar_tables.json")) as f:
+    with open(os.path.join(os.path.dirname(HERE), "tests", "golden", "planar_tables.json")) as f:
         return json.load(f)
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the first physics tier against the batch size: FETCH_SIZE / WRITE_SIZE (separate --pmc passes, no tracing)
-# of `tests/prof_step.py <n> 4 PD` for each library given, at 65 536 .. 524 288 envs.   usage: bash tools/pmc_size_sweep.sh <tag> lib.so [lib.so ...]
+# of `tools/prof_step.py <n> 4 PD` for each library given, at 65 536 .. 524 288 envs.   usage: bash tools/pmc_size_sweep.sh <tag> lib.so [lib.so ...]
 # Raw CSVs under gpurun_out/<tag>/; the summary (per-dispatch means after the first dispatch; FETCH_SIZE doubled, KiB -> bytes: summarize_pmc.py's
 # conventions) goes to gpurun_out/<tag>/pmc_size_sweep.jsonl.
 set -u
@@ -13,7 +13,7 @@ for lib in "$@"; do
   export CASSIE2D_LIB=$root/$lib
   for n in ${SWEEP_SIZES:-65536 131072 262144 524288}; do
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $c --output-format csv -d "$out/pmc_${name}_${n}_$c" -o pmc -- python3 "$root/tests/prof_step.py" $n 4 PD > "$out/pmc_${name}_${n}_$c.log" 2>&1
+      rocprofv3 --pmc $c --output-format csv -d "$out/pmc_${name}_${n}_$c" -o pmc -- python3 "$root/tools/prof_step.py" $n 4 PD > "$out/pmc_${name}_${n}_$c.log" 2>&1
       echo "$name $n $c rc=$?"
     done
   done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The TRPO loop's Fisher-vector product kernel alone (not a test): 524 288 samples, the 26-32-32-6 policy, N products -- the workload behind
-the PMC figures of the matrix-core kernel (profiles/collect_pmc_trpo.sh).  usage: python tests/prof_fvp.py [products]"""
+the PMC figures of the matrix-core kernel (profiles/collect_pmc_trpo.sh).  usage: python tools/prof_fvp.py [products]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2,7 +2,7 @@
 """How often a group of 32 environments of the two-lanes / 64-environments-per-wavefront kernels leaves the six-row sweep (not a test): the kernel
 source compiled for the CPU with 64 lanes = the 32 environments of one group and a counter on its wave-uniform `small` decision, on the bench
 workload (walk env, PD, random targets, every step resets) and on stand env / PD.
-usage: python tests/small_stats.py /path/to/libleg_host_stats64.so
+usage: python tools/small_stats.py /path/to/libleg_host_stats64.so
        (g++ -O2 -march=native -fopenmp -ffp-contract=off -DLEG_HOST_FAST -DLEG_HOST_LANES=64 -DLEG_STATS leg_host.cpp)"""
 import ctypes as ct, os, sys
 import numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a TRPO update spends its time (not a test): python tests/time_trpo_parts.py [envs] [horizon]"""
+"""Where a TRPO update spends its time (not a test): python tools/time_trpo_parts.py [envs] [horizon]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
