@@ -141,8 +141,14 @@ def spawn_ranks(args, poll_s=0.5, deadline_s=3600.0):
         if rc == 0 and live and time.time() > deadline:
             rc = 124
             sys.stderr.write("bench.py: deadline of %.0f s passed with rank(s) %s still running\n" % (deadline_s, live))
-    for p in procs:  # exact PIDs only
+    for p in procs:  # exact PIDs only.  SIGTERM first: rank 0 inside the TRPO stage prints the headline it has measured (trpo_outer_loop's watchdog)
         if p.poll() is None:
+            p.terminate()
+    t_end = time.time() + 8.0
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
             p.kill()
     for p in procs:
         try:
@@ -555,7 +561,7 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s
     try:
         if os.environ.get("CASSIE_TEST_HOOKS") == "1" and os.environ.get("CASSIE_TEST_TRPO_FAIL_RANK") == os.environ.get("RANK", "0"):
             raise RuntimeError("test hook: this rank fails to construct the TRPO stage")
-        algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", device=device, trajectory=default_gait(), batch_size=n * world * 8)
+        algo = T.make_cassie_trpo(n, kind="walk", control_mode="PD", device=device, trajectory=default_gait(), batch_size=n * world * 8, sync_policy=False)
     except Exception as ex:
         err = repr(ex)
     if R.min_over_ranks(0.0 if err else 1.0, device="cuda:%d" % device) < 1.0:
@@ -570,11 +576,43 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s
         finally:
             os._exit(6)   # the ranks are out of step: nothing collective can follow, and a process that has touched the GPU is not re-executed
 
-    dog = threading.Timer(timeout_s, desync, args=("the TRPO stage did not finish within %.0f s (a rank died inside a collective?)" % timeout_s,)) if world > 1 else None
-    if dog is not None:
-        dog.daemon = True
+    # Watchdog thread (world > 1): fires when the stage has not finished within timeout_s, or at once when this process is told to terminate
+    # (SIGTERM: torchrun's agent and bench.py's own launcher stop the surviving ranks that way when one rank dies).  The main thread may
+    # be blocked inside a collective (C++, no Python signal handler can run there), so the signal is caught through the wake-up pipe:
+    # the C-level handler writes a byte, the watchdog thread selects on the other end.
+    dog = stop_dog = None
+    if world > 1:
+        import select
+        import signal
+        import socket as _socket
+        r_sock, w_sock = _socket.socketpair()
+        w_sock.setblocking(False)
+        old_handler = signal.signal(signal.SIGTERM, lambda *_a: None)
+        old_fd = signal.set_wakeup_fd(w_sock.fileno(), warn_on_full_buffer=False)
+        done = threading.Event()
+
+        def watch():
+            ready, _, _ = select.select([r_sock], [], [], timeout_s)
+            if done.is_set():
+                return
+            desync("terminated (another rank died?) inside the TRPO stage" if ready else
+                   "the TRPO stage did not finish within %.0f s (a rank died inside a collective?)" % timeout_s)
+
+        dog = threading.Thread(target=watch, daemon=True)
         dog.start()
+
+        def stop_dog():
+            done.set()
+            signal.set_wakeup_fd(old_fd)
+            signal.signal(signal.SIGTERM, old_handler)
+            try:
+                w_sock.send(b"x")   # wakes the watchdog, which sees `done`
+            except OSError:
+                pass
     try:
+        T.broadcast_initial_policy(algo)
+        if os.environ.get("CASSIE_TEST_HOOKS") == "1" and os.environ.get("CASSIE_TEST_TRPO_DIE_RANK") == os.environ.get("RANK", "0"):
+            os._exit(9)   # test hook: this rank dies inside the stage, after the ranks agreed to run it
         for _ in range(warm):
             algo.train_iteration()
         T.COMM = T.CommTimer() if world > 1 else None
@@ -590,8 +628,8 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s
             desync("the TRPO stage failed on this rank inside its collectives: %r" % (ex,))
         raise
     finally:
-        if dog is not None:
-            dog.cancel()
+        if stop_dog is not None:
+            stop_dog()
         T.COMM = None
         algo.env.close()
     per_iter = {k: dict(calls_per_iteration=v["calls"] / iters, ms_per_iteration=v["total_ms"] / iters, mean_ms=v["mean_ms"], max_ms=v["max_ms"]) for k, v in comm.items()}

@@ -905,8 +905,18 @@ class TRPO:
         return ck.get("extra"), restored
 
 
-def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajectory=None, seed=1, **kw):
-    """trpo_cassie.py:12-42 on the batched MI355X environment."""
+def broadcast_initial_policy(algo):
+    """Rank 0's initial parameters are authoritative (a collective: every rank must call it)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        theta = flat_params(algo.policy)
+        dist.broadcast(theta, 0)
+        set_flat_params(algo.policy, theta)
+
+
+def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajectory=None, seed=1, sync_policy=True, **kw):
+    """trpo_cassie.py:12-42 on the batched MI355X environment.  sync_policy=False: NOTHING collective happens in here (the env, its workspaces, the
+    policy are local allocations that can fail on one rank alone); the caller agrees on success across ranks first and then calls
+    broadcast_initial_policy(algo) (bench.py's TRPO stage)."""
     from .vec_env import CassieVecEnv
     env = CassieVecEnv(n_envs, kind=kind, control_mode=control_mode, n_substeps=10, auto_reset=True, device=device, trajectory=trajectory)
     env.use_torch_stream()
@@ -915,12 +925,10 @@ def make_cassie_trpo(n_envs, kind="walk", control_mode="PD", device=0, trajector
     torch.manual_seed(seed)  # trpo_cassie.py:53 seed=1: every rank builds the same initial policy ...
     obs_w = env.observation_space.shape[0]  # what step() emits (26 for both kinds); the policy is sized from the env, as trpo_cassie.py does through env.spec
     policy = GaussianMLPPolicy(obs_w, env.adim, (32, 32), init_std=2.0).to(dev)
-    if dist.is_initialized() and dist.get_world_size() > 1:  # ... and rank 0's parameters are authoritative anyway
-        theta = flat_params(policy)
-        dist.broadcast(theta, 0)
-        set_flat_params(policy, theta)
     act_map = NormalizedActions(env.action_space.low, env.action_space.high, dev)
     algo = TRPO(lambda a: env.step(a, bufs), lambda: env.reset(bufs), policy, LinearFeatureBaseline(), n_envs, obs_w, act_map, seed=seed,
                 env_reset_masked=lambda m: env.reset(bufs, mask=m), **kw)
     algo.env = env
+    if sync_policy:   # ... and rank 0's parameters are authoritative anyway
+        broadcast_initial_policy(algo)
     return algo

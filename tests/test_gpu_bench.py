@@ -182,10 +182,24 @@ def test_trpo_stage_is_skipped_on_every_rank_when_one_cannot_construct_it():
     the others waiting in a broadcast.  Rank 1 is made to fail its construction: the ranks agree (all_reduce MIN) to skip, the run ends with rc 0,
     ONE JSON line, the headline measured before the stage intact and the row saying why it was skipped."""
     env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_HOOKS="1", CASSIE_TEST_TRPO_FAIL_RANK="1")
-    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2"], env, timeout=600)
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2", "--trpo-timeout", "60"], env, timeout=150, attempts=1)
     assert rc == 0, err[-2000:]
     line = _line(out)
     assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1
     assert line["n_gpus"] == 2 and line["finite"] and line["value"] > 0 and line["config"]["first_tier"] == "g16"
     row = line["config"]["trpo_outer_loop"]
     assert row["skipped"] and "another rank" in row["error"] and line["config"]["trpo_outer_loop_env_steps_per_s"] is None
+
+
+def test_headline_survives_a_rank_that_dies_inside_the_trpo_stage():
+    """... and a rank that dies INSIDE the stage (after the agreement) takes the run down with a non-zero exit -- but rank 0, told to terminate by the
+    launcher while it waits in a collective, still prints the headline it measured before the stage, with the reason in the TRPO row."""
+    import time
+    env = dict(CASSIE_DEVICE_MAP="0,0", CASSIE_BACKEND="gloo", CASSIE_TEST_HOOKS="1", CASSIE_TEST_TRPO_DIE_RANK="1")
+    t0 = time.time()
+    rc, out, err = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "2048", "--no-cpu-baseline", "--trpo-iters", "2", "--trpo-timeout", "60"], env,
+                        timeout=150, attempts=1)
+    assert rc != 0 and rc != 124 and time.time() - t0 < 120, (rc, err[-1500:])
+    line = _line(out)
+    assert line["n_gpus"] == 2 and line["finite"] and line["value"] > 0
+    assert "error" in line["config"]["trpo_outer_loop"] and "TRPO stage" in line["config"]["trpo_outer_loop"]["error"]
