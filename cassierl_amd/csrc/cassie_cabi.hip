@@ -65,6 +65,7 @@ struct CassieVec {
   int seg_mode = -1;                         // CASSIE2D_SEGMENTS=0/1 (A/B, tests): never / always in segments while robots are down; -1: by the count below
   unsigned* pend_hint = nullptr;             // pinned host words [64]: estimated environments that left the first tier in launch serial & 63 (classify_pending_kernel)
   unsigned* pend_hint_dev = nullptr;
+  unsigned* pend_count = nullptr;            // device [130]: the launch's running sum and arrival ticket, per-serial sums and tags (classify_pending_kernel)
   unsigned pend_rate = 0;                    // hand-overs per launch, estimated from the last 48 launches' words
   bool reset_packed = true;                  // CASSIE2D_RESET_PACKED=0: CassieVecReset with one wavefront per environment only (A/B, tests)
   uint8_t* need_slow = nullptr;              // [n] written by the packed reset kernel: environments the wave-per-environment reset takes
@@ -150,7 +151,7 @@ bool seg_resources(CassieVec* h) {
 void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) {
   cassie::VecParams p = pin;
   p.deep_hint = h->deep_hint_dev; p.serial = (int)++h->serial;   // the kernels only store the word; the comparison below is unsigned
-  p.pend_hint = h->pend_hint_dev;
+  p.pend_hint = h->pend_hint_dev; p.pend_count = h->pend_count;
   if (h->pend_hint) {
     // estimated hand-overs of the recent launches, one pinned word per launch (ring of 64, read without synchronisation: a stale value
     // changes the schedule, never a result).  The host runs many launches ahead of the device, so the words of the newest launches
@@ -439,6 +440,7 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   if (hipHostMalloc((void**)&h->pend_hint, 64 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
   for (int k = 0; k < 64; k++) h->pend_hint[k] = 0;
   if (hipHostGetDevicePointer((void**)&h->pend_hint_dev, h->pend_hint, 0) != hipSuccess) return bail(CASSIE_EHIP);
+  if (hipMalloc(&h->pend_count, 130 * sizeof(unsigned)) != hipSuccess || hipMemset(h->pend_count, 0xFF, 130 * sizeof(unsigned)) != hipSuccess || hipMemset(h->pend_count, 0, 2 * sizeof(unsigned)) != hipSuccess) return bail(CASSIE_EHIP);
   { const char* e = getenv("CASSIE2D_RESET_PACKED"); if (e && e[0] == '0') h->reset_packed = false; }
   if (hipMalloc(&h->need_slow, n) != hipSuccess) return bail(CASSIE_EHIP);
   if (hipHostMalloc((void**)&h->deep_hint, sizeof(int), hipHostMallocMapped) != hipSuccess) return bail(CASSIE_EHIP);
@@ -457,7 +459,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->duo_ws); hipFree(h->stats); hipFree(h->phase);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->duo_ws); hipFree(h->pend_count); hipFree(h->stats); hipFree(h->phase);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);

@@ -729,10 +729,26 @@ __global__ void __launch_bounds__(64, 2) classify_pending_kernel(VecParams p, in
   const bool valid = env < p.n_envs;
   const int left = valid ? (pending[env] & PENDING_COUNT) : 0;
   const unsigned long long some = __ballot(left > 0 && l == 0);
+  // how many left the first tier, for the host's choice of schedule: an ESTIMATE from every 64th workgroup, summed in DEVICE memory
+  // (agent-scope atomics) and handed to the host by ONE plain store of the launch's total -- the last sampling workgroup to arrive writes
+  // the pinned word (r06; until r05 every sampling workgroup did a system-scope atomic add on the pinned word itself, which needs PCIe
+  // atomics: where the platform lacks them the hint stayed 0 and the segmented schedule was never chosen, silently).
+  if (lane == 0 && p.pend_hint && p.pend_count && (blockIdx.x & 63) == 0) {
+    if (some) __hip_atomic_fetch_add(p.pend_count, 64u * (unsigned)__popcll(some), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned samplers = (gridDim.x + 63u) >> 6;
+    if (__hip_atomic_fetch_add(p.pend_count + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == samplers - 1u) {
+      const unsigned total = __hip_atomic_exchange(p.pend_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.pend_count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // an Env.step in segments classifies once per segment under ONE serial: the word carries the step's running sum (kept on the device:
+      // [2 + slot] the sum, [66 + slot] the serial it belongs to; only this one thread of this one launch touches them)
+      const unsigned slot = (unsigned)p.serial & 63u;
+      if (p.pend_count[66 + slot] != (unsigned)p.serial) { p.pend_count[66 + slot] = (unsigned)p.serial; p.pend_count[2 + slot] = 0u; }
+      const unsigned sum = p.pend_count[2 + slot] + total;
+      p.pend_count[2 + slot] = sum;
+      *(volatile unsigned*)(p.pend_hint + slot) = sum;   // plain store to host memory
+    }
+  }
   if (some == 0) return;
-  // how many left the first tier, for the host's choice of schedule: an ESTIMATE from every 64th workgroup (an atomic on host memory
-  // costs microseconds: counted by every workgroup, 270 hand-overs per step cost the all-fallen floor 7 %)
-  if (lane == 0 && p.pend_hint && (blockIdx.x & 63) == 0) __hip_atomic_fetch_add(p.pend_hint + (p.serial & 63), 64u * (unsigned)__popcll(some), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   EnvLds& sm = sm4[g];
   const double* st = p.state + (valid ? (size_t)env : 0) * ENV_STRIDE;
   LaneConst c;

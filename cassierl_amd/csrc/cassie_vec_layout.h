@@ -73,7 +73,8 @@ struct VecParams {
   int pending_pick;       // which entries of `pending` this launch takes: PICK_ALL, PICK_DEEP (flagged PENDING_DEEP only), PICK_SHALLOW
   int* deep_hint;         // host-visible word or null: `serial` is stored there whenever an environment needs the wave-per-environment kernel
   int serial;             // launch counter of the handle (scheduling hint only, see launch_physics_tiers)
-  unsigned* pend_hint;    // host-visible [64]: estimated hand-overs of launch `serial` in word serial & 63 (classify_pending_kernel adds to it; scheduling hint only) or null
+  unsigned* pend_count;   // device [130]: [0] running sum of the current classify_pending launch, [1] arrival ticket of its sampling workgroups (both zero between launches), [2..65] per-serial sums, [66..129] their serials
+  unsigned* pend_hint;    // host-visible [64]: estimated hand-overs of launch `serial` in word serial & 63 (classify_pending_kernel's last sampling workgroup stores the launch's total there: a plain store; scheduling hint only) or null
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*

@@ -204,3 +204,31 @@ def test_workspace_claim_table_falling_robots_and_terrain(monkeypatch):
         if not hf:
             assert outs[0][3]["cleanup_substeps"] > 0
         pair.close(); duo.close()
+
+
+def test_handover_estimate_reaches_the_host_while_robots_are_down():
+    """The segment scheduler's input: classify_pending_kernel's estimate of the environments that left the first tier, summed in device memory and
+    handed to the host by ONE plain store per launch (r06; until r05 a system-scope atomic add on pinned host memory, which needs PCIe atomics and
+    left the hint at zero -- and the segmented order unused -- where the platform lacks them).  Robots under random torques without resets are on
+    the ground after ~150 Env.steps; the estimate must then be of the order of the hand-overs the counters report."""
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_ON
+    n = 8192
+    env = CassieVecEnv(n, kind="stand", control_mode="Torque", n_substeps=10, auto_reset=False, flags=LEG_TIER_ON)
+    bufs = env.alloc()
+    env.reset(bufs)
+    ids = torch.arange(n, device="cuda:0")
+    for t in range(220):
+        env.step(R.random_actions(3, ids, t, -TQ, TQ), bufs)
+    env.synchronize()
+
+    env.reset_counters()
+    for t in range(220, 300):
+        env.step(R.random_actions(3, ids, t, -TQ, TQ), bufs)
+    env.synchronize()
+    info, c = env.tier_info(), env.counters()
+    per_launch = c["cleanup_substeps"] / 80.0 / 10.0   # env-substeps handed over per Env.step / substeps left on average ~ environments
+    assert c["cleanup_substeps"] > 0 and info["handovers_per_launch"] > 0, (info, c)
+    assert 0.05 * per_launch < info["handovers_per_launch"] < 40.0 * per_launch + 64, (info["handovers_per_launch"], per_launch)
+    env.close()
