@@ -388,12 +388,23 @@ def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn,
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = env.counters()
+    row = dict(workload=name, note=note, envs=n, warmup_steps=warmup, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3,
+               cleanup_frac=c["cleanup_frac"], k1_frac=c["k1_frac"], nonfinite_resets=c["nonfinite_resets"],
+               episodes_terminated_per_env_step=float(dones.item()) / (n * steps))
+    if mode == "OSC":
+        # BASELINE.md C3 "QP iterations / step": active-set iterations of the OSC QP per substep, counted in a pass of its own BEHIND the timed region
+        # (the controllers store nothing until the first qp_iterations() call), same action stream
+        env.qp_iterations()
+        for t in range(min(steps, 10)):
+            env.step(acts[t], out)
+        qi = env.qp_iterations()
+        row["qp_iterations_per_substep"] = dict(mean=qi["mean"], max=qi["max"], worst_env_mean=qi["worst_env_mean"], stepOsc_calls=qi["calls"],
+                                                note="primal active-set iterations to KKT convergence (cap 60), hot-started from the previous substep's working set; "
+                                                     "the reference gives qpOASES 100 working-set changes / 500 us (OSC_RBDL.cpp:245-246)")
     q, v = env.get_state_host()
     env.close()
-    return dict(workload=name, note=note, envs=n, warmup_steps=warmup, steps=steps, env_steps_per_s=n * steps / dt, ms_per_step=dt / steps * 1e3,
-                cleanup_frac=c["cleanup_frac"], k1_frac=c["k1_frac"], nonfinite_resets=c["nonfinite_resets"],
-                episodes_terminated_per_env_step=float(dones.item()) / (n * steps),
-                finite=bool(np.isfinite(q).all() and np.isfinite(v).all()))
+    row["finite"] = bool(np.isfinite(q).all() and np.isfinite(v).all())
+    return row
 
 
 def extra_workloads(traj, n):

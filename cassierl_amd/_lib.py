@@ -19,7 +19,7 @@ EXPORTS = [
     "GetOperationalSpaceState", "Display", "Render",
     # batched ABI (include/cassie_vec.h)
     "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
-    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecTierInfo", "CassieVecSetTrajectory", "CassieVecSetHeightField", "CassieVecReset", "CassieVecResetTo",
+    "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecTierInfo", "CassieVecQpIterations", "CassieVecSetTrajectory", "CassieVecSetHeightField", "CassieVecReset", "CassieVecResetTo",
     "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecDebugWorkspaceHost", "CassieVecTimeSteps",
@@ -67,6 +67,8 @@ def load():
     L.CassieVecSynchronize.argtypes = [vp]
     L.CassieVecGetCounters.argtypes = [vp, ct.POINTER(ct.c_uint64)]
     L.CassieVecResetCounters.argtypes = [vp]
+    if hasattr(L, "CassieVecQpIterations"):
+        L.CassieVecQpIterations.argtypes = [vp, ct.POINTER(ct.c_double)]
     if hasattr(L, "CassieVecTierInfo"):   # (absent from A/B libraries built from earlier rounds' sources: CASSIE2D_LIB)
         L.CassieVecTierInfo.argtypes = [vp, ct.POINTER(ct.c_uint64)]
     L.CassieVecSetTrajectory.argtypes = [vp, dp, dp, ct.c_int]

@@ -65,6 +65,7 @@ struct CassieVec {
   int seg_mode = -1;                         // CASSIE2D_SEGMENTS=0/1 (A/B, tests): never / always in segments while robots are down; -1: by the count below
   unsigned* pend_hint = nullptr;             // pinned host words [64]: estimated environments that left the first tier in launch serial & 63 (classify_pending_kernel)
   unsigned* pend_hint_dev = nullptr;
+  unsigned* qp_stats = nullptr;              // [3 n]: OSC QP iteration statistics (allocated by the first CassieVecQpIterations call: the controllers only count when someone reads)
   unsigned* pend_count = nullptr;            // device [130]: the launch's running sum and arrival ticket, per-serial sums and tags (classify_pending_kernel)
   unsigned pend_rate = 0;                    // hand-overs per launch, estimated from the last 48 launches' words
   bool reset_packed = true;                  // CASSIE2D_RESET_PACKED=0: CassieVecReset with one wavefront per environment only (A/B, tests)
@@ -121,6 +122,7 @@ cassie::VecParams make_params(CassieVec* h) {
   p.ovf = h->ovf;
   p.ovf_stride = OVF_STRIDE;
   p.stats = h->stats;
+  p.qp_stats = h->qp_stats;
   p.hf = h->hf;
   p.phase = h->phase;
   return p;
@@ -459,7 +461,7 @@ void CassieVecFree(CassieVec* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipFree(h->state); hipFree(h->traj_qpos); hipFree((void*)h->hf.h); hipFree(h->d_act); hipFree(h->d_obs); hipFree(h->d_rew);
-  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->duo_ws); hipFree(h->pend_count); hipFree(h->stats); hipFree(h->phase);
+  hipFree(h->d_done); hipFree(h->d_q); hipFree(h->d_v); hipFree(h->d_dbg); hipFree(h->ovf); hipFree(h->ovf_dbg); hipFree(h->pending); hipFree(h->pending_leg); hipFree(h->duo_ws); hipFree(h->qp_stats); hipFree(h->pend_count); hipFree(h->stats); hipFree(h->phase);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -500,6 +502,30 @@ int CassieVecGetCounters(CassieVec* h, uint64_t* out4) {
   out4[1] = host[cassie::STAT_CLEANUP_SUBSTEPS];
   out4[2] = host[cassie::STAT_K1_SUBSTEPS];
   out4[3] = host[cassie::STAT_NONFINITE];
+  return CASSIE_OK;
+}
+
+int CassieVecQpIterations(CassieVec* h, double* out4) {
+  if (!h || !out4) return CASSIE_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->n;
+  out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+  if (!h->qp_stats) {   // first call: start counting
+    HIPCHK(h, hipMalloc(&h->qp_stats, 3 * n * sizeof(unsigned)));
+    HIPCHK(h, hipMemsetAsync(h->qp_stats, 0, 3 * n * sizeof(unsigned), h->stream));
+    return CASSIE_OK;
+  }
+  std::vector<unsigned> host(3 * n);
+  HIPCHK(h, hipMemcpyAsync(host.data(), h->qp_stats, 3 * n * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->qp_stats, 0, 3 * n * sizeof(unsigned), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double sum = 0.0, calls = 0.0, mx = 0.0, env_mean_max = 0.0;
+  for (size_t e = 0; e < n; e++) {
+    sum += host[e]; calls += host[2 * n + e];
+    if (host[n + e] > mx) mx = host[n + e];
+    if (host[2 * n + e]) { const double m = (double)host[e] / host[2 * n + e]; if (m > env_mean_max) env_mean_max = m; }
+  }
+  out4[0] = calls > 0 ? sum / calls : 0.0; out4[1] = mx; out4[2] = calls; out4[3] = env_mean_max;
   return CASSIE_OK;
 }
 

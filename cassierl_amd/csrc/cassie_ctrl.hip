@@ -260,10 +260,18 @@ __device__ __forceinline__ void apply_nc(const CS& cs, const double (&P4)[16], c
 // (OSC_RBDL.cpp:276-280): bits 0..13 = variable i sits on a bound, bits 14..27 = ... on its lower bound, bit 28 = valid; 0 = cold start (all
 // friction-cone generators at 0, motors free).  The QP is strictly convex, so the warm start changes the number of active-set
 // iterations (typically 8 -> 1 or 2), not the solution.
+// BASELINE.md C3 "QP iterations / step": per environment the sum, the maximum and the number of StepOsc calls since the counters were cleared
+// (CassieVecQpIterations; [n] sums, [n] maxima, [n] calls; each environment is written by the one row that owns it)
+__device__ __forceinline__ void qp_stats_add(unsigned* s, int n, int env, int iters) {
+  s[env] += (unsigned)iters;
+  if ((unsigned)iters > s[n + env]) s[n + env] = (unsigned)iters;
+  s[2 * n + env] += 1u;
+}
+
 constexpr unsigned QP_COLD_WSET = 0x3FC0u | (0x3FFFu << 14);
 template <class SM, class CS>
 __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int l, bool rowok, int rowid, unsigned& wset, bool noshort = false,
-                                         PhaseClock* pc = nullptr) {
+                                         PhaseClock* pc = nullptr, int* qp_iterations = nullptr) {
   const int lane = rowok ? l : 63;
   double P4[16], g4[4];
   ctrl_dyn(sm, cs, c, l, rowok, P4, g4, noshort);
@@ -350,10 +358,12 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
   double z = bound ? (atlo ? lo : hi) : 0.0;  // feasible start: bound variables on their bound, free ones at 0 (inside every box)
   if (l >= 6) z = 0.0;                          // generators have no upper bound
   bool busy = rowok;  // uniform inside a row
+  int my_iters = 0;   // active-set iterations of THIS row's QP (the loop runs until the slowest row of the wavefront is done)
   PHASE_MARK(*pc, 3);
   ctrl_fence();
   for (int it = 0; it < 60; it++) {
     if (__ballot(busy) == 0) break;
+    my_iters += busy ? 1 : 0;
 #ifdef CASSIE_PHASE_TIMING
     pc->acc[8] += 1;
 #endif
@@ -423,6 +433,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
                                                       // every call with all feet loaded re-freed the 8 generators one by one)
   }
   if (lane < 6) cs.u[lane] = z;
+  if (qp_iterations) *qp_iterations = my_iters;
   lds_sync();
   ctrl_fence();
   PHASE_MARK(*pc, 4);
@@ -641,10 +652,12 @@ __global__ void __launch_bounds__(64, 1) env_ctrl_kernel(VecParams p, const doub
   if (lane < 13) { st[ES_KQ + lane] = sm.q[lane]; st[ES_KV + lane] = sm.v[lane]; }  // DynamicModel::setState
   lds_sync();
   ctrl_fence();
-  if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort);
+  int qpit = 0;
+  if (CTRL == 2) ctrl_osc(sm, cs, c, lane, lane < 16, lane >> 4, wset, noshort, nullptr, &qpit);
   else ctrl_jacobian(sm, cs, c, lane, lane < 16, lane >> 4, p.debug ? p.debug + (size_t)env * DBG_STRIDE : nullptr, noshort);
   if (lane < NU) st[ES_CTRL + lane] = cs.u[lane];  // mj_data->ctrl (pre-clamp), consumed by the physics kernel
   if (CTRL == 2 && lane == 0) st[ES_QPWSET] = (double)wset;
+  if (CTRL == 2 && lane == 0 && p.qp_stats) qp_stats_add(p.qp_stats, p.n_envs, env, qpit);
 }
 
 }  // namespace cassie

@@ -88,11 +88,13 @@ __global__ void __launch_bounds__(64, 2) env_ctrl_g16_kernel(VecParams p, const 
   if (valid && l < NV) { st[ES_KQ + l] = sm.q[l]; st[ES_KV + l] = sm.v[l]; }  // DynamicModel::setState
   lds_sync();
   PHASE_MARK(pc, 0);
-  if (CTRL == 2) ctrl_osc(sm, cs, c, l, valid, g, wset, noshort, &pc);
+  int qpit = 0;
+  if (CTRL == 2) ctrl_osc(sm, cs, c, l, valid, g, wset, noshort, &pc, &qpit);
   else ctrl_jacobian(sm, cs, c, l, valid, g, nullptr, noshort);
   if (valid) {
     if (l < NU) st[ES_CTRL + l] = cs.u[l];  // mj_data->ctrl (pre-clamp), consumed by the physics kernel
     if (CTRL == 2 && l == 0) st[ES_QPWSET] = (double)wset;
+    if (CTRL == 2 && l == 0 && p.qp_stats) qp_stats_add(p.qp_stats, p.n_envs, env, qpit);
   }
   pc.flush(p.phase, lane);
 }

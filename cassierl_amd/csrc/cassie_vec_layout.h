@@ -77,6 +77,7 @@ struct VecParams {
   unsigned* pend_hint;    // host-visible [64]: estimated hand-overs of launch `serial` in word serial & 63 (classify_pending_kernel's last sampling workgroup stores the launch's total there: a plain store; scheduling hint only) or null
   Terrain hf;             // terrain under the robots (PD / torque modes); hf.h == null: the flat floor of the MJCF
   unsigned long long* phase;  // profiling builds only (-DCASSIE_PHASE_TIMING): [16] shader cycles accumulated per code phase
+  unsigned* qp_stats;         // [3 n_envs] or null: per environment sum / maximum of the OSC QP's active-set iterations and StepOsc calls (CassieVecQpIterations)
   unsigned long long* stats;  // [STAT_N] event counters of this handle (rare-path atomics only), see STAT_*
   int n_envs, adim, n_sub, flags, env_kind, auto_reset;
 };

@@ -122,6 +122,13 @@ class CassieVecEnv:
         return dict(first_tier=self.TIERS[int(out[0])], duo_table_slots=int(out[1]), duo_workspace_bytes=int(out[2]), ws_probes=int(out[3]),
                     handovers_per_launch=int(out[4]))
 
+    def qp_iterations(self):
+        """Active-set iterations of the OSC QP since the previous call (the first call starts the counting and returns zeros):
+        mean per StepOsc call and environment, maximum, calls counted, largest per-environment mean."""
+        out = (ct.c_double * 4)()
+        self._chk(self.L.CassieVecQpIterations(self.h, out))
+        return dict(mean=out[0], max=int(out[1]), calls=int(out[2]), worst_env_mean=out[3])
+
     def debug_workspace_host(self):
         """The 64-environments kernel's hand-over workspace as the last launch left it: array [wavefront slot][W_N slots][64 lanes] (diagnosis)."""
         n = ct.c_uint64()

@@ -81,6 +81,14 @@ int CassieVecSynchronize(CassieVec* h);
 int CassieVecGetCounters(CassieVec* h, uint64_t* out4);
 int CassieVecResetCounters(CassieVec* h);
 
+/* Active-set iterations of the OSC QP (StepOsc / the scripted standing controller; BASELINE.md C3 "QP iterations / step"; the reference's
+ * qpOASES call has a budget of 100 working-set changes / 500 us on a hot start, OSC_RBDL.cpp:245-246 -- here the active set runs to KKT
+ * convergence, at most 60 iterations).  The FIRST call starts the counting (the controllers store nothing before it) and returns zeros; every
+ * later call returns the statistics since the previous one and clears them:
+ *   out4[0] mean iterations per StepOsc call and environment   out4[1] maximum over all calls   out4[2] calls counted
+ *   out4[3] largest per-environment mean */
+int CassieVecQpIterations(CassieVec* h, double* out4);
+
 /* Which kernel tier this handle runs first, and the state of its hand-over workspace (diagnostics; bench.py labels its roofline with it):
  *   out8[0] first physics tier: 0 one wavefront per environment, 1 four environments per wavefront, 2 two lanes per environment
  *           (env_step_leg_kernel), 3 64 environments per wavefront (env_step_duo_kernel) -- chosen at create by batch size / flags / environment
