@@ -381,6 +381,46 @@ def test_failure_guard_terminates_and_resets_poisoned_envs(vec, traj, mode, wave
     env.close(); ref.close()
 
 
+@pytest.mark.parametrize("tier", ["leg", "duo"])
+@pytest.mark.parametrize("mode", ["PD", "Torque"])
+def test_failure_guard_in_the_lane_per_leg_tiers(vec, traj, mode, tier):
+    """... and in the two-lanes-per-environment and 64-environments-per-wavefront kernels (their row construction leaves out the
+    structurally zero Jacobian terms, so a non-finite velocity or warm start no longer reaches every row as 0 x Inf -- it must still trip the
+    guard through the state it produces): NaN position, infinite velocity, NaN warm start, diverged-but-finite position; neighbours in the same
+    wavefront (both groups of it) untouched, bit for bit."""
+    from cassierl_amd.vec_env import LEG_TIER_ON, DUO_TIER_ON, DUO_TIER_OFF
+    fl = LEG_TIER_ON | (DUO_TIER_ON if tier == "duo" else DUO_TIER_OFF)
+    n = 70
+    kind = "walk" if mode == "PD" else "stand"
+    env = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=fl)
+    ref = vec(n, kind=kind, control_mode=mode, n_substeps=10, auto_reset=True, flags=fl)
+    assert env.tier_info()["first_tier"] == tier
+    for e in (env, ref):
+        e.set_trajectory(traj["time"], traj["qpos"])
+        e.reset_host()
+    s = env.get_full_state_host()
+    s[1, 4] = np.nan          # qpos (left knee)
+    s[6, 13 + 2] = np.inf     # qvel (pitch)
+    s[9, 26 + 3] = np.nan     # warm start only: poisons qacc -> the state after one substep
+    s[40, 13 + 9] = np.nan    # qvel of a right-leg joint, group B of the 64-environments form
+    s[41, 3] = 5e10           # diverged, still finite
+    env.set_full_state_host(s)
+    rng = np.random.default_rng(1)
+    a = rng.uniform(env.action_space.low, env.action_space.high, (n, env.adim))
+    o, r, d = env.step_host(a)
+    o2, r2, d2 = ref.step_host(a)
+    badset = [1, 6, 9, 40, 41]
+    good = [i for i in range(n) if i not in badset]
+    assert d[badset].all() and (r[badset] == 0).all()
+    assert np.isfinite(o).all() and np.isfinite(r).all()
+    assert np.array_equal(o[good], o2[good]) and np.array_equal(r[good], r2[good]) and np.array_equal(d[good], d2[good])
+    assert env.counters()["nonfinite_resets"] == 5
+    assert np.isfinite(env.get_full_state_host()).all()
+    o3, r3, d3 = env.step_host(a)
+    assert np.isfinite(o3).all() and np.isfinite(r3).all() and env.counters()["nonfinite_resets"] == 5
+    env.close(); ref.close()
+
+
 @pytest.mark.parametrize("mode", ["PD", "Torque", "OSC", "Jacobian"])
 def test_results_do_not_depend_on_wavefront_neighbours(vec, traj, mode):
     """Four environments share a wavefront and some control flow is decided per wavefront (straight-line vs general PGS sweep,
