@@ -46,7 +46,7 @@ def dominant_kernel(n_envs, simds=1024):
 # Schema of the JSON line (the meaning of `roofline` and `cpu_baseline` changed between rounds; a reader comparing BENCH_rNN
 # files must not mix them): r01-r03 roofline = HBM (GB/s); from r04 roofline.bound = fp64_valu (useful TFLOP/s; HBM under roofline.hbm)
 # and cpu_baseline.value = the same-source AVX-512 leg (the oracle's leg under cpu_baseline.oracle).
-BENCH_SCHEMA = "r05 (roofline: fp64_valu useful flops, hbm sub-object; cpu_baseline: same-source leg with per_threads / cpu_quota, oracle nested)"
+BENCH_SCHEMA = "r06 (as r05 -- roofline: fp64_valu useful flops, hbm sub-object; cpu_baseline: same-source leg with per_threads / cpu_quota, oracle nested -- plus config.first_tier / duo_workspace_MB from CassieVecTierInfo and extra[configs[2]].qp_iterations_per_substep)"
 PREROLL_STEPS_AT_64K = int(os.environ.get("CASSIE_BENCH_PREROLL_STEPS", "300"))     # untimed Env.steps before the timed region at 65 536 envs, on top of --warmup (see worker())
 ALGO_BYTES_PER_ENV_STEP = 697 + 208  # state+action in, state+obs+reward+done out, + persisted warm-start vector
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec

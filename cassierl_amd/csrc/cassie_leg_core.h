@@ -26,6 +26,12 @@
 // src/Cassie2d/Cassie2d.cpp:86-117; mj_step of MuJoCo 1.50 configured by model/cassie2d_stiff.xml:5; Cassie2dEnv.step,
 // rllab/envs/cassie2d.py:97-225, cassie_stand2d.py:86-137); what differs is the factorisation (block elimination instead of a
 // 13x13 Gauss-Jordan) and the grouping of sums, i.e. roundings at the 1e-16 level.
+// NOT bit-faithful to MuJoCo's / the oracle's operation order in three places, all at the last-bits level and all inside the tolerance the parity
+// tests state (teacher-forced 1e-9, measured 3e-13 .. 7e-12): (1) the impedance uses x * (1 / width) where mj_makeImpedance divides (1 / width is formed
+// once per row kind and substep); (2) the middle-zone warm start of a cone uses D * (1 / cone) where mj_constraintUpdate divides; (3) Jacobian terms
+// that are STRUCTURALLY zero (a connect row has no entry on the toe dof, a contact / limit row none on the rod) are left out of the row construction
+// instead of adding 0 x value -- so a non-finite velocity or warm start no longer reaches every row as 0 x Inf = NaN; it reaches the failure guard
+// through the state it produces (tests/test_gpu_fullsize.py::test_failure_guard_in_the_lane_per_leg_tiers).
 //
 // The code is written against a small "backend" B (per-lane types D/I/M, lane-pair exchange, table gathers, per-lane LDS
 // slots) so that the SAME source is compiled (a) by hipcc with B = the gfx950 backend of cassie_kernels_leg.hip -- the
