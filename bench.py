@@ -629,8 +629,10 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s
         T.COMM = T.CommTimer() if world > 1 else None
         torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
+        roll_s = upd_s = 0.0
         for _ in range(iters):
             st = algo.train_iteration()
+            roll_s += st.get("seconds_rollout", 0.0); upd_s += st.get("seconds_update", 0.0)   # host clocks around the two halves (they include the queue's drain)
         torch.cuda.synchronize(); R.barrier(); torch.cuda.synchronize()
         dt = R.max_over_ranks(time.perf_counter() - t0, device="cuda:%d" % device)
         comm = T.COMM.summary() if T.COMM is not None else {}
@@ -648,6 +650,7 @@ def trpo_outer_loop(n, world, device, warm=4, iters=6, on_desync=None, timeout_s
                 note="TRPO iterations (rollout of 8 Env.steps + update) on %d envs per rank x %d rank(s); env-steps of the rollouts per second of the whole loop" % (n, world),
                 envs=n, envs_total=n * world, ranks=world, iterations=iters, env_steps_per_s=iters * n * world * 8 / dt, ms_per_iteration=dt / iters * 1e3,
                 samples_per_iteration=n * world * 8, kl=st.get("kl"), backtracks=st.get("backtracks"),
+                rollout_ms_per_iteration=roll_s / iters * 1e3, update_ms_per_iteration=upd_s / iters * 1e3,
                 collectives_ms=per_iter, collective_ms_per_iteration=sum(v["ms_per_iteration"] for v in per_iter.values()))
 
 

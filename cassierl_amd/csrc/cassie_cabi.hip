@@ -540,7 +540,8 @@ int CassieVecTierInfo(CassieVec* h, uint64_t* out8) {
   out8[2] = (uint64_t)h->duo_ws_bytes;
   out8[3] = host[cassie::STAT_WS_PROBES];
   out8[4] = h->pend_rate;
-  out8[5] = out8[6] = out8[7] = 0;
+  out8[5] = (uint64_t)L2::duo_workspace_slots_per_wave();
+  out8[6] = out8[7] = 0;
   return CASSIE_OK;
 }
 

@@ -43,6 +43,9 @@
 #ifndef CASSIE_DUO_VIEW_FLAG
 #define CASSIE_DUO_VIEW_FLAG 0x20000000   // (DUO_VIEW_EXPERIMENT builds only; no caller sets it)
 #endif
+#ifndef DUO_JOINT8
+#define DUO_JOINT8 1   // groups that leave the six-row path take the eight-row JOINT sweep (r06); 0: the pair sweep inline, as in r05
+#endif
 #ifndef LEG_NOUNROLL
 #define LEG_NOUNROLL _Pragma("clang loop unroll(disable)")
 #endif
@@ -229,13 +232,17 @@ template <class B> struct Duo : Core<B> {
   enum {
     W_ST = 0,                                           // 24: the lane state (q, v, warm start)
     W_ROWS = W_ST + 24, W_NROWS = 4 * NR + 3 * NR + NA + NP + 3,   // 68: the six-row subset the joint sweep takes (the forces come back in their slots)
-    W_FC = W_ROWS + W_NROWS,                            // 36: block factorisation
+    W_NROWS8 = 4 * CAP + 3 * CAP + CAP * (CAP + 1) / 2 + 3 + 3,     // 98: all eight rows of a leg, for the eight-row joint sweep (r06): the block's size
+    W_FC = W_ROWS + W_NROWS8,                           // 36: block factorisation
     W_ANCH = W_FC + 36,                                 // 4: connect anchors
-    W_MISC = W_ANCH + 4,                                // go, ncon, sweeps done
-    W_GROUP = W_MISC + 4,                               // slots per group (even: every block starts on an even slot, see put_block)
+    W_MISC = W_ANCH + 4,                                // go, ncon, sweeps done, nlim
+    W_DESC = W_MISC + 4,                                // 10: what the finish of an eight-row group needs of the descriptors that exist once per wavefront in LDS:
+                                                        //     4 joint limits (sign x (dof + 1)), third contact pair (x, z, depth), its terrain normal; [8] experiment marker
+    W_GROUP = W_DESC + 10,                              // slots per group (even: every block starts on an even slot, see put_block)
     W_N = 2 * W_GROUP
   };
-  static_assert(W_ROWS % 2 == 0 && W_FC % 2 == 0 && W_ANCH == W_FC + 36 && W_MISC % 2 == 0 && W_GROUP % 2 == 0, "blocks start on even slots; the anchors follow the factorisation");
+  static_assert(W_NROWS8 >= W_NROWS && W_NROWS8 % 2 == 0, "one rows block for both formats");
+  static_assert(W_ROWS % 2 == 0 && W_FC % 2 == 0 && W_ANCH == W_FC + 36 && W_MISC % 2 == 0 && W_DESC % 2 == 0 && W_GROUP % 2 == 0, "blocks start on even slots; the anchors follow the factorisation");
   typedef typename B::W W;
   template <class F> static LEG_FN void rows_each(Sub& s, int base, F&& f) {
     int k = base + W_ROWS;
@@ -371,10 +378,269 @@ template <class B> struct Duo : Core<B> {
     if (B::any(mine)) {
       B::wput_if(wl, W_ROWS, tl, mine); B::wput_if(wr, W_ROWS, tr, mine);
       B::wst_if(wl, W_MISC + 2, B::toD(niter), mine); B::wst_if(wr, W_MISC + 2, B::toD(niter), mine);
-      B::wst_if(wl, W_MISC + 3, D(1.0), mine);   // the group's spare slot: "this path ran" (the guard test reads it back; nothing else writes it)
+      B::wst_if(wl, W_DESC + 8, D(1.0), mine);   // the group's marker slot: "this path ran" (the guard test reads it back; nothing else writes it)
     }
   }
 #endif
+
+  // ------------------------------------------------------------------------------------------------ eight-row joint sweep (r06)
+  // Until r05 a group in which some environment had a joint limit active or a third contact pair on a leg ran the PAIR sweep of cassie_leg_core.h
+  // for that substep (both lanes of an environment execute every step, one keeps it) -- under random torques 95-99.6 % of the groups
+  // (profiles: tools/small_stats.py).  Here such a group hands ALL EIGHT row slots of its legs to the workspace and the wavefront runs one JOINT sweep
+  // with a lane per environment over eight rows per leg: the step functions of `sub_sweeps` (connect, joint limit, contact pair) for one lane, in the
+  // pair sweep's order -- connect L, connect R, limits L, limits R, pairs L, pairs R -- with the row kinds as per-lane masks (limit j at slot 7 - j while
+  // nlim > j, pair P at slots 2 + 2P / 3 + 2P while ncon > P: what sub_setup assigns).  ~190 doubles of row data per lane: the rows are transposed
+  // STRAIGHT from the workspace in chunks (never both groups' Sub in registers), and the allocator keeps part of them in the accumulator file.
+  // A group on its feet that shares the wavefront with such a group is swept with it (its slots 6, 7 are empty rows); results are bit-identical to
+  // the pair sweep either way (same step functions, contraction off, same order, the two legs' cost accumulators added as the pair sweep adds them).
+  struct LegRows8 {
+    D r[CAP], f[CAP], ut[CAP][3], Al[CAP * (CAP + 1) / 2], Adiag[CAP], Ainv[CAP], Ant[3];
+    M pair[3], lim[4];
+  };
+  // order of the 98 slots of the eight-row block: f 0..7 | r 8..15 | Adiag 16..23 | Ainv 24..31 | ut 32..55 | Al 56..91 (packed as in Sub) | Ant 92..94 | a~ 95..97
+  template <int K> static LEG_FN D& sfld8(Sub& s) {
+    if constexpr (K < 8) return s.f[K];
+    else if constexpr (K < 16) return s.r[K - 8];
+    else if constexpr (K < 24) return s.Adiag[K - 16];
+    else if constexpr (K < 32) return s.Ainv[K - 24];
+    else if constexpr (K < 56) return s.ut[(K - 32) / 3][(K - 32) % 3];
+    else if constexpr (K < 92) return s.Al[K - 56];
+    else if constexpr (K < 95) return s.Ant[K - 92];
+    else if constexpr (K == 95) return s.a0;
+    else if constexpr (K == 96) return s.a1;
+    else return s.a2;
+  }
+  template <int K> static LEG_FN D& lfld8(LegRows8& g, D (&a)[3]) {
+    if constexpr (K < 8) return g.f[K];
+    else if constexpr (K < 16) return g.r[K - 8];
+    else if constexpr (K < 24) return g.Adiag[K - 16];
+    else if constexpr (K < 32) return g.Ainv[K - 24];
+    else if constexpr (K < 56) return g.ut[(K - 32) / 3][(K - 32) % 3];
+    else if constexpr (K < 92) return g.Al[K - 56];
+    else if constexpr (K < 95) return g.Ant[K - 92];
+    else return a[K - 95];
+  }
+  static LEG_FN void put_rows8(W ws, int base, Sub& s) {
+    D t[W_NROWS8];
+    lfor<0, W_NROWS8>([&](auto kk) { constexpr int K = decltype(kk)::value; t[K] = sfld8<K>(s); });
+    put_block(ws, base + W_ROWS, t);
+  }
+  // a group on its feet (six-row format in the workspace) re-written in the eight-row format: its slots 6, 7 are empty rows
+  static LEG_FN void widen_rows(W ws, int base) {
+    Sub s;
+    get_rows(ws, base, s);
+    lfor<NR, CAP>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      s.r[Ii] = 0.0; s.f[Ii] = 0.0; s.Adiag[Ii] = 1.0; s.Ainv[Ii] = 1.0;
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; s.ut[Ii][Bc] = 0.0; });
+      lfor<0, CAP>([&](auto jj) { constexpr int Jj = decltype(jj)::value; s.Al[symidx(CAP, Ii, Jj)] = 0.0; });
+    });
+    s.Ant[2] = 0.0;
+    B::fence();
+    put_rows8(ws, base, s);
+    B::wst(ws, base + W_MISC + 3, D(0.0));   // nlim
+  }
+  // a group that does not run in this pass: empty rows, nobody goes
+  static LEG_FN void put_idle8(W ws, int base) {
+    Sub s;
+    idle_rows(s);
+    lfor<NR, CAP>([&](auto ii) {
+      constexpr int Ii = decltype(ii)::value;
+      s.r[Ii] = 0.0; s.f[Ii] = 0.0; s.Adiag[Ii] = 1.0; s.Ainv[Ii] = 1.0;
+      lfor<0, 3>([&](auto bb) { constexpr int Bc = decltype(bb)::value; s.ut[Ii][Bc] = 0.0; });
+    });
+    lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; lfor<Ii, CAP>([&](auto jj) { constexpr int Jj = decltype(jj)::value; s.Al[symidx(CAP, Ii, Jj)] = 0.0; }); });
+    s.Ant[2] = 0.0;
+    put_rows8(ws, base, s);
+    B::wst2(ws, base + W_MISC, D(0.0), D(0.0));
+    B::wst(ws, base + W_MISC + 3, D(0.0));
+  }
+  // the descriptors that exist once per wavefront in LDS (joint limits, third contact pair): parked for the group's finish, restored before it
+  template <bool HF> static LEG_FN void put_desc(typename B::Lds& lds, W ws, int base) {
+    D t[8];
+    lfor<0, 4>([&](auto jj) {
+      constexpr int Jj = decltype(jj)::value;
+      D pos, sgn, invw; I lj;
+      lds.ld_lim(Jj, pos, sgn, invw, lj);
+      t[Jj] = sgn * B::toD(lj + I(1));
+    });
+    D px, pz, dist, invw; I depth;
+    lds.ld_pair(2, px, pz, dist, invw, depth);
+    t[4] = px; t[5] = pz; t[6] = B::toD(depth); t[7] = 0.0;
+    if constexpr (HF) t[7] = lds.ld_nrm(2);
+    put_block(ws, base + W_DESC, t);
+  }
+  template <bool HF> static LEG_FN void get_desc(typename B::Lds& lds, W ws, int base) {
+    D t[8];
+    get_block(ws, base + W_DESC, t);
+    const M all = (B::leg() == I(0)) | !(B::leg() == I(0));
+    lfor<0, 4>([&](auto jj) {
+      constexpr int Jj = decltype(jj)::value;
+      const D c = t[Jj];
+      lds.st_lim(Jj, D(0.0), B::sel(c < 0.0, D(-1.0), D(1.0)), D(0.0), B::toint(B::fabs(c)) - I(1), all);
+    });
+    lds.st_pair(2, t[4], t[5], D(0.0), D(0.0), B::toint(t[6]), all);
+    if constexpr (HF) lds.st_nrm(2, t[7], all);
+  }
+
+  static LEG_FN void joint_sweeps8(LegRows8& L, LegRows8& R, D& a0, D& a1, D& a2, M go, I& niter_out) {
+    const D mu = CP_CONTACT_MU;
+    const D scale = 1.0 / (CP_MEANINERTIA * LNV);
+    M sweeping = go;
+    bool anyLim[2][4], anyPair[2][3];
+    lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; anyLim[0][Jj] = B::any(go & L.lim[Jj]); anyLim[1][Jj] = B::any(go & R.lim[Jj]); });
+    lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; anyPair[0][P] = B::any(go & L.pair[P]); anyPair[1][P] = B::any(go & R.pair[P]); });
+    D accL = 0.0, accR = 0.0;
+    D rdenL[3], rdenR[3];
+    auto eq_step = [&](LegRows8& g, D& acc, auto ss) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int S = decltype(ss)::value;
+      const D res = B::fma(g.ut[S][2], a2, B::fma(g.ut[S][1], a1, B::fma(g.ut[S][0], a0, g.r[S])));
+      D d = -(res * g.Ainv[S]);
+      D chg = d * B::fma(g.Adiag[S], d, res);   // (Adiag of a connect row holds A_ii / 2: sub_setup)
+      d = B::sel(sweeping, d, D(0.0)); chg = B::sel(sweeping, chg, D(0.0));
+      a0 = B::fma(g.ut[S][0], d, a0); a1 = B::fma(g.ut[S][1], d, a1); a2 = B::fma(g.ut[S][2], d, a2);
+      acc = acc + chg;
+      g.f[S] = g.f[S] + d;
+      lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; g.r[Ii] = B::fma(g.Al[symidx(CAP, Ii, S)], d, g.r[Ii]); });
+    };
+    auto lim_step = [&](LegRows8& g, D& acc, auto jj) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int Jj = decltype(jj)::value;
+      constexpr int S = 7 - Jj;
+      const M mine = sweeping & g.lim[Jj];
+      const D res = B::fma(g.ut[S][2], a2, B::fma(g.ut[S][1], a1, B::fma(g.ut[S][0], a0, g.r[S])));
+      const D cand = B::fmax(B::fma(-res, g.Ainv[S], g.f[S]), D(0.0));
+      D d = cand - g.f[S];
+      D chg = d * B::fma(0.5 * g.Adiag[S], d, res);
+      const M keep = mine & (chg <= 1e-10);
+      d = B::sel(keep, d, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+      a0 = B::fma(g.ut[S][0], d, a0); a1 = B::fma(g.ut[S][1], d, a1); a2 = B::fma(g.ut[S][2], d, a2);
+      acc = acc + chg;
+      g.f[S] = g.f[S] + d;
+      lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; g.r[Ii] = B::fma(g.Al[symidx(CAP, Ii, S)], d, g.r[Ii]); });
+    };
+    auto pair_step = [&](LegRows8& g, D& acc, const D (&rden)[3], auto pp) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int P = decltype(pp)::value;
+      constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+      const M mine = sweeping & g.pair[P];
+      const D rn = B::fma(g.ut[N][2], a2, B::fma(g.ut[N][1], a1, B::fma(g.ut[N][0], a0, g.r[N])));
+      const D rt = B::fma(g.ut[T][2], a2, B::fma(g.ut[T][1], a1, B::fma(g.ut[T][0], a0, g.r[T])));
+      const D on = g.f[N], ot = g.f[T];
+      const D Ann = g.Adiag[N], Att = g.Adiag[T], Ant_ = g.Ant[P];
+      const D fn_n = B::fmax(B::fma(-rn, g.Ainv[N], on), D(0.0));
+      D x = -B::fma(ot, rt, on * rn) * rden[P];
+      x = B::fmax(x, D(-1.0));
+      const M use_n = on < LMINVAL;
+      D fn = B::sel(use_n, fn_n, B::fma(x, on, on));
+      D ft = B::sel(use_n, D(0.0), B::fma(x, ot, ot));
+      const D bc = B::fma(Ant_, fn - on, B::fma(-Att, ot, rt));
+      const D x0 = -bc * g.Ainv[T];
+      const D v1 = x0 * (1.0 / mu);
+      const D val = B::fma(v1, v1, -(fn * fn));
+      const M on_cone = (val >= 1e-10) & (val * Att * (mu * mu) >= 2e-10 * (v1 * v1));
+      const D ftc = B::sel(on_cone, B::copysign(mu * fn, x0), x0);
+      ft = B::sel(fn >= LMINVAL, ftc, ft);
+      D dn = fn - on, dt = ft - ot;
+      D chg = B::fma(dt, B::fma(0.5 * Att, dt, B::fma(Ant_, dn, rt)), dn * B::fma(0.5 * Ann, dn, rn));
+      const M keep = mine & (chg <= 1e-10);
+      dn = B::sel(keep, dn, D(0.0)); dt = B::sel(keep, dt, D(0.0)); chg = B::sel(keep, chg, D(0.0));
+      a0 = B::fma(g.ut[T][0], dt, B::fma(g.ut[N][0], dn, a0)); a1 = B::fma(g.ut[T][1], dt, B::fma(g.ut[N][1], dn, a1)); a2 = B::fma(g.ut[T][2], dt, B::fma(g.ut[N][2], dn, a2));
+      acc = acc + chg;
+      g.f[N] = g.f[N] + dn; g.f[T] = g.f[T] + dt;
+      lfor<0, CAP>([&](auto ii) {
+        constexpr int Ii = decltype(ii)::value;
+        g.r[Ii] = B::fma(g.Al[symidx(CAP, Ii, T)], dt, B::fma(g.Al[symidx(CAP, Ii, N)], dn, g.r[Ii]));
+      });
+    };
+    auto ray_den = [&](const LegRows8& g, D (&rden)[3], auto pp) {
+      LEG_FP_CONTRACT_OFF
+      constexpr int P = decltype(pp)::value;
+      constexpr int N = 2 + 2 * P, T = 3 + 2 * P;
+      const D on = g.f[N], ot = g.f[T];
+      const D denom = B::fma(ot, B::fma(g.Adiag[T], ot, g.Ant[P] * on), on * B::fma(g.Ant[P], ot, g.Adiag[N] * on));
+      rden[P] = B::sel(denom >= LMINVAL, B::rcp(denom), D(0.0));
+    };
+    I niter = 0;
+    for (int iter = 0; iter < LEG_ITERS; iter++) {
+      if (!B::any(sweeping)) break;
+      accL = 0.0; accR = 0.0;
+      lfor<0, 3>([&](auto pp) { ray_den(L, rdenL, pp); });
+      lfor<0, 3>([&](auto pp) { ray_den(R, rdenR, pp); });
+      eq_step(L, accL, LI<0>{}); eq_step(L, accL, LI<1>{});
+      eq_step(R, accR, LI<0>{}); eq_step(R, accR, LI<1>{});
+      if (anyLim[0][0]) { lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[0][Jj]) lim_step(L, accL, jj); }); }
+      if (anyLim[1][0]) { lfor<0, 4>([&](auto jj) { constexpr int Jj = decltype(jj)::value; if (anyLim[1][Jj]) lim_step(R, accR, jj); }); }
+      if (anyPair[0][0]) { lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[0][P]) pair_step(L, accL, rdenL, pp); }); }
+      if (anyPair[1][0]) { lfor<0, 3>([&](auto pp) { constexpr int P = decltype(pp)::value; if (anyPair[1][P]) pair_step(R, accR, rdenR, pp); }); }
+      const D improvement = -(accL + accR);
+      niter = niter + B::toI(sweeping);
+      sweeping = sweeping & !(improvement * scale < CP_TOLERANCE);
+    }
+    niter_out = niter;
+  }
+
+  // Both groups' eight-row blocks (written by put_rows8 / widen_rows / put_idle8) -> one joint sweep -> the forces back into the blocks' force slots,
+  // the sweep counts into W_MISC + 2.  `wr[G]`: the group takes part (its forces are wanted).
+  static LEG_FN void joint_solve8(W ws, const bool (&wr)[2]) {
+    const M even = B::leg() == I(0);
+    LegRows8 L, R;
+    D a[3], adummy[3];
+    constexpr int CH = 14;   // slots per chunk (seven sixteen-byte accesses per group): what is in flight between two fences
+    static_assert(W_NROWS8 % CH == 0, "whole chunks");
+    lfor<0, W_NROWS8 / CH>([&](auto cc) {
+      constexpr int C = decltype(cc)::value;
+      D ta[CH], tb[CH];
+      lfor<0, CH / 2>([&](auto pp) {
+        constexpr int P = decltype(pp)::value;
+        B::wld2(ws, W_ROWS + CH * C + 2 * P, ta[2 * P], ta[2 * P + 1]);
+        B::wld2(ws, W_GROUP + W_ROWS + CH * C + 2 * P, tb[2 * P], tb[2 * P + 1]);
+      });
+      lfor<0, CH>([&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        constexpr int K = CH * C + Q;
+        if constexpr (K < 95) {
+          lfld8<K>(L, a) = pick<0>(even, ta[Q], tb[Q]);
+          lfld8<K>(R, adummy) = pick<1>(even, ta[Q], tb[Q]);
+        } else {
+          a[K - 95] = B::sel(even, ta[Q], tb[Q]);   // a~ is the same on both lanes of a pair
+        }
+      });
+      B::fence();
+    });
+    M goA, goB; I nconA, nconB;
+    get_misc(ws, 0, goA, nconA); get_misc(ws, W_GROUP, goB, nconB);
+    const I nlimA = B::toint(B::wld(ws, W_MISC + 3)), nlimB = B::toint(B::wld(ws, W_GROUP + W_MISC + 3));
+    lfor<0, 3>([&](auto pp) {
+      constexpr int P = decltype(pp)::value;
+      L.pair[P] = pickm<0>(even, goA & (nconA > I(P)), goB & (nconB > I(P)));
+      R.pair[P] = pickm<1>(even, goA & (nconA > I(P)), goB & (nconB > I(P)));
+    });
+    lfor<0, 4>([&](auto jj) {
+      constexpr int Jj = decltype(jj)::value;
+      L.lim[Jj] = pickm<0>(even, goA & (nlimA > I(Jj)), goB & (nlimB > I(Jj)));
+      R.lim[Jj] = pickm<1>(even, goA & (nlimA > I(Jj)), goB & (nlimB > I(Jj)));
+    });
+    const M go = (even & goA) | ((!even) & goB);
+    I niter;
+    B::fence();
+    joint_sweeps8(L, R, a[0], a[1], a[2], go, niter);
+    B::fence();
+    const I nsw = B::swapi(niter);
+    if (wr[0]) {
+      D t[CAP];
+      lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; t[Ii] = B::sel(even, L.f[Ii], B::swap(R.f[Ii])); });
+      put_block(ws, W_ROWS, t);
+      B::wst(ws, W_MISC + 2, B::toD(B::seli(even, niter, nsw)));
+    }
+    if (wr[1]) {
+      D t[CAP];
+      lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; t[Ii] = B::sel(even, B::swap(L.f[Ii]), R.f[Ii]); });
+      put_block(ws, W_GROUP + W_ROWS, t);
+      B::wst(ws, W_GROUP + W_MISC + 2, B::toD(B::seli(even, nsw, niter)));
+    }
+  }
 
   // ------------------------------------------------------------------------------------------------ fused Env.step, two groups
   // io_of(g): the group's per-lane pointers (record, action row, observation row ...), g wave-uniform at run time; valid / o: per group.
@@ -427,6 +693,7 @@ template <class B> struct Duo : Core<B> {
     int sub = 0;
     while (true) {
       bool join[2] = {false, false}, ran[2] = {false, false};
+      bool join8[2] = {false, false};   // the group's rows are in the workspace in the eight-row format (r06: DUO_JOINT8)
       M ovf[2] = {none, none};
       I nit[2] = {I(0), I(0)};
       lds.snapshot(reset_pass || sub == cfg.n_sub - 1);
@@ -436,7 +703,7 @@ template <class B> struct Duo : Core<B> {
       LEG_NOUNROLL
       for (int g = 0; g < 2; g++) {
         const M lv = g == 0 ? lv0 : lv1;
-        bool ran_ = false, join_ = false;
+        bool ran_ = false, join_ = false, join8_ = false;
         M ovf_ = none;
         I nit_ = 0;
         if (B::any(lv)) {
@@ -459,18 +726,50 @@ template <class B> struct Duo : Core<B> {
             put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
             lds.mark(10);   // 10 = rows / factorisation out
           } else {
+#if DUO_JOINT8
+            // some environment of the group has a joint limit active or a third pair: all eight row slots go to the workspace, with what the finish
+            // needs of the once-per-wavefront descriptors, for the eight-row joint sweep
+            join8_ = true;
+            put_rows8(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
+            B::wst(ws, base + W_MISC + 3, B::toD(S.nlim));
+            put_desc<HF>(lds, ws, base);
+#else
             C::sub_sweeps(S);
             B::fence();
             nit_ = S.niter;
             C::template sub_finish<HF>(lds, st, !reset_pass, S);
             put_lane(ws, base, st);
+#endif
           }
           B::fence();
         }
-        if (g == 0) { ran[0] = ran_; join[0] = join_; ovf[0] = ovf_; nit[0] = nit_; } else { ran[1] = ran_; join[1] = join_; ovf[1] = ovf_; nit[1] = nit_; }
+        if (g == 0) { ran[0] = ran_; join[0] = join_; join8[0] = join8_; ovf[0] = ovf_; nit[0] = nit_; }
+        else { ran[1] = ran_; join[1] = join_; join8[1] = join8_; ovf[1] = ovf_; nit[1] = nit_; }
       }
       // ---- phase 2: one joint sweep for the groups on their feet; the forces go back into the rows' force slots
+#if DUO_JOINT8
+      const bool eight = join8[0] || join8[1];
+      if (eight) {
+        // the eight-row joint sweep: every group of the wavefront in the eight-row format (a group on its feet is widened, a group that does not
+        // run gets empty rows), one sweep, forces back
+        lds.mark(0);
+        LEG_NOUNROLL
+        for (int g = 0; g < 2; g++) {
+          const bool j6 = g == 0 ? join[0] : join[1], j8 = g == 0 ? join8[0] : join8[1];
+          if (j6) widen_rows(ws, g * W_GROUP);
+          else if (!j8) put_idle8(ws, g * W_GROUP);
+          B::fence();
+        }
+        lds.mark(11);
+        const bool wr[2] = {join[0] || join8[0], join[1] || join8[1]};
+        joint_solve8(ws, wr);
+        B::fence();
+        lds.mark(7);
+      }
+      if (!eight && (join[0] || join[1])) {
+#else
       if (join[0] || join[1]) {
+#endif
         Sub S[2];
         lds.mark(0);
         lfor<0, 2>([&](auto gg) {
@@ -498,10 +797,13 @@ template <class B> struct Duo : Core<B> {
         }
         B::fence();
         lds.mark(12);   // 12 = forces out
+      }
+      if (join[0] || join[1] || join8[0] || join8[1]) {
         // ---- phase 3, per group: finish
         LEG_NOUNROLL
         for (int g = 0; g < 2; g++) {
-          if (!(g == 0 ? join[0] : join[1])) continue;
+          const bool j8 = g == 0 ? join8[0] : join8[1];
+          if (!((g == 0 ? join[0] : join[1]) || j8)) continue;
           const Io io = io_of(g);
           lds.select(g, io);
           const int base = g * W_GROUP;
@@ -509,21 +811,34 @@ template <class B> struct Duo : Core<B> {
           Lane st;
           get_lane(ws, base, st);
           get_keep(ws, base, S1);
-          get_forces(ws, base, S1);
-          lfor<NR, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = 0.0; });   // slots 6, 7 are empty in a group on its feet
           get_misc(ws, base, S1.go, S1.ncon);
           const I nit_ = B::toint(B::wld(ws, base + W_MISC + 2));
           S1.nlim = 0;
+#if DUO_JOINT8
+          if (j8) {
+            // a group of the eight-row sweep: all eight forces, its joint limits, and the once-per-wavefront descriptors back in LDS
+            D t[CAP];
+            get_block(ws, base + W_ROWS, t);
+            lfor<0, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = t[Ii]; });
+            S1.nlim = B::toint(B::wld(ws, base + W_MISC + 3));
+            get_desc<HF>(lds, ws, base);
+          } else
+#endif
+          {
+          get_forces(ws, base, S1);
+          lfor<NR, CAP>([&](auto ii) { constexpr int Ii = decltype(ii)::value; S1.f[Ii] = 0.0; });   // slots 6, 7 are empty in a group on its feet
+          }
           S1.leg = B::opq(B::leg());
           S1.K = B::kbase(S1.leg);
-          // row kinds of a group on its feet: slots 0, 1 connect, pair P at slots 2 + 2P / 3 + 2P, no joint limit
+          // row kinds as sub_setup assigns them: slots 0, 1 connect; pair P at slots 2 + 2P / 3 + 2P while ncon > P; joint limit j at slot 7 - j while
+          // nlim > j (a group on its feet: nlim = 0, ncon <= 2)
           S1.kind[0] = B::seli(S1.go, I(K_EQ), I(K_NONE)); S1.kind[1] = S1.kind[0];
-          lfor<0, NP>([&](auto pp) {
-            constexpr int P = decltype(pp)::value;
-            const M has = S1.go & (S1.ncon > I(P));
-            S1.kind[2 + 2 * P] = B::seli(has, I(K_CN), I(K_NONE)); S1.kind[3 + 2 * P] = B::seli(has, I(K_CT), I(K_NONE));
+          lfor<2, CAP>([&](auto ss) {
+            constexpr int S_ = decltype(ss)::value;
+            constexpr int P = (S_ - 2) >> 1, ODD = (S_ - 2) & 1, LJ = 7 - S_;
+            const M isc = S1.ncon > I(P), isl = S1.nlim > I(LJ);
+            S1.kind[S_] = B::seli(S1.go, B::seli(isc, I(ODD ? K_CT : K_CN), B::seli(isl, I(K_LIM), I(K_NONE))), I(K_NONE));
           });
-          S1.kind[6] = I(K_NONE); S1.kind[7] = I(K_NONE);
           B::fence();
           lds.mark(13);   // 13 = state / factorisation / forces in, before the finish (sub_finish's own marks: 8 generalised force, 9 M^-1, damping, integration)
           C::template sub_finish<HF>(lds, st, !reset_pass, S1);

@@ -41,6 +41,7 @@ void step_leg(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pend
 void step_duo(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace, int table_slots, bool flat_hint);
 void step_duo_hf(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending, double* workspace, int table_slots, bool flat_hint);   // tu_duo_hf.hip: ... on the height field (p.hf)
 int duo_table_slots(int n_envs, int simds);                  // 0 up to 1024 tasks, else a power of two >= 2 x simds
+int duo_workspace_slots_per_wave();                          // Duo::W_N: slots of 64 doubles per wavefront slot (diagnosis: CassieVecTierInfo)
 size_t duo_workspace_bytes(int n_envs, int table_slots);     // workspaces + claim table; to be zeroed once by the owner
 // ... for a SEGMENT of the Env.step's substeps (p.n_sub = its length; `later` = substeps of the segments behind it; gone[env]: the
 // environment left this tier in an earlier segment; see env_step_leg_seg_kernel)

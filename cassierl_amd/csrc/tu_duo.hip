@@ -14,6 +14,7 @@ int duo_table_slots(int n_envs, int simds) {
   while (t < 2 * simds) t *= 2;
   return t;
 }
+int duo_workspace_slots_per_wave() { return leg::DDuo::W_N; }
 size_t duo_workspace_bytes(int n_envs, int table_slots) {
   const int tasks = ((n_envs + 63) / 64 + DUO_WAVES - 1) / DUO_WAVES * DUO_WAVES;
   const size_t slots = table_slots ? (size_t)table_slots : (size_t)tasks;

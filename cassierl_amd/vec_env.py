@@ -120,7 +120,7 @@ class CassieVecEnv:
         out = (ct.c_uint64 * 8)()
         self._chk(self.L.CassieVecTierInfo(self.h, out))
         return dict(first_tier=self.TIERS[int(out[0])], duo_table_slots=int(out[1]), duo_workspace_bytes=int(out[2]), ws_probes=int(out[3]),
-                    handovers_per_launch=int(out[4]))
+                    handovers_per_launch=int(out[4]), duo_workspace_slots_per_wave=int(out[5]))
 
     def qp_iterations(self):
         """Active-set iterations of the OSC QP since the previous call (the first call starts the counting and returns zeros):
@@ -135,9 +135,10 @@ class CassieVecEnv:
         self._chk(self.L.CassieVecDebugWorkspaceHost(self.h, None, 0, ct.byref(n)))
         buf = np.zeros(int(n.value))
         self._chk(self.L.CassieVecDebugWorkspaceHost(self.h, buf.ctypes.data, n.value, ct.byref(n)))
-        per = 136 * 64 * 2
-        w = buf[:len(buf) // per * per].reshape(-1, 136, 64, 2)          # [wave][slot pair][lane][2]
-        return w.transpose(0, 1, 3, 2).reshape(w.shape[0], 272, 64)       # [wave][slot][lane]
+        wn = self.tier_info()["duo_workspace_slots_per_wave"]          # Duo::W_N
+        per = wn * 64
+        w = buf[:len(buf) // per * per].reshape(-1, wn // 2, 64, 2)       # [wave][slot pair][lane][2]
+        return w.transpose(0, 1, 3, 2).reshape(w.shape[0], wn, 64)        # [wave][slot][lane]
 
     def reset_counters(self):
         self._chk(self.L.CassieVecResetCounters(self.h))

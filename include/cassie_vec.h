@@ -95,7 +95,8 @@ int CassieVecQpIterations(CassieVec* h, double* out4);
  *   out8[1] claim-table slots of the 64-environments kernel's workspace (0: one slot per 64-environment task, batches of up to one round of the chip)
  *   out8[2] bytes of that workspace
  *   out8[3] extra probes of its workspace claims since create / CassieVecResetCounters (0 while the physical-place hash is collision-free)
- *   out8[4] hand-overs per launch, as the segment scheduler currently estimates them;  out8[5..7] reserved (0) */
+ *   out8[4] hand-overs per launch, as the segment scheduler currently estimates them
+ *   out8[5] slots (of 64 doubles) per wavefront slot of that workspace (layout: Duo::W_* in csrc/cassie_duo_core.h);  out8[6..7] reserved (0) */
 int CassieVecTierInfo(CassieVec* h, uint64_t* out8);
 
 /* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */

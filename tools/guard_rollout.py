@@ -63,7 +63,8 @@ def main(out):
         env.step(R.random_actions(1, ids, t, PD_LO, PD_HI), bufs)
     res["ms_per_65536_env_step"] = np.array([env.time_steps(R.random_actions(1, ids, 5, PD_LO, PD_HI), 10, bufs)])
     ws = env.debug_workspace_host()
-    res["ms_view_marks"] = np.array([float(ws[:, 135, :].sum() + ws[:, 136 + 135, :].sum())])   # Duo::W_MISC + 3 of both groups: written by joint_solve_view only
+    wg = ws.shape[1] // 2                                                                        # Duo::W_GROUP
+    res["ms_view_marks"] = np.array([float(ws[:, wg - 2, :].sum() + ws[:, 2 * wg - 2, :].sum())])   # Duo::W_DESC + 8 of both groups: written by joint_solve_view only
     env.close()
     np.savez(out, **res)
 
