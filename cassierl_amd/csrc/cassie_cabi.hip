@@ -183,7 +183,10 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
   // in segments only while MANY robots are down: the three extra launches of the first tier cost ~3 % of a step, and a handful of
   // hand-overs is a short tail (r04, alternating A/B at 65 536 envs: all-fallen floor 15.5 -> 17.0 M with ~270 hand-overs per step;
   // stand_torque_random 22.4 -> 21.6 M when forced; by this rule 22.7 M / 16.9 M)
-  const bool segments = h->seg_mode >= 0 ? h->seg_mode == 1 : h->pend_rate >= SEG_MIN_HANDOVERS;
+  // r06: only where the first tier is the two-lanes kernel.  The segments are launches of that kernel (step_leg_segment); since the 64-environments
+  // kernel sweeps its eight-row groups with a lane per environment it is ahead of four segments of the pair sweep on both falling-robot workloads
+  // (tools/ab_segments.py, 65 536 envs: stand_torque_random 25.9 M never / 22.7 M always / 22.4 M by the estimate; all-fallen floor 17.5 / 17.2 / 17.2)
+  const bool segments = h->seg_mode >= 0 ? h->seg_mode == 1 : (!h->duo && h->pend_rate >= SEG_MIN_HANDOVERS);
   if (side_by_side && segments && !h->seg_failed && p.n_sub >= 4 && !p.debug && seg_resources(h)) {
     // ---- the Env.step in segments (r04).  A robot that is down costs its substeps end to end (~0.13 ms each) in the lower tiers,
     // and in the order below these only start when the first tier has finished ALL its substeps: 1.4 ms of first tier + up to
