@@ -718,21 +718,31 @@ template <class B> struct Duo : Core<B> {
           lds.mark(15);   // 15 = state in, before the set-up (sub_setup's own marks: 1 kinematics .. 5 rows)
           Sub S;
           SubOut so;
-          C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf, []() {}, []() {});   // (this backend: no split tail, nothing to do inside)
+          // The rows leave for the workspace INSIDE the branch of the set-up that built them (six slots on their feet / eight): with B::SPLIT_TAIL the two
+          // cases never meet again, so nothing of a row has to survive a merge of the two paths (and a group on its feet does not build its two empty slots).
+          auto rows_small = [&]() {
+            B::fence();
+            put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
+            lds.mark(10);   // 10 = rows / factorisation out
+          };
+          auto rows_general = [&]() {
+#if DUO_JOINT8
+            // some environment of the group has a joint limit active or a third pair: all eight row slots go to the workspace, with what the finish
+            // needs of the once-per-wavefront descriptors, for the eight-row joint sweep
+            B::fence();
+            put_rows8(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
+            B::wst(ws, base + W_MISC + 3, B::toD(S.nlim));
+            put_desc<HF>(lds, ws, base);
+#endif
+          };
+          C::template sub_setup<MODE, HF>(lds, st, reset_pass || MODE == 2, lv, !reset_pass, so, S, hf, rows_small, rows_general);
           ovf_ = so.overflow;
           B::fence();
           if (S.small) {
             join_ = true;
-            put_rows(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
-            lds.mark(10);   // 10 = rows / factorisation out
           } else {
 #if DUO_JOINT8
-            // some environment of the group has a joint limit active or a third pair: all eight row slots go to the workspace, with what the finish
-            // needs of the once-per-wavefront descriptors, for the eight-row joint sweep
             join8_ = true;
-            put_rows8(ws, base, S); put_keep(ws, base, S); put_misc(ws, base, S.go, S.ncon);
-            B::wst(ws, base + W_MISC + 3, B::toD(S.nlim));
-            put_desc<HF>(lds, ws, base);
 #else
             C::sub_sweeps(S);
             B::fence();

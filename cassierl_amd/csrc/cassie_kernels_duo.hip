@@ -50,7 +50,14 @@ struct DuoShared {
 static_assert(sizeof(DuoShared) == 39168, "LDS budget of four wavefronts per CU");
 
 struct DevDuoB : DevB {
-  static constexpr bool SPLIT_TAIL = false;
+#ifndef DUO_SPLIT_TAIL
+#define DUO_SPLIT_TAIL 1
+#endif
+  // sub_setup: a group on its feet does not build its two empty row slots and warm-starts over six.  r05 had this off for this kernel (the branch cost 75 more
+  // spills with the eight-row pair solve inline behind the set-up: 1.01 -> 1.08 ms); r06: the eight-row groups leave for the joint sweep like the others, the
+  // set-up's two branches end in their own stores to the workspace and never meet again: 304 B of scratch instead of 264, **1.018 -> 0.990 ms** per 65 536-env
+  // step (tools/ab_bench.py, both orders), bit-identical.
+  static constexpr bool SPLIT_TAIL = DUO_SPLIT_TAIL != 0;
   // per-wavefront workspace in global memory (Duo::W_*): [slot][lane], the lane's pointer is the base of its column
   // Buffer addressing: one resource descriptor per wavefront (SGPRs), the lane's byte offset in ONE VGPR, the slot as the scalar offset
   // of the instruction -- so a slot costs an s_mov, not a 64-bit per-lane pointer (with plain pointers the compiler materialises one

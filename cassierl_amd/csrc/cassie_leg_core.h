@@ -754,8 +754,8 @@ template <class B> struct Core {
       // warm start runs over six slots -- the two left-out slots would add exact zeros to every sum.  Nothing reads their rows in that
       // case (six-row sweeps); the finish reads their kind and force.
       if constexpr (!B::SPLIT_TAIL) {
-        // (the 64-environments kernel: its set-up sits in a loop over the two groups with the eight-row solve inline behind it, and the branch
-        // here cost it 75 more spills -- 1.01 -> 1.08 ms per step -- where the two-lanes kernel gained 7 %: it builds the two empty slots)
+        // (backends that always build the two empty slots: the CPU lane emulation; until r05 the 64-environments kernel, whose set-up then had the
+        // eight-row solve inline behind it)
         build_slot(LI<6>{}); build_slot(LI<7>{});
         B::fence();
         lds.mark(5);
