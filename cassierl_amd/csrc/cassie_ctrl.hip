@@ -304,11 +304,21 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
         if constexpr (C != R) x[C] += h * w[R];
       });
     });
+    // the whole column in registers FIRST, stored behind the last read of Hinv / the controller rows: in the packed kernel's LDS layout T lives where
+    // those lived (EnvLdsC, cassie_ctrl_g16.hip)
+    double tcol[11];
+    static_for<0, 11>([&](auto rr) {
+      constexpr int r = decltype(rr)::value;
+      double s = 0;
+      static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += jd<4 + r, C>(cs) * x[C]; });
+      asm volatile("" : "+v"(s));   // the sum is finished HERE (without the pin the 143 row loads are hoisted above all the sums and spilled: the G loop's lesson)
+      tcol[r] = s;
+    });
+    ctrl_fence();
     if (lane < 15) {
       static_for<0, 11>([&](auto rr) {
         constexpr int r = decltype(rr)::value;
-        double s = 0;
-        static_for<0, NV>([&](auto cc) { constexpr int C = decltype(cc)::value; s += jd<4 + r, C>(cs) * x[C]; });
+        const double s = tcol[r];
         if (lane < 14) cs.T[lane][r] = s;
         else {
           // t0 = A q0 + AdotQdot - xdd, q0 = Hinv ce = -x ; xdd packing of Cassie2d.cpp:185-193
@@ -358,12 +368,12 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
   double z = bound ? (atlo ? lo : hi) : 0.0;  // feasible start: bound variables on their bound, free ones at 0 (inside every box)
   if (l >= 6) z = 0.0;                          // generators have no upper bound
   bool busy = rowok;  // uniform inside a row
-  int my_iters = 0;   // active-set iterations of THIS row's QP (the loop runs until the slowest row of the wavefront is done)
+  // (active-set iterations of THIS row's QP -- the loop runs until the slowest row of the wavefront is done -- are noted in a spare LDS word when the row
+  // converges: a counter register would be the 169th of a kernel sized for three wavefronts per SIMD)
   PHASE_MARK(*pc, 3);
   ctrl_fence();
   for (int it = 0; it < 60; it++) {
     if (__ballot(busy) == 0) break;
-    my_iters += busy ? 1 : 0;
 #ifdef CASSIE_PHASE_TIMING
     pc->acc[8] += 1;
 #endif
@@ -411,7 +421,7 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
       const int rel = __ffs(hit) - 1;
       if (full && !conv && l == rel) bound = false;
     }
-    if (conv) busy = false;
+    if (conv) { busy = false; if (l == 15) cs.u[7] = (double)(it + 1); }
 #ifdef CASSIE_PHASE_TIMING
     if (it == 59) {  // environments that leave the loop unconverged, bucketed by the size of their last multiplier violation
       const bool un = busy && l == 0;
@@ -433,9 +443,10 @@ __device__ __forceinline__ void ctrl_osc(SM& sm, CS& cs, const LaneConst& c, int
                                                       // every call with all feet loaded re-freed the 8 generators one by one)
   }
   if (lane < 6) cs.u[lane] = z;
-  if (qp_iterations) *qp_iterations = my_iters;
+  if (busy && l == 15) cs.u[7] = 60.0;   // left the loop unconverged
   lds_sync();
   ctrl_fence();
+  if (qp_iterations) *qp_iterations = (int)cs.u[7];
   PHASE_MARK(*pc, 4);
 }
 

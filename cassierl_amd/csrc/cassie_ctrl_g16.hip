@@ -16,6 +16,7 @@
 #ifndef CASSIE_CTRL_G16_HIP_
 #define CASSIE_CTRL_G16_HIP_
 
+#include <cstddef>
 namespace cassie {
 namespace g16 {
 
@@ -35,17 +36,26 @@ struct EnvLdsC {
     struct { double kq[16], kv[16]; };      // kinematics of the LAST setState (scripted targets only)
     struct { double acc[16], bias[16]; };   // JdotQdot of each controller row; NonlinearEffects + damping*qvel
   };
-  double minv[NV * (NV + 1) / 2 + 5];       // Hinv, packed upper triangle
-  double Jc[NCR][8];                        // compact controller rows
   double y[16], act[8], u[8], s18[18];
+  // 300 doubles shared by lifetime (r06: 414 doubles = 3.3 KB per environment, 13.2 KB per wavefront -- TWELVE wavefronts, three per SIMD, share
+  // the 160 KB of a CU; r03..r05: 582 doubles, two per SIMD).  Inside one wavefront LDS accesses are in program order, so a block may be overwritten as
+  // soon as the code that reads its previous tenant lies behind:
+  //   [  0,  84)  lc ls lw lox loz lax laz     read until the controller rows exist          then  JH, S4 (born behind the rows)
+  //   [ 84, 252)  lcx lcz lfx lfz s1* lv* site  dead behind mass_rows                         then  Hinv [84, 180) (born behind the Gauss-Jordan)
+  //   [180, 300)                                                                               then  the controller rows Jc (born behind the last FK read)
+  //   [ 84, 264)  T, t0 / U: stored when every read of Hinv, Jc for the T (U) columns lies behind (ctrl_osc computes a whole column in registers first)
   union {
     struct {                                // forward kinematics and mass-matrix exchange
-      double lc[12], ls[12], lw[12], lox[12], loz[12], lcx[12], lcz[12], lfx[12], lfz[12];
-      double s1x[16], s1z[16], s2[16];
-      double lvx[12], lvz[12], lax[12], laz[12], site[2][6][4];
+      double lc[12], ls[12], lw[12], lox[12], loz[12], lax[12], laz[12];
+      double lcx[12], lcz[12], lfx[12], lfz[12], s1x[16], s1z[16], s2[16], lvx[12], lvz[12], site[2][6][4];
     };
-    struct {                                // constraint projector and the controller's own matrices
-      double JH[4][NV], S4[16];
+    struct {                                // constraint projector, Hinv, controller rows
+      double JH[4][NV], S4[16], pad0_[16];
+      double minv[NV * (NV + 1) / 2 + 5];   // Hinv, packed upper triangle
+      double Jc[NCR][8];                    // compact controller rows
+    };
+    struct {                                // the controller's own matrices
+      double pad1_[84];
       union {
         struct { double T[NZ][12]; double t0[12]; };
         struct { double U[6][NV]; };
@@ -57,11 +67,17 @@ struct EnvLdsC {
     return lo * NV - lo * (lo - 1) / 2 + (hi - lo);
   }
 };
-static_assert(sizeof(EnvLdsC) * 4 * 8 <= 160 * 1024, "eight controller wavefronts must fit the LDS of a CU");
+static_assert(sizeof(EnvLdsC) == 414 * sizeof(double), "layout of the controller's LDS block");
+static_assert(offsetof(EnvLdsC, minv) - offsetof(EnvLdsC, lc) == 84 * sizeof(double) && offsetof(EnvLdsC, lcx) == offsetof(EnvLdsC, minv) &&
+              offsetof(EnvLdsC, Jc) - offsetof(EnvLdsC, lc) == 180 * sizeof(double) && offsetof(EnvLdsC, T) == offsetof(EnvLdsC, minv), "overlay offsets");
+static_assert(sizeof(EnvLdsC) * 4 * 12 <= 160 * 1024, "twelve controller wavefronts must fit the LDS of a CU");
 
 // CTRL: 2 = OSC, 3 = Jacobian.  SCRIPTED: targets from standing_controller_* (zpos/zvel per env) instead of actions.
+#ifndef CTRL_WAVES
+#define CTRL_WAVES 3   // wavefronts per SIMD the kernel is sized for (r06; registers <= 168, LDS 13.2 KB per wavefront)
+#endif
 template <int CTRL, bool SCRIPTED>
-__global__ void __launch_bounds__(64, 2) env_ctrl_g16_kernel(VecParams p, const double* zpos, const double* zvel) {
+__global__ void __launch_bounds__(64, CTRL_WAVES) env_ctrl_g16_kernel(VecParams p, const double* zpos, const double* zvel) {
   __shared__ EnvLdsC sm4[4];
   const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
   const int env = blockIdx.x * 4 + g;
