@@ -469,7 +469,13 @@ def extra_workloads(traj, n):
         r2 = rows[-1]
         if o2 and o2.get("envs") == n and "env_steps_per_s" in r2:
             ach = o2["valu_flop_issued_per_env_step"] * r2["env_steps_per_s"] / 1e12
+            ea = o2.get("valu_flop_exec_active_per_env_step")
             r2["roofline"] = dict(bound="fp64_valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_VALU_PEAK_TFLOPS, flops="issued (upper bound of useful)",
+                                  exec_active=None if not ea else dict(achieved=ea * r2["env_steps_per_s"] / 1e12, frac=ea * r2["env_steps_per_s"] / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                                                       active_lane_frac=o2.get("active_lane_frac"),
+                                                                       note="issued x the EXEC-active share of each kernel's lanes (PMC SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU), normalised by the "
+                                                                            "lane-per-leg physics kernel): what the controller's 16-lane rows leave idle by masking is out; of an active row's 16 lanes 13 "
+                                                                            "carry a dof (14 a QP variable), so the useful share of the controller's part is at most 13/16 of this"),
                                   traffic=o2["hbm_bytes_per_env_step_batch"], algorithmic_bytes=o2["algorithmic_bytes_per_env_step_batch"],
                                   kernel="cassie::g16::env_ctrl_g16_kernel<2,false> + cassie::leg::env_step_duo_kernel<2> per substep (+ hand-over passes)",
                                   note="two launches per substep, each re-staging the state records (and the physics kernel its hand-over workspace): latency- and "

@@ -9,6 +9,7 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 G1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
+G3="SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_WAVES"   # r06: thread-level VALU activity (how many lanes of an instruction are EXEC-active)
 G2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM GRBM_GUI_ACTIVE"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters, program args...
@@ -22,10 +23,11 @@ for wl in ${PMC_WORKLOADS:-pd osc c3}; do
     osc) prog="$root/tools/prof_step.py 65536 4 OSC" ;;
     c3)  prog="$root/tools/bench_cassie3d.py --envs 16384 --steps 4" ;;
   esac
-  for grp in ${PMC_GROUPS:-sq1 sq2 fetch write}; do
+  for grp in ${PMC_GROUPS:-sq1 sq2 sq3 fetch write}; do
     case $grp in
       sq1) run ${wl}_sq1 "$G1" $prog ;;
       sq2) run ${wl}_sq2 "$G2" $prog ;;
+      sq3) run ${wl}_sq3 "$G3" $prog ;;
       fetch) run ${wl}_fetch "FETCH_SIZE" $prog ;;
       write) run ${wl}_write "WRITE_SIZE" $prog ;;
     esac

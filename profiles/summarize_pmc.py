@@ -46,7 +46,7 @@ def read_pass(d):
 
 def workload(src, wl, want, envs, units_per_launch_name):
     merged = defaultdict(dict)
-    for grp in ("sq1", "sq2", "fetch", "write"):
+    for grp in ("sq1", "sq2", "sq3", "fetch", "write"):
         for k, v in read_pass(os.path.join(src, "pmc_%s_%s" % (wl, grp))).items():
             if any(w in k for w in want):
                 merged[k].update(v)
@@ -69,17 +69,27 @@ def workload(src, wl, want, envs, units_per_launch_name):
                                                                                            "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_FMA_F64")),
                    hbm_read_bytes=2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0), hbm_write_bytes=1024.0 * v.get("WRITE_SIZE", 0.0))
         row["hbm_bytes"] = row["hbm_read_bytes"] + row["hbm_write_bytes"]
+        # r06: SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU) = EXEC-active lanes per VALU instruction (a kernel whose instructions all run with 64
+        # active lanes reads 1.015: the calibration is K1d; see active_lane_frac below)
+        thr = v.get("SQ_THREAD_CYCLES_VALU", 0.0)
+        row["valu_thread_cycles_per_lane_inst"] = thr / (64.0 * valu) if (thr and valu) else None
         # Per SIMD (1024 of them): GRBM_GUI_ACTIVE is summed over the 8 XCDs.  cycles_per_valu_inst above is per WAVEFRONT (how long a
         # wavefront lives per instruction it issues); with W wavefronts resident on a SIMD the SIMD issues W times as often.
         gui = v.get("GRBM_GUI_ACTIVE", 0.0)
         row["simd_cycles_per_valu_inst"] = (gui / 8.0) * 1024.0 / valu if (gui and valu) else None
         row["simd_valu_busy_frac"] = 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / ((gui / 8.0) * 1024.0) if gui else None
         rows.append(row)
+    full = max([r["valu_thread_cycles_per_lane_inst"] or 0.0 for r in rows] + [0.0])
+    for r in rows:   # normalised by the fullest kernel of the workload when that one is a lane-per-leg kernel (all lanes active): ~1.015
+        t = r["valu_thread_cycles_per_lane_inst"]
+        r["active_lane_frac"] = min(1.0, t / max(full, 1.0)) if t else None
     rows.sort(key=lambda r: -(r["counters"].get("SQ_INSTS_VALU", 0.0)))
     tot_flop = sum(r["fp64_lane_flops_issued"] for r in rows)
+    tot_active = sum(r["fp64_lane_flops_issued"] * (r["active_lane_frac"] if r["active_lane_frac"] is not None else 1.0) for r in rows)
     tot_bytes = sum(r["hbm_bytes"] for r in rows)
     return dict(envs=envs, launch=units_per_launch_name, kernels=rows, hbm_bytes_per_launch=tot_bytes,
-                fp64_lane_flops_issued_per_launch=tot_flop, fp64_lane_flops_issued_per_env_step=tot_flop / envs)
+                fp64_lane_flops_issued_per_launch=tot_flop, fp64_lane_flops_issued_per_env_step=tot_flop / envs,
+                fp64_lane_flops_exec_active_per_env_step=tot_active / envs)
 
 
 def main():
@@ -108,6 +118,8 @@ def main():
                        # the other configs the bench line attaches a roofline object to (per Env.step of 10 substeps: the OSC kernels are
                        # profiled per substep, hence x 10)
                        osc=dict(envs=65536, valu_flop_issued_per_env_step=10.0 * osc["fp64_lane_flops_issued_per_env_step"],
+                                valu_flop_exec_active_per_env_step=10.0 * osc["fp64_lane_flops_exec_active_per_env_step"],
+                                active_lane_frac={r["kernel"][:48]: r["active_lane_frac"] for r in osc["kernels"][:2]},
                                 hbm_bytes_per_env_step_batch=int(10.0 * osc["hbm_bytes_per_launch"]), algorithmic_bytes_per_env_step_batch=(ALGO_BYTES_PER_ENV_STEP + 8) * 65536),
                        cassie3d=dict(envs=16384, valu_flop_issued_per_env_step=c3["fp64_lane_flops_issued_per_env_step"], hbm_bytes_per_launch=int(c3["hbm_bytes_per_launch"])),
                        note="bench workload at 65 536 envs: packed kernel + its hand-over pass per Env.step.  valu_flop_per_env_step = ISSUED FP64 lane-flops "
