@@ -35,10 +35,14 @@ FIRST_TIER_KERNEL = {"duo": "cassie::leg::env_step_duo_kernel<0>", "leg": "cassi
 
 
 def dominant_kernel(n_envs, simds=1024):
-    """The kernel one bench step launches (PD mode, flat floor), by the library's rule (cassie_cabi.hip, CassieVecCreate: whole rounds of one
-    wavefront per SIMD -- 64 environments per wavefront at ~1.05 ms a round against 32 at ~0.65 ms; LEG_MIN_ENVS below that)."""
-    rp, rj = -(-(-(-n_envs // 32)) // simds), -(-(-(-n_envs // 64)) // simds)
-    if n_envs > 32768 and 1.05 * rj < 0.65 * rp:
+    """The kernel that steps most of a PD batch on the flat floor, by the library's rule (cassie_cabi.hip, CassieVecCreate: whole rounds of one wavefront per
+    SIMD -- 64 environments per wavefront at ~1.0 ms a round against 32 at ~0.62 ms, the whole rounds of a batch in the former and a short remainder in the
+    latter; LEG_MIN_ENVS below that).  The bench line itself asks the library (CassieVecTierInfo); this mirror is for tests and tools without a GPU."""
+    rp, rj = -(-n_envs // (32 * simds)), -(-n_envs // (64 * simds))
+    whole = n_envs // (64 * simds) * (64 * simds)
+    rest = n_envs - whole
+    split = 1.0 * (whole // (64 * simds)) + 0.62 * (-(-rest // (32 * simds)))
+    if n_envs > 32768 and ((whole > 0 and rest > 0 and split < 0.62 * rp and split < 1.0 * rj) or 1.05 * 1.0 * rj < 0.62 * rp):
         return "cassie::leg::env_step_duo_kernel<0>"
     return "cassie::leg::env_step_leg_kernel<0>" if n_envs >= 6144 else "cassie::g16::env_step_g16_kernel<0, false>"
 

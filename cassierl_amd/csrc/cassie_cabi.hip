@@ -47,6 +47,7 @@ struct CassieVec {
   int duo_table = 0;                         // claim-table slots of its workspace (L2::duo_table_slots; 0: one slot per task).  CASSIE2D_DUO_TABLE=<slots> forces a table (tests)
   bool duo_flat_hint = false;                // CASSIE2D_DUO_FLAT_HINT=1 (tests): every wavefront's first probe is word 0
   size_t duo_ws_bytes = 0;
+  int duo_envs = 0;                          // environments [0, duo_envs) take that form, the rest the two-lanes kernel (0 or n unless the size rule splits the batch)
   bool duo = false;                          // ... in its 64-environments-per-wavefront form (cassie_kernels_duo.hip; CASSIE2D_DUO=0/1 overrides the size rule)
   unsigned long long* phase = nullptr;       // profiling builds (-DCASSIE_PHASE_TIMING): 16 cycle accumulators
   unsigned long long* stats = nullptr;       // device event counters (cassie::STAT_*)
@@ -144,6 +145,31 @@ bool seg_resources(CassieVec* h) {
   return true;
 }
 
+// The first tier of a launch (flat floor or height field): the first `duo_envs` environments in the 64-environments-per-wavefront kernel, the rest in
+// the two-lanes kernel (r06: a batch of whole rounds of the chip plus a remainder of at most one short round takes BOTH -- 65 537 .. 98 304 envs: 1.0 + 0.62 ms
+// instead of three short rounds; the two kernels are bit-identical, so which environment runs where is invisible in the results).
+void launch_first_tier(CassieVec* h, int mode, const cassie::VecParams& p, bool hf) {
+  const int nd = h->duo_envs;
+  if (nd > 0) {
+    if (hf) L2::step_duo_hf(mode, nd, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint);
+    else L2::step_duo(mode, nd, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint);
+  }
+  if (nd < h->n) {
+    cassie::VecParams q = p;
+    if (nd > 0) {   // the remainder: every per-environment array moved on by nd environments
+      const size_t o = (size_t)nd;
+      q.n_envs = h->n - nd;
+      q.state = p.state + o * cassie::ENV_STRIDE;
+      if (p.actions) q.actions = p.actions + o * (size_t)p.adim;
+      if (p.obs) q.obs = p.obs + o * 26;
+      if (p.terminal_obs) q.terminal_obs = p.terminal_obs + o * 26;
+      if (p.reward) q.reward = p.reward + o;
+      if (p.done) q.done = p.done + o;
+    }
+    if (hf) L2::step_leg_hf(mode, h->n - nd, h->stream, q, h->pending_leg + nd); else L2::step_leg(mode, h->n - nd, h->stream, q, h->pending_leg + nd);
+  }
+}
+
 // Physics tiers on the flat floor (mode 0 PD, 1 torque, 2 commands from the record).  Each tier leaves an environment it cannot
 // hold untouched from that substep on and says how many substeps are left; the next tier finishes it (results are what that
 // tier alone would give: an environment's arithmetic is a function of its own state in every kernel).
@@ -235,7 +261,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (side_by_side) {
-    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    launch_first_tier(h, mode, p, false);
     L2::classify_pending(h->n, h->stream, p, h->pending_leg);
     const bool forked = hipEventRecord(h->ev_fork, h->stream) == hipSuccess && hipStreamWaitEvent(h->side, h->ev_fork, 0) == hipSuccess;
     if (forked) {
@@ -259,7 +285,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
     return;
   }
   if (h->leg) {
-    if (h->duo) L2::step_duo(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg(mode, h->n, h->stream, p, h->pending_leg);
+    launch_first_tier(h, mode, p, false);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16(mode, h->n, h->stream, p2, h->pending);
@@ -270,7 +296,7 @@ void launch_physics_tiers(CassieVec* h, int mode, const cassie::VecParams& pin) 
 void launch_physics_tiers_hf(CassieVec* h, int mode, const cassie::VecParams& p) {
   cassie::VecParams p2 = p, p3 = p;
   if (h->leg) {
-    if (h->duo) L2::step_duo_hf(mode, h->n, h->stream, p, h->pending_leg, h->duo_ws, h->duo_table, h->duo_flat_hint); else L2::step_leg_hf(mode, h->n, h->stream, p, h->pending_leg);
+    launch_first_tier(h, mode, p, true);
     p2.pending = h->pending_leg; p2.pending_pick = cassie::PICK_ALL;
   }
   L2::step_g16_hf(mode, h->n, h->stream, p2, h->pending);
@@ -420,21 +446,33 @@ int CassieVecCreate(CassieVec** out, int n_envs, int device, const CassieVecConf
   int simds = 1024;
   {
     // both forms run one wavefront per SIMD, so a launch takes whole ROUNDS of the chip's SIMDs: per round the pair form's wavefront
-    // (32 environments) lives ~0.65 ms, the joint form's (64 environments) ~1.05 ms (r05, MI355X).  65 536 envs: 2 x 0.65 against 1 x 1.05;
-    // 32 768: one round either way, the pair form's is shorter; 98 304: 3 x 0.65 against 2 x 1.05.
+    // (32 environments) lives ~0.62 ms, the joint form's (64 environments) ~1.0 ms (r06 sweep, MI355X: profiles/r06_size_sweep.jsonl).  Three
+    // candidates: the pair form for everyone; the joint form for everyone; the joint form for the whole rounds of the batch and the pair form for the
+    // remainder (r06).  32 768 envs: one round either way, the pair form's is shorter; 65 536: 1 x 1.0 against 2 x 0.62; 98 304: 1.0 + 0.62 against
+    // 3 x 0.62 or 2 x 1.0; 131 072: 2 x 1.0.
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
-    const int rounds_pair = ((n_envs + 31) / 32 + simds - 1) / simds, rounds_joint = ((n_envs + 63) / 64 + simds - 1) / simds;
-    h->duo = h->leg && n_envs > DUO_MIN_ENVS && 1.05 * rounds_joint < 0.65 * rounds_pair;
+    const double T_PAIR = 0.62, T_JOINT = 1.0;
+    const int round_pair = 32 * simds, round_joint = 64 * simds;
+    auto rounds = [](int n, int per) { return (n + per - 1) / per; };
+    const double cost_pair = T_PAIR * rounds(n_envs, round_pair), cost_joint = T_JOINT * rounds(n_envs, round_joint);
+    const int whole = n_envs / round_joint * round_joint, rest = n_envs - whole;
+    const double cost_split = T_JOINT * (whole / round_joint) + T_PAIR * rounds(rest, round_pair);
+    h->duo_envs = 0;
+    if (h->leg && n_envs > DUO_MIN_ENVS) {
+      if (whole > 0 && rest > 0 && cost_split < cost_pair && cost_split < cost_joint) h->duo_envs = whole;
+      else if (1.05 * cost_joint < cost_pair) h->duo_envs = n_envs;
+    }
   }
-  { const char* e = getenv("CASSIE2D_DUO"); if (e && (e[0] == '0' || e[0] == '1')) h->duo = h->leg && e[0] == '1'; }
-  if (h->cfg.flags & CASSIE_DUO_TIER_OFF) h->duo = false;
-  if (h->cfg.flags & CASSIE_DUO_TIER_ON) h->duo = h->leg;
+  { const char* e = getenv("CASSIE2D_DUO"); if (e && (e[0] == '0' || e[0] == '1')) h->duo_envs = (h->leg && e[0] == '1') ? n_envs : 0; }
+  if (h->cfg.flags & CASSIE_DUO_TIER_OFF) h->duo_envs = 0;
+  if (h->cfg.flags & CASSIE_DUO_TIER_ON) h->duo_envs = h->leg ? n_envs : 0;
+  h->duo = h->duo_envs > 0;
   if (h->duo) {
-    h->duo_table = L2::duo_table_slots(n_envs, simds);
+    h->duo_table = L2::duo_table_slots(h->duo_envs, simds);
     { const char* e = getenv("CASSIE2D_DUO_TABLE"); if (e && atoi(e) >= 2) { int t = 2; while (t < atoi(e)) t *= 2; h->duo_table = t; } }   // tests: a small batch through the claim path
     { const char* e = getenv("CASSIE2D_DUO_FLAT_HINT"); h->duo_flat_hint = e && e[0] == '1'; }
-    h->duo_ws_bytes = L2::duo_workspace_bytes(n_envs, h->duo_table);
+    h->duo_ws_bytes = L2::duo_workspace_bytes(h->duo_envs, h->duo_table);
     if (hipMalloc(&h->duo_ws, h->duo_ws_bytes) != hipSuccess) return bail(CASSIE_EHIP);
     if (hipMemset(h->duo_ws, 0, h->duo_ws_bytes) != hipSuccess) return bail(CASSIE_EHIP);
   }
@@ -544,7 +582,8 @@ int CassieVecTierInfo(CassieVec* h, uint64_t* out8) {
   out8[3] = host[cassie::STAT_WS_PROBES];
   out8[4] = h->pend_rate;
   out8[5] = (uint64_t)L2::duo_workspace_slots_per_wave();
-  out8[6] = out8[7] = 0;
+  out8[6] = (uint64_t)h->duo_envs;
+  out8[7] = 0;
   return CASSIE_OK;
 }
 

@@ -120,7 +120,7 @@ class CassieVecEnv:
         out = (ct.c_uint64 * 8)()
         self._chk(self.L.CassieVecTierInfo(self.h, out))
         return dict(first_tier=self.TIERS[int(out[0])], duo_table_slots=int(out[1]), duo_workspace_bytes=int(out[2]), ws_probes=int(out[3]),
-                    handovers_per_launch=int(out[4]), duo_workspace_slots_per_wave=int(out[5]))
+                    handovers_per_launch=int(out[4]), duo_workspace_slots_per_wave=int(out[5]), duo_envs=int(out[6]))
 
     def qp_iterations(self):
         """Active-set iterations of the OSC QP since the previous call (the first call starts the counting and returns zeros):

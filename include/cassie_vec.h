@@ -96,7 +96,9 @@ int CassieVecQpIterations(CassieVec* h, double* out4);
  *   out8[2] bytes of that workspace
  *   out8[3] extra probes of its workspace claims since create / CassieVecResetCounters (0 while the physical-place hash is collision-free)
  *   out8[4] hand-overs per launch, as the segment scheduler currently estimates them
- *   out8[5] slots (of 64 doubles) per wavefront slot of that workspace (layout: Duo::W_* in csrc/cassie_duo_core.h);  out8[6..7] reserved (0) */
+ *   out8[5] slots (of 64 doubles) per wavefront slot of that workspace (layout: Duo::W_* in csrc/cassie_duo_core.h)
+ *   out8[6] environments [0, out8[6]) run in the 64-environments kernel, the rest in the two-lanes kernel (0, n, or the whole rounds of a batch the size
+ *           rule splits: the two kernels give bit-identical results);  out8[7] reserved (0) */
 int CassieVecTierInfo(CassieVec* h, uint64_t* out8);
 
 /* reference-gait table of cassie2d_trajectory.py (time[n], qpos[n][13]); host pointers, copied once */

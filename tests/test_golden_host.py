@@ -87,7 +87,7 @@ def test_bench_tier_rule_and_cpu_limit_helpers():
     spec.loader.exec_module(b)
     assert "g16" in b.dominant_kernel(4096) and "env_step_leg_kernel" in b.dominant_kernel(8192) and "env_step_leg_kernel" in b.dominant_kernel(32768)
     assert "env_step_duo_kernel" in b.dominant_kernel(40000) and "env_step_duo_kernel" in b.dominant_kernel(65536)
-    assert "env_step_leg_kernel" in b.dominant_kernel(98304) and "env_step_duo_kernel" in b.dominant_kernel(131072) and "env_step_duo_kernel" in b.dominant_kernel(524288)
+    assert "env_step_duo_kernel" in b.dominant_kernel(98304) and "env_step_duo_kernel" in b.dominant_kernel(131072) and "env_step_duo_kernel" in b.dominant_kernel(524288)   # 98 304: split (r06)
     assert b.thread_ladder(256) == [256, 128, 64, 32, 16, 8, 4, 2, 1] and b.thread_ladder(1) == [1] and b.thread_ladder(6) == [6, 3, 1]
     lim = b.cpu_limits()
     assert set(lim) == {"cpu_count", "affinity", "cpu_quota", "cpu_quota_source"} and (lim["cpu_quota"] is None or lim["cpu_quota"] > 0)

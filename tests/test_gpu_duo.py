@@ -232,3 +232,31 @@ def test_handover_estimate_reaches_the_host_while_robots_are_down():
     assert c["cleanup_substeps"] > 0 and info["handovers_per_launch"] > 0, (info, c)
     assert 0.05 * per_launch < info["handovers_per_launch"] < 40.0 * per_launch + 64, (info["handovers_per_launch"], per_launch)
     env.close()
+
+
+def test_size_rule_splits_a_batch_between_the_two_kernels(traj):
+    """r06: a batch of whole rounds of the chip plus a short remainder (65 537 .. 98 304 envs on an MI355X) steps its whole rounds in the 64-environments
+    kernel and the remainder in the two-lanes kernel, in one Env.step -- `tier_info()["duo_envs"]` says where the cut is.  The kernels are bit-identical,
+    so the result must equal the all-two-lanes run, record for record, across the cut."""
+    import torch
+    from cassierl_amd import rollout as R
+    from cassierl_amd.vec_env import CassieVecEnv, LEG_TIER_ON, DUO_TIER_OFF
+    n = 65536 + 4141
+    split = CassieVecEnv(n, kind="stand", control_mode="PD", n_substeps=10, auto_reset=True)
+    info = split.tier_info()
+    if info["duo_envs"] in (0, n):
+        split.close()
+        pytest.skip("the size rule does not split %d envs on this part (duo_envs = %d)" % (n, info["duo_envs"]))
+    assert info["first_tier"] == "duo" and info["duo_envs"] == 65536
+    pair = CassieVecEnv(n, kind="stand", control_mode="PD", n_substeps=10, auto_reset=True, flags=LEG_TIER_ON | DUO_TIER_OFF)
+    ids = torch.arange(n, device="cuda:0")
+    outs = []
+    for env in (pair, split):
+        bufs = env.alloc()
+        env.reset(bufs)
+        for t in range(12):
+            o, r, d = env.step(R.random_actions(5, ids, t, PD_LO, PD_HI), bufs)
+        outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy(), env.get_full_state_host()))
+    for k, what in enumerate(("obs", "reward", "done", "state records")):
+        _same(outs[0][k], outs[1][k], what)
+    pair.close(); split.close()
