@@ -18,7 +18,7 @@
 
 #define LEG_FN __device__ __forceinline__
 #define LEG3_SUBSTEP_FN __device__ __noinline__
-#ifdef CASSIE3D_PHASE_TIMING   // profiling builds (tests/phase_profile_3d.py): cycles per phase of the substep, summed over wavefronts and launches
+#ifdef CASSIE3D_PHASE_TIMING   // profiling builds (tools/phase_profile_3d.py): cycles per phase of the substep, summed over wavefronts and launches
 namespace cassie3d { namespace leg { __device__ unsigned long long k5c_phase[16]; } }
 #define LEG3_PHASE_BEGIN unsigned long long t_last_ = __builtin_readcyclecounter(), sw_[3] = {0ull, 0ull, 0ull};
 #define LEG3_MARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&::cassie3d::leg::k5c_phase[k], n_ - t_last_); t_last_ = n_; }

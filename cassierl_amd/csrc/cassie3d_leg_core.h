@@ -45,10 +45,10 @@
 namespace cassie3d {
 namespace leg {
 
-#ifndef LEG3_STAT   // instrumented CPU builds only (tests/leg3d_stats.py): counts executed sweeps / limit steps / contact steps / Newton iterations per wavefront
+#ifndef LEG3_STAT   // instrumented CPU builds only (tools/leg3d_stats.py): counts executed sweeps / limit steps / contact steps / Newton iterations per wavefront
 #define LEG3_STAT(k)
 #endif
-#ifndef LEG3_MARK   // profiling builds of the device kernel only (cassie3d_leg.hip, -DCASSIE3D_PHASE_TIMING; tests/phase_profile_3d.py): shader cycles per phase of the substep
+#ifndef LEG3_MARK   // profiling builds of the device kernel only (cassie3d_leg.hip, -DCASSIE3D_PHASE_TIMING; tools/phase_profile_3d.py): shader cycles per phase of the substep
 #define LEG3_PHASE_BEGIN
 #define LEG3_MARK(k)
 #define LEG3_SW_MARK(k)
@@ -782,7 +782,7 @@ template <class B> struct Core3 {
         lfor<0, 6>([&](auto bb) { constexpr int Bc = decltype(bb)::value; at[Bc] = B::fma(ut[Bc], d, at[Bc]); });
       };
       auto eq_step = [&](auto ss, M mine) {   // a connect row: unclamped
-        typename B::OwnerScope scope_(mine);   // op-counting builds of the CPU emulation only (tests/count_flops.py); empty on the device
+        typename B::OwnerScope scope_(mine);   // op-counting builds of the CPU emulation only (tools/count_flops.py); empty on the device
         constexpr int S = decltype(ss)::value;
         const D res = (B::fma(eq[S].R, eq[S].f, eq[S].b) + dot_c(eq[S].jl)) + dot_a(eq[S].ut);
         D d = -(res * eq[S].ai);

@@ -12,7 +12,7 @@
 //   contact force of site c:  fx = mu (l1 - l2), fz = l1 + l2, l >= 0        (generators of the 2-D friction cone)
 //   min (T z + t0)' W (T z + t0) + 1/2 1e-4 sum (fx^2 + fz^2),  u in ctrlrange, lambda >= 0
 // i.e. a 14-variable box-constrained strictly convex QP, solved by a primal active-set method whose linear systems are
-// 14x14 masked Gauss-Jordan solves with rows on lanes (tests/planar_proto.py::box_qp is the executable spec; the oracle
+// 14x14 masked Gauss-Jordan solves with rows on lanes (tools/planar_proto.py::box_qp is the executable spec; the oracle
 // solves the reference's literal 39-variable formulation, so parity also checks this reduction).
 #ifndef CASSIE_CTRL_HIP_
 #define CASSIE_CTRL_HIP_

@@ -8,7 +8,7 @@
 // the state record) followed by the physics kernel of cassie_kernels_g16.hip in MODE 2 (one mj_step with the commands of the
 // record; with the observation / reward / reset section on the last substep of an Env.step).
 //
-// Why two kernels (r02, tests/phase_profile.py): fused into one kernel the controller's ~500 registers and 8.6 KB of LDS per
+// Why two kernels (r02, tools/phase_profile.py): fused into one kernel the controller's ~500 registers and 8.6 KB of LDS per
 // environment held the whole kernel at ONE wavefront per SIMD, and 62-71 % of its time was the physics substep running
 // latency-bound at half the issue rate it reaches in its own kernel (2 wavefronts per SIMD).  The price of the split is one
 // round trip of the 704-byte state record through HBM/L2 per substep (~90 MB per substep at 65 536 envs: ~15 us).
@@ -20,14 +20,14 @@
 namespace cassie {
 namespace g16 {
 
-// LDS of one environment for the controller kernel: 582 doubles = 4.7 KB, 18.6 KB per wavefront, so that EIGHT wavefronts
-// (two per SIMD) share the 160 KB of a CU -- the kernel is latency-bound (r03 PMC: 10.7 cycles per VALU instruction at one
-// wavefront per SIMD), a second wavefront hides most of that.  r02 had 1035 doubles (33 KB per wavefront, one per SIMD).
+// LDS of one environment for the controller kernel: 414 doubles = 3.3 KB, 13.2 KB per wavefront, so that TWELVE wavefronts
+// (three per SIMD) share the 160 KB of a CU -- the kernel is latency-bound (r03 PMC: 10.7 cycles per VALU instruction at one
+// wavefront per SIMD), every further wavefront hides part of that.  r02 had 1035 doubles (33 KB per wavefront, one per SIMD),
+// r03..r05 582 (two per SIMD).
 // The layout is also the controller's scratch (the `cs` argument of cassie_ctrl.hip is this same object).  Three things make
 // it small:
-//   * buffers with disjoint lifetimes share storage: the kinematics / mass-matrix exchange arrays are dead once the
-//     controller rows and Hinv exist (the lds_sync after the rows in ctrl_dyn), which is where JH, S4 and T / U are born;
-//     the stale-kinematics inputs kq / kv are only read by scripted_targets, before ctrl_dyn writes acc / bias;
+//   * buffers with disjoint lifetimes share storage (the 300-double overlay below; the stale-kinematics inputs kq / kv are only
+//     read by scripted_targets, before ctrl_dyn writes acc / bias);
 //   * controller rows are kept compact (3 base + 5 own-leg columns instead of 13);
 //   * Hinv is symmetric and stored as a packed upper triangle (91 instead of 169 doubles).
 struct EnvLdsC {

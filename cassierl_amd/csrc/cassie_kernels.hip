@@ -673,7 +673,7 @@ __device__ __forceinline__ void substep(Smem& sm, const LaneConst& c, int lane, 
     res += aN * Dn + aT * Dt;
   };
   int niter = 0;
-#ifndef K1_ITERS   // timing builds only (tests/k1_latency.py): fewer sweeps, to separate the solver from the rest of a substep
+#ifndef K1_ITERS   // timing builds only (tools/k1_latency.py): fewer sweeps, to separate the solver from the rest of a substep
 #define K1_ITERS CP_ITERATIONS
 #endif
   for (int iter = 0; iter < K1_ITERS; iter++) {

@@ -103,7 +103,7 @@ struct DevDuoB : DevB {
     const double* act;
     bool has_act, snap;
     int lo, ao;
-#ifdef CASSIE_PHASE_TIMING   // profiling builds (tests/phase_profile.py duo): shader cycles per phase of this wavefront; the time up to mark(k) goes to bucket k
+#ifdef CASSIE_PHASE_TIMING   // profiling builds (tools/phase_profile.py duo): shader cycles per phase of this wavefront; the time up to mark(k) goes to bucket k
     unsigned long long t_last, acc[16];
     LEG_FN void mark(int k) {
       __builtin_amdgcn_sched_barrier(0);
@@ -183,7 +183,7 @@ constexpr size_t duo_workspace_doubles_per_wave = (size_t)(DDuo::W_N + DUO_WS_PA
 // the headline's 65 536 envs) indexes the workspace by its task number, as r05 did.  A larger batch CLAIMS a slot per wavefront from a table
 // of `mask + 1` busy words (a power of two >= 2 x the chip's SIMDs, one eighth of it per XCD): the first probe is a hash of the wavefront's physical place
 // (XCC, SE, CU, SIMD from HW_REG_XCC_ID / HW_REG_HW_ID) -- two resident wavefronts of this kernel cannot share a SIMD, so the probe finds its
-// word free and the same SIMD comes back to the same 139 KB, launch after launch: 143 MB touched on an MI355X for any batch, Infinity-Cache
+// word free and the same SIMD comes back to the same 176 KB (of which a batch on its feet touches 139), launch after launch: 180 MB touched on an MI355X for any batch (360 MB allocated: two words per SIMD), Infinity-Cache
 // resident (r05 indexed by the task: 1.14 GB at 524 288 envs).  The place is only a HINT: the claim is an atomic compare-and-swap with linear
 // probing, so a collision (another hash layout, a future part, the test mode that zeroes the hint) costs probes (STAT_WS_PROBES), never a
 // result.  The hardware's dispatcher stays the task queue: a wavefront that lost the arbitration for the fabric (-7..+10 % lifetime spread,

@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(64, 2) env_step_g16_kernel(VecParams p, int* p
     const int ev = (int)blockIdx.x * 4 + (opaque((int)threadIdx.x) >> 4);
     return ev < p.n_envs ? (size_t)ev : 0;
   };
-  PhaseClock pc;   // profiling builds only (-DCASSIE_PHASE_TIMING, tests/phase_profile.py physics)
+  PhaseClock pc;   // profiling builds only (-DCASSIE_PHASE_TIMING, tools/phase_profile.py physics)
   pc.start();
   LaneConst c;
   load_lane_const(c, l);  // roles are per 16-lane row

@@ -41,7 +41,7 @@ struct DevB {
     int pdepth[3][64];
     int lmj[4][64];
 #ifdef CASSIE_PHASE_TIMING
-    unsigned long long t_last, acc[16];   // profiling builds: shader cycles per code phase of this wavefront (tests/phase_profile.py leg)
+    unsigned long long t_last, acc[16];   // profiling builds: shader cycles per code phase of this wavefront (tools/phase_profile.py leg)
     LEG_FN void mark(int k) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

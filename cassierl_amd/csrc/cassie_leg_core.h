@@ -60,7 +60,7 @@ constexpr double LH = CP_TIMESTEP;
 constexpr double LMINVAL = 1e-15;
 constexpr int CAP = 8;  // constraint rows per leg
 #define LEG_NPAIR_SLOTS 3   // contact-pair descriptor slots per lane
-#ifndef LEG_STAT_SMALL   // instrumented CPU builds only (tests/small_stats.py): how often a wavefront's group takes the eight-row sweep, and why
+#ifndef LEG_STAT_SMALL   // instrumented CPU builds only (tools/small_stats.py): how often a wavefront's group takes the eight-row sweep, and why
 #define LEG_STAT_SMALL(small, go, nlim, ncon)
 #endif
 #ifndef LEG_ITERS

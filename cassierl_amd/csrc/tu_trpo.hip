@@ -2,7 +2,7 @@
 //
 // One TRPO update evaluates, on the 524 288 samples one rank collects per iteration, the policy gradient and ~11 Fisher-vector
 // products of the 26-32-32-6 tanh policy.  As torch operations a product is ~8 skinny GEMMs (K = 32) and a dozen element-wise passes
-// over [N, 32] tensors: 0.67 ms each, 7.3 ms per update (r04 profile, tests/prof_trpo_update.py).  Here it is ONE launch on the
+// over [N, 32] tensors: 0.67 ms each, 7.3 ms per update (r04 profile, tools/prof_trpo_update.py).  Here it is ONE launch on the
 // matrix cores, exact float32 (v_mfma_f32_32x32x2_f32 = a k-ordered fmaf chain):
 //
 //   * a wavefront owns a tile of 32 samples; every activation-like quantity X (hidden units x samples, 32 x 32) lives in the

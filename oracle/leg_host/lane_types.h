@@ -19,7 +19,7 @@ static_assert(NL >= 2 && NL % 2 == 0, "two lanes per environment");
 #define LANES for (int l = 0; l < NL; l++)
 typedef long long i64;   // every lane type is 64 bits wide, so that one AVX-512 register holds eight lanes of any of them
 
-// Op counting (tests/count_flops.py): every arithmetic operation on a lane value adds 1 per COUNTED lane (a*b+c is written as a
+// Op counting (tools/count_flops.py): every arithmetic operation on a lane value adds 1 per COUNTED lane (a*b+c is written as a
 // multiply and an add in the core: 2); divisions, square roots and reciprocals count 1, sincos 2, exp 1; comparisons and selects 0.
 // Inside a Gauss-Seidel step only the owner leg's lane is counted (the other lane executes the same instructions on values
 // that are thrown away); everywhere else both lanes are.  Compiled out of the timing build.

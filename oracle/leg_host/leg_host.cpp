@@ -1,12 +1,12 @@
 // leg_host.cpp -- CHECKER / CPU-BASELINE INFRASTRUCTURE (lives under oracle/): compiles cassierl_amd/csrc/cassie_leg_core.h (the
 // two-lanes-per-environment Env.step of the HIP kernel cassie_kernels_leg.hip) for the CPU with a lane emulation backend, so that
 //   (a) the CPU test-suite can check the kernel's SOURCE against the oracle before anything runs on a GPU (tests/test_leg_host.py;
-//       LEG_HOST_LANES = 2: one environment per call group, operation counting for tests/count_flops.py), and
+//       LEG_HOST_LANES = 2: one environment per call group, operation counting for tools/count_flops.py), and
 //   (b) bench.py's cpu_baseline leg can time the SAME SOURCE as the HIP kernel on the host cores (BASELINE.md section 3 / SURVEY.md
 //       8(d): "-O3 -march=native, OpenMP over envs"): -DLEG_HOST_FAST -DLEG_HOST_LANES=8 puts four environments into the lanes of
 //       one AVX-512 register (the loops over lanes below are what the compiler vectorises), no operation counting, OpenMP over
 //       groups of environments.
-// Only tests/, bench.py's cpu_baseline leg and tests/count_flops.py build and load this; the product (cassierl_amd/) has no CPU path.
+// Only tests/, bench.py's cpu_baseline leg and tools/count_flops.py build and load this; the product (cassierl_amd/) has no CPU path.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -17,7 +17,7 @@
 #define LEG_FN inline
 #define LEG_NOUNROLL
 #define LEG_FP_CONTRACT_OFF   /* the whole file is compiled with -ffp-contract=off; the step functions write their FMAs out */
-#ifdef LEG_STATS   // tests/small_stats.py: per set-up of a lane group: [0] set-ups, [1] not "small", [2] lanes with a joint limit, [3] lanes with a third pair
+#ifdef LEG_STATS   // tools/small_stats.py: per set-up of a lane group: [0] set-ups, [1] not "small", [2] lanes with a joint limit, [3] lanes with a third pair
 #include <atomic>
 static std::atomic<long long> g_small_stat[8];   // [4] set-ups whose worst lane has <= 1 limit and <= 2 pairs, [5] lanes with >= 2 limits, [6] set-ups with any lane over 8 rows
 #define LEG_STAT_SMALL(small, go, nlim, ncon) do { g_small_stat[0]++; if (!(small)) g_small_stat[1]++; bool one_ = true, ovf_ = false; \
