@@ -383,12 +383,12 @@ def run_env_workload(name, n, kind, mode, flags, traj, warmup, steps, action_fn,
         env.step(action_fn(t), out)
     acts = [action_fn(warmup + t) for t in range(steps)]
     env.reset_counters()
-    dones = torch.zeros((), dtype=torch.float64, device="cuda:0")
+    dones = torch.zeros(1, dtype=torch.int64, device="cuda:0")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(steps):
-        _, _, d = env.step(acts[t], out)
-        dones += d.sum()
+        _, r, d = env.step(acts[t], out)
+        env.accumulate(r, d, None, dones)   # episode count of the step (one launch; headline loop: returns too)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = env.counters()
@@ -739,12 +739,13 @@ def worker(args):
     total = args.warmup + args.steps
     actions = [R.random_actions(1, ids, t, low, high) for t in range(total)]  # resident in HBM before timing
     returns = torch.zeros(n_local, dtype=torch.float64, device=device)
-    dones = torch.zeros((), dtype=torch.float64, device=device)
+    dones = torch.zeros(1, dtype=torch.int64, device=device)
     env.reset(out)
+    # Rollout bookkeeping per Env.step: returns += reward (what the one collective gathers) and the episode count, ONE launch of the library
+    # (CassieVecAccumulate; until r06 three torch expressions = four launches, ~30 us of every timed step: profiles/r06_accumulate.txt)
     for t in range(args.warmup):
         _, rew, dn = env.step(actions[t], out)
-        returns += rew
-        dones += dn.sum()
+        env.accumulate(rew, dn, returns, dones)
     # Fixed pre-roll, separate from the caller's --warmup: a fresh process on a fresh box ramps its clocks over the first few
     # hundred milliseconds (r02: the driver's `--warmup 5` left the 20 timed steps 19 % slower than steady state), so Env.steps
     # of the same workload run for at least PREROLL_SECONDS before the timed region, whatever --warmup says.  Their actions come
@@ -765,9 +766,8 @@ def worker(args):
     preroll_steps = preroll_count(n_local)
     torch.cuda.synchronize()
     for k in range(preroll_steps):   # the timed loop's body, kernel for kernel: the first use of a torch kernel costs its module load
-        _, rew, dn = env.step(pre_actions[k % 10], out)   # (r03: `dn.sum()` first ran inside the timed region -- 8-25 ms of host time in
-        returns += rew                                      # its first step, i.e. 1.6-2.6 ms per step over the driver's 20 steps against
-        dones += dn.sum()                                   # 1.43 in steady state; r02's 15 % driver gap was the same thing)
+        _, rew, dn = env.step(pre_actions[k % 10], out)   # (r03: a torch kernel first ran inside the timed region -- 8-25 ms of host time in
+        env.accumulate(rew, dn, returns, dones)             # its first step; r02's 15 % driver gap was the same thing)
     torch.cuda.synchronize()
     returns.zero_(); dones.zero_()
     env.reset_counters()
@@ -775,15 +775,13 @@ def worker(args):
     R.barrier()
     torch.cuda.synchronize()
     # Two HIP events bracket the timed region on the stream its kernels are launched on (use_torch_stream above): GPU time per
-    # Env.step = the dominant kernel + its ~5 us hand-over pass + the three elementwise kernels of the return accumulation
-    # (~10 us).  (Events around every single step would agree with rocprofv3's per-kernel average even more directly, but their
+    # Env.step = the dominant kernel + its two hand-over passes (~12 us) + the return accumulation (one launch, ~3 us).  (Events around every single step would agree with rocprofv3's per-kernel average even more directly, but their
     # barrier packets cost 0.15 ms per step -- they would change the number being reported.)
     t0 = time.perf_counter()
     kev0.record()
     for t in range(args.warmup, total):
         _, rew, dn = env.step(actions[t], out)
-        returns += rew
-        dones += dn.sum()
+        env.accumulate(rew, dn, returns, dones)
     kev1.record()
     ev0.record()
     all_returns = R.gather_returns(returns)  # the single collective of the rollout batch (RCCL over xGMI)

@@ -20,7 +20,7 @@ EXPORTS = [
     # batched ABI (include/cassie_vec.h)
     "CassieVecCreate", "CassieVecFree", "CassieVecLastError", "CassieVecNumEnvs", "CassieVecActionDim",
     "CassieVecSetStream", "CassieVecSynchronize", "CassieVecGetCounters", "CassieVecResetCounters", "CassieVecTierInfo", "CassieVecQpIterations", "CassieVecSetTrajectory", "CassieVecSetHeightField", "CassieVecReset", "CassieVecResetTo",
-    "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
+    "CassieVecStep", "CassieVecSubstep", "CassieVecStandingStep", "CassieVecAccumulate", "CassieVecGetState", "CassieVecGetOpState", "CassieVecStatePtr",
     "CassieVecStepHost", "CassieVecGetStateHost", "CassieVecSetStateHost", "CassieVecGetFullStateHost",
     "CassieVecDebugSubstepHost", "CassieVecDebugWorkspaceHost", "CassieVecTimeSteps",
     # batched Cassie3d physics (include/cassie3d_vec.h)
@@ -78,6 +78,8 @@ def load():
     L.CassieVecStep.argtypes = [vp, dp, dp, dp, u8p, dp]
     L.CassieVecSubstep.argtypes = [vp, ct.c_int, dp, ct.c_int]
     L.CassieVecStandingStep.argtypes = [vp, ct.c_int, dp, dp, ct.c_int]
+    if hasattr(L, "CassieVecAccumulate"):   # (absent from A/B libraries built from earlier sources: CASSIE2D_LIB)
+        L.CassieVecAccumulate.argtypes = [vp, dp, u8p, dp, vp]
     L.CassieVecGetState.argtypes = [vp, dp, dp]
     L.CassieVecGetOpState.argtypes = [vp, dp]
     L.CassieVecStatePtr.argtypes = [vp]

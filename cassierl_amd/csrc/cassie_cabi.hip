@@ -597,6 +597,15 @@ extern "C" int CassieVecPhaseCycles(CassieVec* h, unsigned long long* out16) {  
 }
 #endif
 
+int CassieVecAccumulate(CassieVec* h, const double* reward_dev, const uint8_t* done_dev, double* returns_dev, unsigned long long* episodes_dev) {
+  if (!h || (returns_dev && !reward_dev) || (episodes_dev && !done_dev)) return fail(h, CASSIE_EINVAL, "CassieVecAccumulate: an accumulator without its input");
+  if (!returns_dev && !episodes_dev) return CASSIE_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  L2::accumulate_returns(h->n, h->stream, reward_dev, done_dev, returns_dev, episodes_dev);
+  HIPCHK(h, hipGetLastError());
+  return CASSIE_OK;
+}
+
 int CassieVecResetCounters(CassieVec* h) {
   if (!h) return CASSIE_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));

@@ -28,6 +28,7 @@ void reset_hf(int n_envs, hipStream_t s, const VecParams& p, const uint8_t* mask
 void opstate(int n_envs, hipStream_t s, const VecParams& p, double* out18);
 void init_state(int n_envs, hipStream_t s, double* state);
 void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel);
+void accumulate_returns(int n_envs, hipStream_t s, const double* reward, const uint8_t* done, double* returns, unsigned long long* episodes);
 // tu_g16.hip: four environments per wavefront
 void step_g16(int mode, int n_envs, hipStream_t s, const VecParams& p, int* pending);
 // tu_leg.hip: two lanes per environment (one per leg), 32 environments per wavefront; environments that need more than 8 rows on

@@ -26,6 +26,9 @@ void opstate(int n_envs, hipStream_t s, const VecParams& p, double* out18) {
 void init_state(int n_envs, hipStream_t s, double* state) {
   hipLaunchKernelGGL(env_init_kernel, dim3((n_envs * ENV_STRIDE + 255) / 256), dim3(256), 0, s, state, n_envs);
 }
+void accumulate_returns(int n_envs, hipStream_t s, const double* reward, const uint8_t* done, double* returns, unsigned long long* episodes) {
+  hipLaunchKernelGGL(accumulate_returns_kernel, dim3((n_envs + 1023) / 1024), dim3(1024), 0, s, reward, done, returns, episodes, n_envs);
+}
 void get_state(int n_envs, hipStream_t s, const double* state, double* qpos, double* qvel) {
   hipLaunchKernelGGL(get_state_kernel, dim3((n_envs * 13 + 255) / 256), dim3(256), 0, s, state, n_envs, qpos, qvel);
 }

@@ -271,6 +271,14 @@ class CassieVecEnv:
                                        out["done"].data_ptr(), None if terminal_obs is None else terminal_obs.data_ptr()))
         return out["obs"], out["reward"], out["done"]
 
+    def accumulate(self, reward, done, returns=None, episodes=None):
+        """Rollout bookkeeping of one Env.step in one launch on the env's stream: `returns += reward` (float64 CUDA tensors [n_envs]) and
+        `episodes += done.count_nonzero()` (`episodes`: int64 CUDA tensor with one element).  Either accumulator may be None."""
+        assert returns is None or (returns.is_cuda and returns.element_size() == 8 and returns.numel() == self.n_envs and returns.is_contiguous())
+        assert episodes is None or (episodes.is_cuda and episodes.element_size() == 8 and episodes.numel() == 1)
+        self._chk(self.L.CassieVecAccumulate(self.h, reward.data_ptr(), done.data_ptr(), None if returns is None else returns.data_ptr(),
+                                             None if episodes is None else episodes.data_ptr()))
+
     def time_steps(self, actions, steps, out=None):
         """Average kernel time (ms) of `steps` back-to-back Env.steps, HIP events on the env's stream."""
         out = out or self.alloc()

@@ -126,6 +126,11 @@ int CassieVecSubstep(CassieVec* h, int control_mode, const double* actions_dev, 
  * changes them every call, so a squat is n_sub = 1 with new targets per call) */
 int CassieVecStandingStep(CassieVec* h, int control_mode, const double* zpos_dev, const double* zvel_dev, int n_sub);
 
+/* Rollout bookkeeping of one Env.step for the whole batch, one launch on the handle's stream: returns_dev[e] += reward_dev[e]
+ * (the undiscounted return a sampler sums per path -- rllab's `rollout`, external to the reference tree; the north star gathers
+ * these once per rollout batch) and *episodes_dev += number of non-zero done_dev flags.  Either accumulator may be NULL. */
+int CassieVecAccumulate(CassieVec* h, const double* reward_dev, const uint8_t* done_dev, double* returns_dev, unsigned long long* episodes_dev);
+
 int CassieVecGetState(CassieVec* h, double* qpos_dev, double* qvel_dev);      /* [n][13] each */
 int CassieVecGetOpState(CassieVec* h, double* x18_dev);                      /* [n][18], operational_state_to_array order */
 void* CassieVecStatePtr(CassieVec* h);                                       /* device pointer to [n][CASSIE_STATE_STRIDE] */

@@ -542,6 +542,40 @@ def test_terminal_observation_on_a_caller_stream(vec, streams, traj, flags):
     env.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 1024, 4141, 65536])
+def test_accumulate_is_the_torch_bookkeeping_in_one_launch(vec, n, traj):
+    """CassieVecAccumulate (`returns += reward; episodes += done.count_nonzero()` on the env's stream) against the torch expressions it
+    replaces in the rollout loops, on the rewards / flags the env itself produces and on ragged synthetic ones; either accumulator
+    may be absent; an accumulator without its input is an error."""
+    import torch
+    from cassierl_amd import rollout as R
+    env = vec(n, kind="walk", control_mode="PD", n_substeps=10, auto_reset=True)
+    env.set_trajectory(traj["time"], traj["qpos"])
+    env.use_torch_stream()
+    out = env.alloc()
+    env.reset(out)
+    ids = torch.arange(n, device="cuda")
+    low, high = env.action_space.low, env.action_space.high
+    ret = torch.zeros(n, dtype=torch.float64, device="cuda"); ep = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ret_ref = torch.zeros_like(ret); ep_ref = 0
+    for t in range(4):
+        _, rew, dn = env.step(R.random_actions(3, ids, t, low, high), out)
+        env.accumulate(rew, dn, ret, ep)
+        ret_ref += rew; ep_ref += int(dn.count_nonzero())
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    rew = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    dn = (torch.rand(n, device="cuda", generator=g) < 0.3).to(torch.uint8) * 7   # any non-zero byte is a done flag
+    env.accumulate(rew, dn, ret, ep)
+    ret_ref += rew; ep_ref += int(dn.count_nonzero())
+    env.accumulate(rew, dn, None, ep); ep_ref += int(dn.count_nonzero())       # episodes only
+    env.accumulate(rew, dn, ret, None); ret_ref += rew                          # returns only
+    env.synchronize()
+    assert torch.equal(ret, ret_ref) and int(ep.item()) == ep_ref
+    assert env.L.CassieVecAccumulate(env.h, None, dn.data_ptr(), ret.data_ptr(), None) < 0
+    assert env.L.CassieVecAccumulate(env.h, rew.data_ptr(), None, None, ep.data_ptr()) < 0
+    env.close()
+
+
 def test_error_behaviour_of_the_batched_abi(vec):
     """int error codes + CassieVecLastError instead of the reference's process exit (mju_error, Cassie2d.cpp:49-52)."""
     import ctypes as ct2
